@@ -1,0 +1,274 @@
+"""Generate the golden fixtures by running the REFERENCE itself (build container only).
+
+    python tests/golden/make_golden.py        # writes tests/golden/*.npz, *.json
+
+The reference (/root/reference) is imported through ref_loader.py; only inputs/outputs (plain arrays)
+are stored.  Tests re-create inputs/params from the seeds in recipe.py.  Fixture map:
+  f0 state-dict keys/shapes         f1 integer/index ops           f2 calc_rel_pos_spatial
+  f3 Attention (full)               f4 RVSA sampling grid          f5 RVSA attention fwd+grads
+  f6 Mlp/Block/PatchEmbed/Norm2d/fpn  f7 ViT-B whole forward (cfg 1)  f8 small whole model fwd+grads(+bf16 autocast)
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_loader import load_reference  # noqa: E402
+import recipe  # noqa: E402
+
+ref = load_reference()
+torch.set_num_threads(8)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def build(embed_dim, depth, heads, interval, out_indices, img_size=224, drop_path_rate=0.0, seed=2023):
+    net = quiet(ref.ViT_Win_RVSA_V3_WSZ7, img_size=img_size, patch_size=16, drop_path_rate=drop_path_rate,
+                out_indices=out_indices, embed_dim=embed_dim, depth=depth, num_heads=heads, mlp_ratio=4,
+                qkv_bias=True, use_abs_pos_emb=True, interval=interval, use_rel_pos_bias=True)
+    shapes = recipe.state_shapes(embed_dim, depth, heads, interval, img_size)
+    sd = net.state_dict()
+    float_keys = [k for k, v in sd.items() if v.dtype.is_floating_point]
+    assert float_keys == list(shapes.keys()), "state_shapes() order/names differ from the reference"
+    for k in float_keys:
+        assert tuple(sd[k].shape) == tuple(shapes[k]), k
+    msg = net.load_state_dict(recipe.make_params(shapes, seed), strict=False)
+    assert not msg.unexpected_keys and all("relative_position_index" in k for k in msg.missing_keys), msg
+    return net, shapes
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------ f0: state dict keys
+def f0():
+    rec = {}
+    for tag, cfg in {"vit_b": (768, 12, 12, 3), "small": (128, 6, 2, 3)}.items():
+        net = quiet(ref.ViT_Win_RVSA_V3_WSZ7, img_size=224, embed_dim=cfg[0], depth=cfg[1], num_heads=cfg[2], interval=cfg[3],
+                    qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
+        rec[tag] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+
+    class A:
+        image_size = 224
+        use_ckpt = "False"
+    for tag, fac in (("factory_b", ref.vit_b_rvsa), ("factory_l", ref.vit_l_rvsa)):
+        net = quiet(fac, A)
+        rec[tag] = dict(n_params=sum(p.numel() for p in net.parameters()), out_indices=list(net.out_indices), interval=net.interval,
+                        depth=len(net.blocks), embed_dim=net.embed_dim, out_channels=list(net.out_channels),
+                        heads=net.blocks[0].attn.num_heads,
+                        window_blocks=[isinstance(b.attn, ref.RotatedVariedSizeWindowAttention) for b in net.blocks],
+                        drop_path=[(b.drop_path.drop_prob if isinstance(b.drop_path, ref.DropPath) else 0.0) for b in net.blocks],
+                        num_layers=net.get_num_layers(), no_weight_decay=sorted(net.no_weight_decay()),
+                        patch_shape=list(net.patch_embed.patch_shape), n_keys=len(net.state_dict()))
+        del net
+    with open(os.path.join(HERE, "f0_state_keys.json"), "w") as f:
+        json.dump(rec, f)
+    print("f0_state_keys.json")
+
+
+# ------------------------------------------------------------------ f1: integer ops
+def f1():
+    att = quiet(ref.RotatedVariedSizeWindowAttention, 128, 2, window_size=(7, 7))
+    out = {"relative_position_index": att.relative_position_index}
+    # dist tables via behaviour: table row r carries value r in channel 0, q = e0  => attn == dist index
+    for k in (7, 14):
+        tab = torch.zeros(2 * k - 1, 4)
+        tab[:, 0] = torch.arange(2 * k - 1)
+        q = torch.zeros(1, 1, k * k, 4)
+        q[..., 0] = 1
+        a = ref.calc_rel_pos_spatial(torch.zeros(1, 1, k * k, k * k), q, (k, k), (k, k), tab, torch.zeros_like(tab))
+        out["dist_h_%d" % k] = a.reshape(k, k, k, k)[:, 0, :, 0].long()
+        a = ref.calc_rel_pos_spatial(torch.zeros(1, 1, k * k, k * k), q, (k, k), (k, k), torch.zeros_like(tab), tab)
+        out["dist_w_%d" % k] = a.reshape(k, k, k, k)[0, :, 0, :].long()
+    x = torch.arange(2 * 14 * 21 * 3).reshape(2, 14, 21, 3)
+    w = ref.window_partition(x, 7)
+    out["wp_in"], out["wp_out"] = x, w
+    out["wr_out"] = ref.window_reverse(w, 7, 14, 21)
+    save("f1_index.npz", **out)
+
+
+# ------------------------------------------------------------------ f2: calc_rel_pos_spatial
+def f2():
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for k in (7, 14):
+        q = torch.randn(2, 3, k * k, 16, generator=g)
+        attn = torch.randn(2, 3, k * k, k * k, generator=g)
+        rh, rw = torch.randn(2 * k - 1, 16, generator=g), torch.randn(2 * k - 1, 16, generator=g)
+        out.update({"q%d" % k: q, "attn%d" % k: attn.clone(), "rh%d" % k: rh, "rw%d" % k: rw,
+                    "out%d" % k: ref.calc_rel_pos_spatial(attn.clone(), q, (k, k), (k, k), rh, rw)})
+    save("f2_relpos.npz", **out)
+
+
+# ------------------------------------------------------------------ f3: full attention module
+def f3():
+    g = torch.Generator().manual_seed(12)
+    C, heads, B = 128, 2, 2
+    att = ref.Attention(C, num_heads=heads, qkv_bias=True, window_size=(14, 14))
+    with torch.no_grad():
+        for p in att.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.2 if p.ndim == 2 and p.shape[1] == 64 else 0.08))
+    x = torch.randn(B, 196, C, generator=g, requires_grad=True)
+    y = att(x, 14, 14)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    save("f3_full_attn.npz", x=x, dy=dy, y=y, dx=x.grad,
+         **{"p_" + n: p for n, p in att.named_parameters()}, **{"g_" + n: p.grad for n, p in att.named_parameters()})
+
+
+# ------------------------------------------------------------------ f4/f5: RVSA
+def _rvsa_module(C, heads, g, zero_heads=False):
+    att = quiet(ref.RotatedVariedSizeWindowAttention, C, heads, window_size=(7, 7), qkv_bias=True)
+    with torch.no_grad():
+        for n, p in att.named_parameters():
+            std = 0.3 if "sampling" in n else (0.2 if ("rel_pos" in n or "table" in n) else 0.08)
+            p.copy_(torch.randn(p.shape, generator=g) * std)
+            if zero_heads and "sampling" in n:
+                p.zero_()
+    return att
+
+
+def f45():
+    g = torch.Generator().manual_seed(13)
+    C, heads, B = 128, 2, 2
+    grids = {}
+    real = F.grid_sample
+
+    def spy(inp, grid, **kw):
+        grids.setdefault("g", grid.detach().clone())
+        return real(inp, grid, **kw)
+
+    out4, out5 = {}, {}
+    for tag, (Hp, Wp), zero in (("a", (14, 14), False), ("b", (32, 32), False), ("c", (16, 12), False), ("z", (14, 14), True)):
+        att = _rvsa_module(C, heads, g, zero)
+        x = torch.randn(B, Hp * Wp, C, generator=g, requires_grad=True)
+        grids.clear()
+        F.grid_sample = spy
+        ref.F.grid_sample = spy
+        try:
+            y = att(x, Hp, Wp)
+        finally:
+            F.grid_sample = real
+            ref.F.grid_sample = real
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        out4["grid_" + tag] = grids["g"]
+        out4["x_" + tag] = x
+        for n, p in att.named_parameters():
+            if "sampling" in n:
+                out4["p_%s_%s" % (tag, n)] = p
+        if tag != "b":
+            out5.update({"x_" + tag: x, "dy_" + tag: dy, "y_" + tag: y, "dx_" + tag: x.grad})
+            out5.update({"p_%s_%s" % (tag, n): p for n, p in att.named_parameters()})
+            out5.update({"g_%s_%s" % (tag, n): p.grad for n, p in att.named_parameters()})
+        else:
+            # padded 32->35 case: keep compact (outputs + input grad summary)
+            s, v = recipe.summarize(y)
+            out4.update({"y_b_sum": s, "y_b_samples": v})
+            out4.update({"pall_b_" + n: p for n, p in att.named_parameters() if "sampling" not in n})
+    save("f4_rvsa_grid.npz", **out4)
+    save("f5_rvsa.npz", **out5)
+
+
+# ------------------------------------------------------------------ f6: Mlp / Block / PatchEmbed / Norm2d / fpn
+def f6():
+    C, heads, B = 128, 2, 2
+    net, shapes = build(C, 3, heads, 3, [0, 1, 2, 2])   # blocks 0,1 window; block 2 full
+    net.eval()
+    g = torch.Generator().manual_seed(14)
+    out = {}
+    x = torch.randn(B, 196, C, generator=g)
+    out["x"] = x
+    out["mlp"] = net.blocks[0].mlp(x)
+    for i, tag in ((0, "win"), (2, "full")):
+        xi = x.clone().requires_grad_(True)
+        y = net.blocks[i](xi, 14, 14)
+        dy = recipe.loss_weights(y.shape, 100 + i)
+        net.zero_grad()
+        y.backward(dy)
+        out["block_%s" % tag] = y
+        out["block_%s_dx" % tag] = xi.grad
+        for n, p in net.blocks[i].named_parameters():
+            out["block_%s_g_%s" % (tag, n)] = p.grad.clone()
+    img = recipe.make_input(B, 224, 224, seed=5)
+    tok, hw = net.patch_embed(img)
+    out["patch_embed"] = tok
+    assert hw == (14, 14)
+    fm = torch.randn(B, C, 14, 14, generator=g)
+    out["fm"] = fm
+    out["norm2d"] = net.fpn1[1](fm)
+    out["fpn1"], out["fpn2"], out["fpn4"] = net.fpn1(fm), net.fpn2(fm), net.fpn4(fm)
+    save("f6_ops.npz", **out)
+
+
+# ------------------------------------------------------------------ f7: ViT-B whole forward (BASELINE config 1)
+def f7():
+    net, shapes = build(768, 12, 12, 3, [3, 5, 7, 11])
+    net.eval()
+    img = recipe.make_input(2, 224, 224).requires_grad_(True)
+    feats = net(img)
+    out = {}
+    for i, f in enumerate(feats):
+        out["f%d_sum" % i], out["f%d_samples" % i] = recipe.summarize(f)
+        out["f%d_shape" % i] = np.array(f.shape)
+    loss = sum(f.mean() for f in feats)
+    loss.backward()
+    out["loss"] = loss.detach()
+    out["dimg_sum"], out["dimg_samples"] = recipe.summarize(img.grad)
+    for n in ("pos_embed", "blocks.0.attn.sampling_offsets.2.weight", "blocks.2.attn.full_attn_rel_pos_h", "blocks.5.mlp.fc1.weight",
+              "blocks.7.attn.relative_position_bias_table", "blocks.11.attn.qkv.bias", "fpn1.0.weight", "patch_embed.proj.weight"):
+        p = dict(net.named_parameters())[n]
+        out["g_%s_sum" % n], out["g_%s_samples" % n] = recipe.summarize(p.grad)
+    out["norm_has_grad"] = np.array([net.norm.weight.grad is not None])
+    save("f7_vitb.npz", **out)
+
+
+# ------------------------------------------------------------------ f8: small whole model, fwd + all grads, train mode, bf16 autocast
+def f8():
+    net, shapes = build(128, 6, 2, 3, [1, 2, 3, 5])
+    net.train()   # drop_path_rate = 0 -> identical to eval (VIT:495)
+    img = recipe.make_input(2, 224, 224, seed=99).requires_grad_(True)
+    feats = net(img)
+    out = {}
+    loss = 0
+    for i, f in enumerate(feats):
+        out["f%d_sum" % i], out["f%d_samples" % i] = recipe.summarize(f, 2048)
+        loss = loss + (f * recipe.loss_weights(f.shape, 200 + i)).sum()
+    out["f2"], out["f3"] = feats[2], feats[3]
+    loss.backward()
+    out["loss"] = loss.detach()
+    out["dimg_sum"], out["dimg_samples"] = recipe.summarize(img.grad, 2048)
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            out["nograd_" + n] = np.array([1])
+            continue
+        if p.numel() <= 4096:
+            out["g_" + n] = p.grad
+        else:
+            out["gs_%s_sum" % n], out["gs_%s_samples" % n] = recipe.summarize(p.grad, 1024)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        fb = net(img.detach())
+    for i, f in enumerate(fb):
+        out["bf16_f%d_sum" % i], out["bf16_f%d_samples" % i] = recipe.summarize(f.float(), 2048)
+    save("f8_small.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8"]
+    for w in which:
+        globals()[w]()

@@ -1,0 +1,104 @@
+"""Deterministic parameter / input recipes shared by make_golden.py (build container, with the reference)
+and the tests (anywhere, without it).  Fixtures store only outputs; inputs are re-created from seeds."""
+import zlib
+
+import numpy as np
+import torch
+
+
+def state_shapes(embed_dim=768, depth=12, heads=12, interval=3, img_size=224, mlp_ratio=4):
+    """Reference state-dict keys and shapes (float tensors only), in the reference's order
+    (checked against the reference's own state_dict() in make_golden.py -> f0_state_keys.json)."""
+    C, hd = embed_dim, embed_dim // heads
+    Hp = img_size // 16
+    s = {"pos_embed": (1, Hp * Hp, C), "patch_embed.proj.weight": (C, 3, 16, 16), "patch_embed.proj.bias": (C,)}
+    for i in range(depth):
+        p = "blocks.%d." % i
+        window = (i + 1) % interval != 0
+        s[p + "norm1.weight"] = (C,)
+        s[p + "norm1.bias"] = (C,)
+        if window:
+            s[p + "attn.rel_pos_h"] = (13, hd)
+            s[p + "attn.rel_pos_w"] = (13, hd)
+            s[p + "attn.relative_position_bias_table"] = (169, heads)
+            s[p + "attn.sampling_offsets.2.weight"] = (2 * heads, C, 1, 1)
+            s[p + "attn.sampling_offsets.2.bias"] = (2 * heads,)
+            s[p + "attn.sampling_scales.2.weight"] = (2 * heads, C, 1, 1)
+            s[p + "attn.sampling_scales.2.bias"] = (2 * heads,)
+            s[p + "attn.sampling_angles.2.weight"] = (heads, C, 1, 1)
+            s[p + "attn.sampling_angles.2.bias"] = (heads,)
+        else:
+            s[p + "attn.full_attn_rel_pos_h"] = (2 * Hp - 1, hd)
+            s[p + "attn.full_attn_rel_pos_w"] = (2 * Hp - 1, hd)
+        s[p + "attn.qkv.weight"] = (3 * C, C)
+        s[p + "attn.qkv.bias"] = (3 * C,)
+        s[p + "attn.proj.weight"] = (C, C)
+        s[p + "attn.proj.bias"] = (C,)
+        s[p + "norm2.weight"] = (C,)
+        s[p + "norm2.bias"] = (C,)
+        s[p + "mlp.fc1.weight"] = (mlp_ratio * C, C)
+        s[p + "mlp.fc1.bias"] = (mlp_ratio * C,)
+        s[p + "mlp.fc2.weight"] = (C, mlp_ratio * C)
+        s[p + "mlp.fc2.bias"] = (C,)
+    s["norm.weight"] = (C,)
+    s["norm.bias"] = (C,)
+    s["fpn1.0.weight"] = (C, C, 2, 2)
+    s["fpn1.0.bias"] = (C,)
+    s["fpn1.1.ln.weight"] = (C,)
+    s["fpn1.1.ln.bias"] = (C,)
+    s["fpn1.3.weight"] = (C, C, 2, 2)
+    s["fpn1.3.bias"] = (C,)
+    s["fpn2.0.weight"] = (C, C, 2, 2)
+    s["fpn2.0.bias"] = (C,)
+    return s
+
+
+def _std_for(name):
+    if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("ln.weight") or name == "norm.weight":
+        return None  # 1 + 0.1 N
+    if "sampling_" in name:
+        return 0.04
+    if "rel_pos" in name or "relative_position_bias_table" in name:
+        return 0.1     # zero at init in the reference; randomised so the branch is exercised
+    if name.endswith(".bias"):
+        return 0.02
+    if name == "pos_embed":
+        return 0.02
+    if name.startswith("fpn") or name.startswith("patch_embed"):
+        return 0.03
+    return 0.02
+
+
+def make_params(shapes, seed=2023, dtype=torch.float32):
+    """name -> tensor, drawn per-name from a generator seeded by (seed, crc32(name)) so that subsets agree."""
+    out = {}
+    for name, shape in shapes.items():
+        g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(name.encode()) % 1000003)
+        t = torch.randn(*shape, generator=g, dtype=torch.float32)
+        std = _std_for(name)
+        t = 1.0 + 0.1 * t if std is None else std * t
+        out[name] = t.to(dtype)
+    return out
+
+
+def make_input(B, H, W, seed=2023):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, 3, H, W, generator=g)
+
+
+def loss_weights(shape, seed):
+    """Fixed pseudo-random cotangent for a feature map (so gradients exercise every element)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) / float(np.prod(shape[1:])) ** 0.5
+
+
+def sample_indices(numel, n=512, seed=7):
+    rng = np.random.RandomState(seed)
+    return np.sort(rng.choice(numel, size=min(n, numel), replace=False))
+
+
+def summarize(t, n=512, seed=7):
+    """(sum, abs-sum, sampled values) of a tensor -- compact pin for big outputs."""
+    a = t.detach().double().reshape(-1).numpy()
+    idx = sample_indices(a.size, n, seed)
+    return np.array([a.sum(), np.abs(a).sum()]), a[idx].astype(np.float32)

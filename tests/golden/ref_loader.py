@@ -1,0 +1,58 @@
+"""Import the reference backbone (THIS CONTAINER ONLY) with in-memory stubs.
+
+The reference file /root/reference/Multi-Task_Pretrain/backbone/vit_win_rvsa_v3_wsz7.py
+needs four symbols that are not installed here:
+  timm.models.layers.{drop_path, to_2tuple, trunc_normal_}  (VIT:22)
+  mmengine.dist.get_dist_info                                 (VIT:24)
+They touch init/RNG helpers only, none of the arithmetic under test.
+
+This module is used only by make_golden.py; it is never imported by tests,
+bench.py or the product (the reference does not exist on the GPU box).
+"""
+import importlib.util
+import sys
+import types
+
+import torch
+
+REF_VIT = "/root/reference/Multi-Task_Pretrain/backbone/vit_win_rvsa_v3_wsz7.py"
+
+
+def _drop_path(x, drop_prob: float = 0.0, training: bool = False):
+    if drop_prob == 0.0 or not training:
+        return x
+    keep = 1 - drop_prob
+    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+    mask = keep + torch.rand(shape, dtype=x.dtype, device=x.device)
+    mask.floor_()
+    return x.div(keep) * mask
+
+
+def _to_2tuple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def load_reference():
+    if "ref_vit" in sys.modules:
+        return sys.modules["ref_vit"]
+    timm = types.ModuleType("timm")
+    timm_models = types.ModuleType("timm.models")
+    timm_layers = types.ModuleType("timm.models.layers")
+    timm_layers.drop_path = _drop_path
+    timm_layers.to_2tuple = _to_2tuple
+    timm_layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    timm.models = timm_models
+    timm_models.layers = timm_layers
+    mmengine = types.ModuleType("mmengine")
+    mmengine_dist = types.ModuleType("mmengine.dist")
+    mmengine_dist.get_dist_info = lambda: (0, 1)
+    mmengine.dist = mmengine_dist
+    for name, mod in [("timm", timm), ("timm.models", timm_models),
+                      ("timm.models.layers", timm_layers),
+                      ("mmengine", mmengine), ("mmengine.dist", mmengine_dist)]:
+        sys.modules.setdefault(name, mod)
+    spec = importlib.util.spec_from_file_location("ref_vit", REF_VIT)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_vit"] = mod
+    spec.loader.exec_module(mod)
+    return mod
