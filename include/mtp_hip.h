@@ -1,0 +1,154 @@
+/* libmtp_hip.so -- C ABI of the MI355X-native (gfx950) ViT+RVSA backbone hot path of ViTAE-Transformer/MTP.
+ *
+ * Drop-in boundary.  The reference's only native-operator precedent is DCNv3's
+ * pybind pair dcnv3_forward / dcnv3_backward (Multi-Task_Pretrain/backbone/ops_dcnv3/src/vision.cpp:14-17,
+ * dcnv3.h:20-59): contiguous device tensors in, work on the current stream, no hidden sync.  For the ViT/RVSA
+ * path the reference has NO native ops -- every entry point below replaces a chain of ATen library calls made by
+ * Multi-Task_Pretrain/backbone/vit_win_rvsa_v3_wsz7.py ("VIT"), cited per function.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every buffer (inputs, outputs, workspaces) is owned by the CALLER
+ *     (torch's caching allocator on the Python side) -- nothing is allocated or freed in here;
+ *   - every call is asynchronous on `stream`, never synchronises, keeps no global mutable state, and may be
+ *     issued concurrently on different streams;
+ *   - inputs must be contiguous (leading dimensions are passed where a kernel supports strides) and 16-byte
+ *     aligned; token tensors are row-major (T, C) with T = B*Hp*Wp (row t = (b, y, x));
+ *   - return value: 0 = launched; MTP_ERR_* (<0) = argument check failed (nothing launched); >0 = hipError_t;
+ *   - dtype arguments use mtp_dtype; "ACT" tensors are bf16 (throughput mode) or f32 (parity mode); statistics,
+ *     parameters, parameter gradients and the residual stream are always f32.
+ */
+#ifndef MTP_HIP_H_
+#define MTP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mtp_stream_t; /* hipStream_t */
+
+typedef enum { MTP_F32 = 0, MTP_BF16 = 1 } mtp_dtype;
+
+enum { MTP_OK = 0, MTP_ERR_ARG = -1, MTP_ERR_UNSUPPORTED = -2 };
+
+/* GEMM epilogues (fused elementwise work of VIT:55-62, 506-513, 793-794) */
+typedef enum {
+    MTP_EPI_BIAS = 0,      /* C = acc + bias                          (bias may be NULL)                   */
+    MTP_EPI_BIAS_GELU = 1, /* aux = acc + bias (pre-activation u);  C = gelu(u)            nn.GELU erf   */
+    MTP_EPI_BIAS_RES = 2,  /* C(f32) = res[row % res_mod] + rowscale[row / rows_per_sample] * (acc + bias) */
+    MTP_EPI_DGELU = 3      /* C = acc * gelu'(aux)                                                         */
+} mtp_epilogue;
+
+typedef struct {
+    const void* A;      /* NT: (M, K) row-major, lda.   TN: (Kc, M) row-major, lda                         */
+    const void* B;      /* NT: (N, K) row-major, ldb.   TN: (Kc, N) row-major, ldb                         */
+    void* C;            /* (M, N) row-major, ldc                                                          */
+    int64_t M, N, K;    /* K = contraction length                                                         */
+    int64_t lda, ldb, ldc;
+    int in_dtype;       /* mtp_dtype of A and B                                                           */
+    int out_dtype;      /* mtp_dtype of C (and aux)                                                       */
+    int epilogue;       /* mtp_epilogue (NT only)                                                         */
+    const float* bias;  /* [bias_mod ? bias_mod : N] or NULL                                              */
+    int64_t bias_mod;   /* bias index = n % bias_mod when > 0 (ConvTranspose2d bias repeated per tap)      */
+    const float* res;   /* EPI_BIAS_RES: f32 (res rows, N), ld res_ld                                     */
+    int64_t res_ld, res_mod;
+    const float* rowscale; /* EPI_BIAS_RES: per-sample drop-path factor or NULL                           */
+    int64_t rows_per_sample;
+    void* aux;          /* EPI_BIAS_GELU: u out;  EPI_DGELU: u in;  (M, N), ld aux_ld, dtype out_dtype     */
+    int64_t aux_ld;
+    int split_k;        /* TN only: >1 = split the contraction over gridDim.z, f32 atomicAdd into zeroed C */
+    int variant;        /* 0 = default; 1 = register-staged NT loads instead of direct-to-LDS (debug/A-B)  */
+} mtp_gemm_args;
+
+/* y = x W^T (+epilogue): nn.Linear fwd/dgrad (VIT:50,52,78,87,256,262), patch-embed conv as GEMM (VIT:529),
+ * ConvTranspose2d(2,2) as GEMM (VIT:642-649).  C[m][n] = sum_k A[m][k] * B[n][k]. */
+int mtp_gemm_nt(const mtp_gemm_args* args, mtp_stream_t stream);
+/* weight gradient: C[m][n] = sum_k A[k][m] * B[k][n]  (dW = dY^T X), f32 output. */
+int mtp_gemm_tn(const mtp_gemm_args* args, mtp_stream_t stream);
+
+/* nn.LayerNorm(C, eps) over the last dim (VIT:484,496,579,596); optional fused exact GELU (fpn1: Norm2d -> GELU,
+ * VIT:643-644).  x: (rows, C) in x_dtype; y in y_dtype; mean/rstd f32 (rows). */
+int mtp_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                      float* mean, float* rstd, int64_t rows, int64_t C, float eps, int fuse_gelu, mtp_stream_t stream);
+/* dx_out(f32 or ACT) = [dres] + [extra] + LN'(dy);  dx_copy (ACT, optional) = copy_scale[row / rows_per_sample] * dx_out;
+ * dgamma/dbeta partials: (nblk, C) f32 each where nblk = mtp_layernorm_bwd_partial_rows(rows). */
+int64_t mtp_layernorm_bwd_partial_rows(int64_t rows);
+int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int fuse_gelu,
+                      const float* dres, const float* extra, void* dx, int dx_dtype,
+                      void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
+                      float* dgamma_part, float* dbeta_part, int64_t rows, int64_t C, mtp_stream_t stream);
+/* out[c] (+)= sum_r part[r][c]   (also used for bias gradients) */
+int mtp_reduce_rows_f32(const float* part, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);
+/* bias gradient: out[n] = sum_m dY[m][n] */
+int mtp_colsum(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream);
+
+/* ---- layout / elementwise ------------------------------------------------------------------------------- */
+/* PatchEmbed im2col (VIT:529,536-539): img f32 NCHW -> cols (B*Hp*Wp, Cin*P*P) ACT, K order (c, ky, kx). */
+int mtp_patchify(const float* img, void* cols, int dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, mtp_stream_t stream);
+int mtp_unpatchify(const void* cols, int dtype, float* dimg, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, mtp_stream_t stream);
+int mtp_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, mtp_stream_t stream);
+/* dst (C, R) = src (R, C)^T with dtype conversion (weight copies for dgrad) */
+int mtp_transpose_cast(const float* src, void* dst, int dst_dtype, int64_t R, int64_t C, mtp_stream_t stream);
+/* ConvTranspose2d weight (Cin, Cout, 2, 2) f32 -> GEMM weight wg (4*Cout, Cin) and its transpose wgT (Cin, 4*Cout) */
+int mtp_convt_pack(const float* w, void* wg, void* wgT, int dtype, int64_t Cin, int64_t Cout, mtp_stream_t stream);
+/* dwg (4*Cout, Cin) f32 -> dw (Cin, Cout, 2, 2) f32 */
+int mtp_convt_unpack_grad(const float* dwg, float* dw, int64_t Cin, int64_t Cout, mtp_stream_t stream);
+/* rows (b, py, px, q_1..q_L) x C -> NCHW (B, C, Hp*2^L, Wp*2^L)  (VIT:807 + ConvT pixel shuffle) and back */
+int mtp_tokens_to_nchw(const void* x, int x_dtype, void* out, int out_dtype, int64_t B, int64_t Hp, int64_t Wp, int64_t C, int levels, mtp_stream_t stream);
+int mtp_nchw_to_tokens(const void* f, int f_dtype, void* out, int out_dtype, int64_t B, int64_t Hp, int64_t Wp, int64_t C, int levels, mtp_stream_t stream);
+/* fpn4 = MaxPool2d(2,2) (VIT:654) on token-major x (T,C) f32 -> y (B*(Hp/2)*(Wp/2), C) token-major (then mtp_tokens_to_nchw);
+ * bwd routes dy to the FIRST maximum of each 2x2 window (torch's tie rule); dx (T,C) f32 */
+int mtp_maxpool2_tokens_fwd(const float* x, void* y, int y_dtype, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream);
+int mtp_maxpool2_tokens_bwd(const float* x, const void* dy, int dy_dtype, float* dx, int accumulate, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream);
+int mtp_axpy_f32(float* y, const float* x, float alpha, int64_t n, mtp_stream_t stream);
+/* dst (rows, C) ACT = scale[row / rows_per_sample] * src (rows, C) f32   (scale may be NULL = plain cast) */
+int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, const float* scale, int64_t rows_per_sample, int64_t rows, int64_t C, mtp_stream_t stream);
+
+/* ---- attention --------------------------------------------------------------------------------------------- */
+/* Attention.forward core (VIT:97-108 + calc_rel_pos_spatial VIT:142-193): qkv (T,3C) ACT [q|k|v][head][hd] ->
+ * o (T,C) ACT; lse (B, heads, N) f32.  logits = s*q.k + s*q.Rh[hq-hk+Hp-1] + s*q.Rw[wq-wk+Wp-1]. */
+int mtp_full_attn_fwd(const void* qkv, void* o, float* lse, int dtype, const float* rel_h, const float* rel_w,
+                      int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream);
+/* drel partials: (B*heads, 2*Hp-1 + 2*Wp-1, hd) f32, reduced by mtp_reduce_rows_f32 */
+int mtp_full_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int dtype,
+                      const float* rel_h, const float* rel_w, float* drel_part,
+                      int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream);
+
+/* RVSA sampling heads, stage 1 (VIT:347 zero pad, AvgPool2d(7,7), LeakyReLU): x (T,C) ACT -> avg, pooled (B*nh*nw, C) f32 */
+int mtp_rvsa_pool_fwd(const void* x, int dtype, float* avg, float* pooled, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream);
+/* dx (T,C) ACT += / = dpooled * leaky'(avg) / 49 broadcast over the window */
+int mtp_rvsa_pool_bwd(const float* dpooled, const float* avg, void* dx, int dtype, int accumulate, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream);
+/* small f32 linear for the three 1x1 conv heads (VIT:231,236,242): y (R,N) = x (R,K) W(N,K)^T + b; and its backward */
+int mtp_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t R, int64_t N, int64_t K, mtp_stream_t stream);
+int mtp_small_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t R, int64_t N, int64_t K, mtp_stream_t stream);
+/* RotatedVariedSizeWindowAttention core (VIT:312-428): samp (B*nh*nw, 5*heads) f32 = [off(h,2)|scale(h,2)|angle(h)];
+ * lse (B, heads, nh*nw, 49) f32 */
+int mtp_rvsa_attn_fwd(const void* qkv, const float* samp, void* o, float* lse, int dtype,
+                      const float* rel_h, const float* rel_w, const float* bias_table,
+                      int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream);
+/* dqkv (T,3C) ACT: q part written directly; k/v parts are scattered through the bilinear weights with f32 atomics into
+ * dkv_f32 (T, 2C) (zeroed by the callee) and then converted into dqkv by the callee.  dsamp (B*nh*nw, 5*heads) f32.
+ * rel_part (B*nh*nw*heads, 26*hd) f32 = per-workgroup partials of [drel_h (13,hd) | drel_w (13,hd)];
+ * tab_part (B*nh*nw, heads, 169) f32 = partials of the bias-table gradient (transposed: [head][idx]). */
+int mtp_rvsa_attn_bwd(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse,
+                      void* dqkv, float* dkv_f32, float* dsamp, float* rel_part, float* tab_part, int dtype,
+                      const float* rel_h, const float* rel_w, const float* bias_table,
+                      int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream);
+
+/* ---- optimizer (the step recipe around the path: MAIN:424-457,783-788) ---------------------------------------- */
+/* sum of squares of g[0:n] accumulated into *out (f32, zeroed by caller) -- for clip_grad_norm_ */
+int mtp_sqnorm_f32(const float* g, float* out, int64_t n, mtp_stream_t stream);
+/* AdamW over a flat f32 buffer; per-segment weight decay via sorted seg_start[nseg] (element offsets) and seg_wd[nseg];
+ * hyper (device, f32[6]) = {lr, beta1, beta2, eps, bias_corr1, bias_corr2}; clip_coef = min(1, max_norm / (sqrt(*sqnorm)+1e-6)) if sqnorm */
+int mtp_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_start, const float* seg_wd, int nseg,
+                   const float* hyper, const float* sqnorm, float max_norm, float grad_scale, mtp_stream_t stream);
+
+const char* mtp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTP_HIP_H_ */

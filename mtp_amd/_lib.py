@@ -1,0 +1,88 @@
+"""ctypes binding of libmtp_hip.so (the C ABI declared in include/mtp_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol does not resolve, importing the
+ops raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C mtp_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtp_hip.so")
+
+MTP_F32, MTP_BF16 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU = 0, 1, 2, 3
+
+p, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", p), ("B", p), ("C", p), ("M", i64), ("N", i64), ("K", i64),
+                ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("in_dtype", i32), ("out_dtype", i32), ("epilogue", i32),
+                ("bias", p), ("bias_mod", i64), ("res", p), ("res_ld", i64), ("res_mod", i64),
+                ("rowscale", p), ("rows_per_sample", i64), ("aux", p), ("aux_ld", i64),
+                ("split_k", i32), ("variant", i32)]
+
+
+# name -> (restype, argtypes); must list EVERY function declared in include/mtp_hip.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "mtp_gemm_nt": (i32, [C.POINTER(GemmArgs), p]),
+    "mtp_gemm_tn": (i32, [C.POINTER(GemmArgs), p]),
+    "mtp_layernorm_fwd": (i32, [p, i32, p, p, p, i32, p, p, i64, i64, f32, i32, p]),
+    "mtp_layernorm_bwd_partial_rows": (i64, [i64]),
+    "mtp_layernorm_bwd": (i32, [p, i32, p, i32, p, p, p, p, i32, p, p, p, i32, p, i32, p, i64, p, p, i64, i64, p]),
+    "mtp_reduce_rows_f32": (i32, [p, p, i64, i64, i32, p]),
+    "mtp_colsum": (i32, [p, i32, i64, p, i64, i64, p]),
+    "mtp_patchify": (i32, [p, p, i32, i64, i64, i64, i64, i64, p]),
+    "mtp_unpatchify": (i32, [p, i32, p, i64, i64, i64, i64, i64, p]),
+    "mtp_cast": (i32, [p, i32, p, i32, i64, p]),
+    "mtp_transpose_cast": (i32, [p, p, i32, i64, i64, p]),
+    "mtp_convt_pack": (i32, [p, p, p, i32, i64, i64, p]),
+    "mtp_convt_unpack_grad": (i32, [p, p, i64, i64, p]),
+    "mtp_tokens_to_nchw": (i32, [p, i32, p, i32, i64, i64, i64, i64, i32, p]),
+    "mtp_nchw_to_tokens": (i32, [p, i32, p, i32, i64, i64, i64, i64, i32, p]),
+    "mtp_maxpool2_tokens_fwd": (i32, [p, p, i32, i64, i64, i64, i64, p]),
+    "mtp_maxpool2_tokens_bwd": (i32, [p, p, i32, p, i32, i64, i64, i64, i64, p]),
+    "mtp_axpy_f32": (i32, [p, p, f32, i64, p]),
+    "mtp_scale_rows_cast": (i32, [p, p, i32, p, i64, i64, i64, p]),
+    "mtp_full_attn_fwd": (i32, [p, p, p, i32, p, p, i64, i64, i64, i64, i64, f32, p]),
+    "mtp_full_attn_bwd": (i32, [p, p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
+    "mtp_rvsa_pool_fwd": (i32, [p, i32, p, p, i64, i64, i64, i64, p]),
+    "mtp_rvsa_pool_bwd": (i32, [p, p, p, i32, i32, i64, i64, i64, i64, p]),
+    "mtp_small_linear_fwd": (i32, [p, p, p, p, i64, i64, i64, p]),
+    "mtp_small_linear_bwd": (i32, [p, p, p, p, p, p, i64, i64, i64, p]),
+    "mtp_rvsa_attn_fwd": (i32, [p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
+    "mtp_rvsa_attn_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
+    "mtp_sqnorm_f32": (i32, [p, p, i64, p]),
+    "mtp_adamw_flat": (i32, [p, p, p, p, i64, p, p, i32, p, p, f32, f32, p]),
+    "mtp_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class MtpHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmtp_hip.so and bind every symbol; raises if the HIP extension is missing (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MtpHipError("libmtp_hip.so not found at %s -- build it first (__graft_entry__.build() or make -C mtp_amd/csrc); "
+                          "mtp_amd has no CPU/PyTorch fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported configuration"}.get(rc, "hipError_t %d" % rc)
+        raise MtpHipError("%s failed: %s" % (what, kind))

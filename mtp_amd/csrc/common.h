@@ -1,0 +1,99 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels of the MTP ViT+RVSA backbone path.
+// Written for gfx950 only: 64-wide wavefronts, MFMA 16x16x32 bf16 / 16x16x4 f32, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mtp_hip.h"
+
+#define MTP_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct bf16_t {  // storage-only 16-bit brain float
+    uint16_t bits;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
+    static constexpr int kDtype = MTP_F32;
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<bf16_t> {
+    static constexpr int kPerChunk = 8;
+    static constexpr int kDtype = MTP_BF16;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_bits_to_f32(p->bits); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { p->bits = (uint16_t)f32_to_bf16_bits(v); }
+};
+
+// 4 consecutive elements <-> float4 (vectorised: 16 B for f32, 8 B for bf16)
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_bits_to_f32(v.x & 0xffffu), bf16_bits_to_f32(v.x >> 16), bf16_bits_to_f32(v.y & 0xffffu), bf16_bits_to_f32(v.y >> 16));
+}
+__device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+// 8 consecutive elements (32 B f32 / 16 B bf16)
+__device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
+    float4 a = load4(p), b = load4(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = bf16_bits_to_f32(v.x & 0xffffu); o[1] = bf16_bits_to_f32(v.x >> 16);
+    o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
+    o[4] = bf16_bits_to_f32(v.z & 0xffffu); o[5] = bf16_bits_to_f32(v.z >> 16);
+    o[6] = bf16_bits_to_f32(v.w & 0xffffu); o[7] = bf16_bits_to_f32(v.w >> 16);
+}
+__device__ __forceinline__ void store8(float* p, const float (&o)[8]) {
+    store4(p, make_float4(o[0], o[1], o[2], o[3]));
+    store4(p + 4, make_float4(o[4], o[5], o[6], o[7]));
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&o)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+}
+
+// exact-erf GELU (nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// wave-wide reductions over 64 lanes
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+#define MTP_CHECK_ARG(cond) \
+    do {                    \
+        if (!(cond)) return MTP_ERR_ARG; \
+    } while (0)
+
+static inline int mtp_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

@@ -1,0 +1,550 @@
+// HBM-bound layout / elementwise kernels of the backbone path (gfx950): im2col for the patch embedding, dtype
+// casts and weight (re)packing, token-major <-> NCHW feature-map transposes (FPN tail), MaxPool2d(2,2), small f32
+// linear layers of the RVSA sampling heads, and the flat-buffer optimizer step.  All accesses are 8/16-byte vectors
+// on the contiguous dimension; transposes go through a padded LDS tile so both sides stay coalesced.
+#include "common.h"
+
+namespace {
+
+inline unsigned blocks_for(int64_t n, int per_block, int64_t cap = 1 << 20) {
+    int64_t b = (n + per_block - 1) / per_block;
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ------------------------------------------------------------------------------------------------ patchify
+// cols[t][c*P*P + ky*P + kx] = img[b][c][py*P+ky][px*P+kx], t = (b*Hp + py)*Wp + px   (VIT:529,536-539)
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void patchify_kernel(float* __restrict__ img, T* __restrict__ cols, int B, int Cin, int H, int W, int P, int Hp, int Wp) {
+    const int K4 = Cin * P * P / 4, P4 = P / 4;
+    const int64_t total = (int64_t)B * Hp * Wp * K4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k4 = (int)(i % K4);
+        const int64_t t = i / K4;
+        const int kx4 = k4 % P4, ky = (k4 / P4) % P, c = k4 / (P4 * P);
+        const int px = (int)(t % Wp), py = (int)((t / Wp) % Hp), b = (int)(t / ((int64_t)Wp * Hp));
+        float* ip = img + (((int64_t)b * Cin + c) * H + py * P + ky) * W + px * P + kx4 * 4;
+        T* cp = cols + t * (K4 * 4) + k4 * 4;
+        if (INVERSE)
+            *reinterpret_cast<float4*>(ip) = load4(cp);
+        else
+            store4(cp, *reinterpret_cast<const float4*>(ip));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cast
+template <typename Ts, typename Td>
+__global__ __launch_bounds__(256) void cast_kernel(const Ts* __restrict__ s, Td* __restrict__ d, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) store4(d + 4 * i, load4(s + 4 * i));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) Elem<Td>::store(d + (n4 << 2) + threadIdx.x, Elem<Ts>::load(s + (n4 << 2) + threadIdx.x));
+}
+
+// ------------------------------------------------------------------------------------------------ tiled transposes
+// Generic 64x64 tile through LDS.  "row side": rows (length-C vectors, C contiguous);  "col side": (C, S) with S contiguous.
+//   ROWS2COLS: out[bt][c][s] = in[bt][rowmap(s)][c]      (tokens -> NCHW; weight transpose with rowmap = identity)
+//   else     : out[bt][rowmap(s)][c] = in[bt][c][s]      (NCHW -> tokens)
+// rowmap(s): pixel s = (y, x) of the (Hp<<L, Wp<<L) map -> row ((py*Wp+px)*4 + q1)*4 + q2 ..., q_l = ky_l*2 + kx_l.
+__device__ __forceinline__ int64_t pixel_to_row(int64_t s, int Wp, int L) {
+    if (L == 0) return s;
+    const int Wo = Wp << L;
+    const int y = (int)(s / Wo), x = (int)(s % Wo);
+    int64_t r = (int64_t)(y >> L) * Wp + (x >> L);
+    for (int l = 1; l <= L; ++l) r = r * 4 + (((y >> (L - l)) & 1) << 1) + ((x >> (L - l)) & 1);
+    return r;
+}
+
+template <typename Tin, typename Tout, bool ROWS2COLS>
+__global__ __launch_bounds__(256) void transpose_kernel(const Tin* __restrict__ in, Tout* __restrict__ out, int64_t S, int64_t C, int Wp, int L) {
+    __shared__ float tile[64][65];
+    const int64_t bt = blockIdx.z;
+    const int64_t s0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    const Tin* ib = in + bt * S * C;
+    Tout* ob = out + bt * S * C;
+    const int t = threadIdx.x;
+    const int a = t >> 2, g = (t & 3) * 16;   // a: index on the "slow" side of this phase, g: 16 contiguous elements
+    if (ROWS2COLS) {
+        // read rows: row s0+a, channels c0+g..g+15
+        const int64_t s = s0 + a;
+        if (s < S) {
+            const Tin* rp = ib + pixel_to_row(s, Wp, L) * C + c0 + g;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (c0 + g + 4 * v < C) {
+                    const float4 x = load4(rp + 4 * v);
+                    tile[g + 4 * v + 0][a] = x.x; tile[g + 4 * v + 1][a] = x.y; tile[g + 4 * v + 2][a] = x.z; tile[g + 4 * v + 3][a] = x.w;
+                }
+            }
+        }
+        __syncthreads();
+        // write cols: channel c0+a, positions s0+g..g+15
+        const int64_t c = c0 + a;
+        if (c < C) {
+            Tout* wp = ob + c * S + s0 + g;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t s2 = s0 + g + 4 * v;
+                if (s2 + 3 < S && (S & 3) == 0) {
+                    store4(wp + 4 * v, make_float4(tile[a][g + 4 * v], tile[a][g + 4 * v + 1], tile[a][g + 4 * v + 2], tile[a][g + 4 * v + 3]));
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (s2 + e < S) Elem<Tout>::store(wp + 4 * v + e, tile[a][g + 4 * v + e]);
+                }
+            }
+        }
+    } else {
+        const int64_t c = c0 + a;
+        if (c < C) {
+            const Tin* rp = ib + c * S + s0 + g;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t s2 = s0 + g + 4 * v;
+                if (s2 + 3 < S && (S & 3) == 0) {
+                    const float4 x = load4(rp + 4 * v);
+                    tile[a][g + 4 * v] = x.x; tile[a][g + 4 * v + 1] = x.y; tile[a][g + 4 * v + 2] = x.z; tile[a][g + 4 * v + 3] = x.w;
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (s2 + e < S) tile[a][g + 4 * v + e] = Elem<Tin>::load(rp + 4 * v + e);
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t s = s0 + a;
+        if (s < S) {
+            Tout* wp = ob + pixel_to_row(s, Wp, L) * C + c0 + g;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (c0 + g + 4 * v < C)
+                    store4(wp + 4 * v, make_float4(tile[g + 4 * v][a], tile[g + 4 * v + 1][a], tile[g + 4 * v + 2][a], tile[g + 4 * v + 3][a]));
+        }
+    }
+}
+
+template <bool ROWS2COLS>
+int launch_transpose(const void* in, int in_dt, void* out, int out_dt, int64_t batches, int64_t S, int64_t C, int Wp, int L, hipStream_t s) {
+    if (C % 4) return MTP_ERR_ARG;
+    dim3 grid((unsigned)((S + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)batches), block(256);
+#define MTP_TR(TI, TO) hipLaunchKernelGGL((transpose_kernel<TI, TO, ROWS2COLS>), grid, block, 0, s, (const TI*)in, (TO*)out, S, C, Wp, L)
+    if (in_dt == MTP_F32 && out_dt == MTP_F32) MTP_TR(float, float);
+    else if (in_dt == MTP_F32 && out_dt == MTP_BF16) MTP_TR(float, bf16_t);
+    else if (in_dt == MTP_BF16 && out_dt == MTP_F32) MTP_TR(bf16_t, float);
+    else if (in_dt == MTP_BF16 && out_dt == MTP_BF16) MTP_TR(bf16_t, bf16_t);
+    else return MTP_ERR_UNSUPPORTED;
+#undef MTP_TR
+    return mtp_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ ConvTranspose2d weight packing
+// w (Cin, Cout, 2, 2) -> wg[(q*Cout + co)][ci], wgT[ci][q*Cout + co], q = ky*2+kx
+template <typename T>
+__global__ __launch_bounds__(256) void convt_pack_kernel(const float* __restrict__ w, T* __restrict__ wg, T* __restrict__ wgT, int64_t Cin, int64_t Cout) {
+    const int64_t total = Cin * Cout * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i & 3);
+        const int64_t co = (i >> 2) % Cout, ci = (i >> 2) / Cout;
+        const float v = w[i];
+        if (wg) Elem<T>::store(wg + (q * Cout + co) * Cin + ci, v);
+        if (wgT) Elem<T>::store(wgT + ci * (4 * Cout) + q * Cout + co, v);
+    }
+}
+__global__ __launch_bounds__(256) void convt_unpack_kernel(const float* __restrict__ dwg, float* __restrict__ dw, int64_t Cin, int64_t Cout) {
+    const int64_t total = Cin * Cout * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i & 3);
+        const int64_t co = (i >> 2) % Cout, ci = (i >> 2) / Cout;
+        dw[i] = dwg[(q * Cout + co) * Cin + ci];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ MaxPool2d(2,2) on tokens
+template <typename Tout>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, Tout* __restrict__ y, int B, int Hp, int Wp, int C) {
+    const int Ho = Hp / 2, Wo = Wp / 2, C4 = C / 4;
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const int64_t o = i / C4;
+        const int xo = (int)(o % Wo), yo = (int)((o / Wo) % Ho), b = (int)(o / ((int64_t)Wo * Ho));
+        const float* p = x + (((int64_t)b * Hp + 2 * yo) * Wp + 2 * xo) * C + 4 * c4;
+        const float4 a = load4(p), bb = load4(p + C), c = load4(p + (int64_t)Wp * C), d = load4(p + (int64_t)Wp * C + C);
+        store4(y + o * C + 4 * c4, make_float4(fmaxf(fmaxf(a.x, bb.x), fmaxf(c.x, d.x)), fmaxf(fmaxf(a.y, bb.y), fmaxf(c.y, d.y)),
+                                              fmaxf(fmaxf(a.z, bb.z), fmaxf(c.z, d.z)), fmaxf(fmaxf(a.w, bb.w), fmaxf(c.w, d.w))));
+    }
+}
+// dx[token] (+)= dy[window] where token is the FIRST maximum of its 2x2 window in scan order (torch's tie rule)
+template <typename Tdy>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const Tdy* __restrict__ dy, float* __restrict__ dx, int accumulate,
+                                                         int B, int Hp, int Wp, int C) {
+    const int Ho = Hp / 2, Wo = Wp / 2, C4 = C / 4;
+    const int64_t total = (int64_t)B * Hp * Wp * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const int64_t t = i / C4;
+        const int xx = (int)(t % Wp), yy = (int)((t / Wp) % Hp), b = (int)(t / ((int64_t)Wp * Hp));
+        float4 g = make_float4(0, 0, 0, 0);
+        if (yy < 2 * Ho && xx < 2 * Wo) {
+            const int yo = yy >> 1, xo = xx >> 1, me = ((yy & 1) << 1) | (xx & 1);
+            const float* p = x + (((int64_t)b * Hp + 2 * yo) * Wp + 2 * xo) * C + 4 * c4;
+            float v[4][4];
+            const float4 q0 = load4(p), q1 = load4(p + C), q2 = load4(p + (int64_t)Wp * C), q3 = load4(p + (int64_t)Wp * C + C);
+            v[0][0] = q0.x; v[0][1] = q0.y; v[0][2] = q0.z; v[0][3] = q0.w;
+            v[1][0] = q1.x; v[1][1] = q1.y; v[1][2] = q1.z; v[1][3] = q1.w;
+            v[2][0] = q2.x; v[2][1] = q2.y; v[2][2] = q2.z; v[2][3] = q2.w;
+            v[3][0] = q3.x; v[3][1] = q3.y; v[3][2] = q3.z; v[3][3] = q3.w;
+            const float4 d = load4(dy + (((int64_t)b * Ho + yo) * Wo + xo) * C + 4 * c4);
+            const float dd[4] = {d.x, d.y, d.z, d.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int arg = 0;
+                float m = v[0][e];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (v[k][e] > m) { m = v[k][e]; arg = k; }
+                o[e] = arg == me ? dd[e] : 0.f;
+            }
+            g = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        float* dp = dx + t * C + 4 * c4;
+        if (accumulate) {
+            const float4 old = load4(dp);
+            g.x += old.x; g.y += old.y; g.z += old.z; g.w += old.w;
+        }
+        store4(dp, g);
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] += alpha * x[i];
+}
+
+// ------------------------------------------------------------------------------------------------ RVSA sampling heads
+// zero-pad to (He,We), AvgPool2d(7,7) (divide by 49 always), LeakyReLU(0.01)    (VIT:229-230, 347)
+template <typename T>
+__global__ __launch_bounds__(256) void rvsa_pool_fwd_kernel(const T* __restrict__ x, float* __restrict__ avg, float* __restrict__ pooled,
+                                                           int Hp, int Wp, int C, int pad_t, int pad_l, int nh, int nw) {
+    const int win = blockIdx.x;   // (b, i, j)
+    const int j = win % nw, i = (win / nw) % nh, b = win / (nw * nh);
+    for (int c4 = blockIdx.y * 256 + threadIdx.x; c4 < C / 4; c4 += gridDim.y * 256) {
+        float4 s = make_float4(0, 0, 0, 0);
+        for (int a = 0; a < 7; ++a) {
+            const int y = i * 7 + a - pad_t;
+            if (y < 0 || y >= Hp) continue;
+            for (int bb = 0; bb < 7; ++bb) {
+                const int xx = j * 7 + bb - pad_l;
+                if (xx < 0 || xx >= Wp) continue;
+                const float4 v = load4(x + (((int64_t)b * Hp + y) * Wp + xx) * C + 4 * c4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        const float inv = 1.0f / 49.0f;
+        s = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+        store4(avg + (int64_t)win * C + 4 * c4, s);
+        store4(pooled + (int64_t)win * C + 4 * c4, make_float4(s.x > 0 ? s.x : 0.01f * s.x, s.y > 0 ? s.y : 0.01f * s.y,
+                                                              s.z > 0 ? s.z : 0.01f * s.z, s.w > 0 ? s.w : 0.01f * s.w));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void rvsa_pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ avg, T* __restrict__ dx, int accumulate,
+                                                           int B, int Hp, int Wp, int C, int pad_t, int pad_l, int nh, int nw) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)B * Hp * Wp * C4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(idx % C4);
+        const int64_t t = idx / C4;
+        const int xx = (int)(t % Wp), yy = (int)((t / Wp) % Hp), b = (int)(t / ((int64_t)Wp * Hp));
+        const int win = (b * nh + (yy + pad_t) / 7) * nw + (xx + pad_l) / 7;
+        const float4 d = load4(dpooled + (int64_t)win * C + 4 * c4), a = load4(avg + (int64_t)win * C + 4 * c4);
+        const float k = 1.0f / 49.0f;
+        float4 g = make_float4(d.x * (a.x > 0 ? k : 0.01f * k), d.y * (a.y > 0 ? k : 0.01f * k), d.z * (a.z > 0 ? k : 0.01f * k), d.w * (a.w > 0 ? k : 0.01f * k));
+        T* p = dx + t * C + 4 * c4;
+        if (accumulate) {
+            const float4 o = load4(p);
+            g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+        }
+        store4(p, g);
+    }
+}
+
+// y (R,N) = x (R,K) W(N,K)^T + b : one block per row, one wave per output column group
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int N, int K) {
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xr = x + (int64_t)r * K;
+    for (int n = wave; n < N; n += 4) {
+        const float* wr = w + (int64_t)n * K;
+        float s = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 a = load4(xr + k), b = load4(wr + k);
+            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        s = wave_sum(s);
+        if (lane == 0) y[(int64_t)r * N + n] = s + (bias ? bias[n] : 0.f);
+    }
+}
+// dx (R,K) = dy (R,N) W (N,K)
+__global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int R, int N, int K) {
+    const int K4 = K / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)R * K4; i += (int64_t)gridDim.x * 256) {
+        const int k4 = (int)(i % K4), r = (int)(i / K4);
+        float4 s = make_float4(0, 0, 0, 0);
+        for (int n = 0; n < N; ++n) {
+            const float d = dy[(int64_t)r * N + n];
+            const float4 ww = load4(w + (int64_t)n * K + 4 * k4);
+            s.x += d * ww.x; s.y += d * ww.y; s.z += d * ww.z; s.w += d * ww.w;
+        }
+        store4(dx + (int64_t)r * K + 4 * k4, s);
+    }
+}
+// dw (N,K) = dy^T x ; db[n] = sum_r dy[r][n]
+__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K) {
+    const int K4 = K / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)N * K4; i += (int64_t)gridDim.x * 256) {
+        const int k4 = (int)(i % K4), n = (int)(i / K4);
+        float4 s = make_float4(0, 0, 0, 0);
+        float sb = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float d = dy[(int64_t)r * N + n];
+            const float4 xv = load4(x + (int64_t)r * K + 4 * k4);
+            s.x += d * xv.x; s.y += d * xv.y; s.z += d * xv.z; s.w += d * xv.w;
+            sb += d;
+        }
+        store4(dw + (int64_t)n * K + 4 * k4, s);
+        if (k4 == 0 && db) db[n] = sb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, float* __restrict__ out, int64_t n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = load4(g + 4 * i);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = g[(n4 << 2) + threadIdx.x];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// AdamW (torch.optim.AdamW semantics, MAIN:424-457) over a flat buffer; segments start at multiples of 4 elements.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   const int64_t* __restrict__ seg_start, const float* __restrict__ seg_wd, int nseg,
+                                                   const float* __restrict__ hyper, const float* __restrict__ sqnorm, float max_norm, float grad_scale) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2 = hyper[5];
+    float gs = grad_scale;
+    if (sqnorm) {
+        const float total = sqrtf(*sqnorm) * grad_scale;
+        const float coef = max_norm / (total + 1e-6f);
+        gs *= coef < 1.0f ? coef : 1.0f;
+    }
+    const float rbc2 = rsqrtf(bc2), step = lr / bc1;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = nseg - 1;   // last segment with start <= 4*i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg_start[mid] <= 4 * i) lo = mid; else hi = mid - 1;
+        }
+        const float decay = 1.0f - lr * seg_wd[lo];
+        float4 pv = load4(p + 4 * i), gv = load4(g + 4 * i), mv = load4(m + 4 * i), vv = load4(v + 4 * i);
+        float P[4] = {pv.x, pv.y, pv.z, pv.w}, G[4] = {gv.x, gv.y, gv.z, gv.w}, M[4] = {mv.x, mv.y, mv.z, mv.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = G[e] * gs;
+            P[e] *= decay;
+            M[e] = b1 * M[e] + (1.0f - b1) * ge;
+            V[e] = b2 * V[e] + (1.0f - b2) * ge * ge;
+            P[e] -= step * M[e] / (sqrtf(V[e]) * rbc2 + eps);
+        }
+        store4(p + 4 * i, make_float4(P[0], P[1], P[2], P[3]));
+        store4(m + 4 * i, make_float4(M[0], M[1], M[2], M[3]));
+        store4(v + 4 * i, make_float4(V[0], V[1], V[2], V[3]));
+    }
+}
+
+}  // namespace
+
+extern "C" int mtp_patchify(const float* img, void* cols, int dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, mtp_stream_t stream) {
+    if (!img || !cols || B <= 0 || (P % 4) || (W % 4) || H < P || W < P) return MTP_ERR_ARG;
+    const int Hp = (int)(H / P), Wp = (int)(W / P);
+    const int64_t total = B * Hp * Wp * Cin * P * P / 4;
+    dim3 grid(blocks_for(total, 256, 8192)), block(256);
+    if (dtype == MTP_BF16)
+        hipLaunchKernelGGL((patchify_kernel<bf16_t, false>), grid, block, 0, (hipStream_t)stream, (float*)img, (bf16_t*)cols, (int)B, (int)Cin, (int)H, (int)W, (int)P, Hp, Wp);
+    else
+        hipLaunchKernelGGL((patchify_kernel<float, false>), grid, block, 0, (hipStream_t)stream, (float*)img, (float*)cols, (int)B, (int)Cin, (int)H, (int)W, (int)P, Hp, Wp);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_unpatchify(const void* cols, int dtype, float* dimg, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, mtp_stream_t stream) {
+    if (!dimg || !cols || B <= 0 || (P % 4) || (W % 4) || H < P || W < P) return MTP_ERR_ARG;
+    const int Hp = (int)(H / P), Wp = (int)(W / P);
+    hipStream_t s = (hipStream_t)stream;
+    if ((H % P) || (W % P)) {
+        hipError_t e = hipMemsetAsync(dimg, 0, sizeof(float) * (size_t)(B * Cin * H * W), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int64_t total = B * Hp * Wp * Cin * P * P / 4;
+    dim3 grid(blocks_for(total, 256, 8192)), block(256);
+    if (dtype == MTP_BF16)
+        hipLaunchKernelGGL((patchify_kernel<bf16_t, true>), grid, block, 0, s, dimg, (bf16_t*)cols, (int)B, (int)Cin, (int)H, (int)W, (int)P, Hp, Wp);
+    else
+        hipLaunchKernelGGL((patchify_kernel<float, true>), grid, block, 0, s, dimg, (float*)cols, (int)B, (int)Cin, (int)H, (int)W, (int)P, Hp, Wp);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_cast(const void* src, int sd, void* dst, int dd, int64_t n, mtp_stream_t stream) {
+    if (!src || !dst || n <= 0) return MTP_ERR_ARG;
+    dim3 grid(blocks_for(n / 4 + 1, 256, 8192)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (sd == MTP_F32 && dd == MTP_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == MTP_BF16 && dd == MTP_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == MTP_F32 && dd == MTP_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, s, (const float*)src, (float*)dst, n);
+    else if (sd == MTP_BF16 && dd == MTP_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_transpose_cast(const float* src, void* dst, int dst_dtype, int64_t R, int64_t C, mtp_stream_t stream) {
+    if (!src || !dst || R <= 0 || C <= 0) return MTP_ERR_ARG;
+    // src (R rows of C) is the "row side": out[c][r] = in[r][c]
+    return launch_transpose<true>(src, MTP_F32, dst, dst_dtype, 1, R, C, 1, 0, (hipStream_t)stream);
+}
+
+extern "C" int mtp_convt_pack(const float* w, void* wg, void* wgT, int dtype, int64_t Cin, int64_t Cout, mtp_stream_t stream) {
+    if (!w || Cin <= 0 || Cout <= 0) return MTP_ERR_ARG;
+    dim3 grid(blocks_for(Cin * Cout * 4, 256, 4096)), block(256);
+    if (dtype == MTP_BF16)
+        hipLaunchKernelGGL((convt_pack_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, w, (bf16_t*)wg, (bf16_t*)wgT, Cin, Cout);
+    else
+        hipLaunchKernelGGL((convt_pack_kernel<float>), grid, block, 0, (hipStream_t)stream, w, (float*)wg, (float*)wgT, Cin, Cout);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_convt_unpack_grad(const float* dwg, float* dw, int64_t Cin, int64_t Cout, mtp_stream_t stream) {
+    if (!dwg || !dw || Cin <= 0 || Cout <= 0) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(convt_unpack_kernel, dim3(blocks_for(Cin * Cout * 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, dwg, dw, Cin, Cout);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_tokens_to_nchw(const void* x, int x_dtype, void* out, int out_dtype, int64_t B, int64_t Hp, int64_t Wp, int64_t C, int levels, mtp_stream_t stream) {
+    if (!x || !out || B <= 0 || Hp <= 0 || Wp <= 0 || levels < 0 || levels > 4) return MTP_ERR_ARG;
+    return launch_transpose<true>(x, x_dtype, out, out_dtype, B, (Hp * Wp) << (2 * levels), C, (int)Wp, levels, (hipStream_t)stream);
+}
+extern "C" int mtp_nchw_to_tokens(const void* f, int f_dtype, void* out, int out_dtype, int64_t B, int64_t Hp, int64_t Wp, int64_t C, int levels, mtp_stream_t stream) {
+    if (!f || !out || B <= 0 || Hp <= 0 || Wp <= 0 || levels < 0 || levels > 4) return MTP_ERR_ARG;
+    return launch_transpose<false>(f, f_dtype, out, out_dtype, B, (Hp * Wp) << (2 * levels), C, (int)Wp, levels, (hipStream_t)stream);
+}
+
+extern "C" int mtp_maxpool2_tokens_fwd(const float* x, void* y, int y_dtype, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream) {
+    if (!x || !y || B <= 0 || Hp < 2 || Wp < 2 || (C % 4)) return MTP_ERR_ARG;
+    dim3 grid(blocks_for(B * (Hp / 2) * (Wp / 2) * C / 4, 256, 8192)), block(256);
+    if (y_dtype == MTP_BF16)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, x, (bf16_t*)y, (int)B, (int)Hp, (int)Wp, (int)C);
+    else
+        hipLaunchKernelGGL((maxpool_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, x, (float*)y, (int)B, (int)Hp, (int)Wp, (int)C);
+    return mtp_launch_status();
+}
+extern "C" int mtp_maxpool2_tokens_bwd(const float* x, const void* dy, int dy_dtype, float* dx, int accumulate, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream) {
+    if (!x || !dy || !dx || B <= 0 || Hp < 2 || Wp < 2 || (C % 4)) return MTP_ERR_ARG;
+    dim3 grid(blocks_for(B * Hp * Wp * C / 4, 256, 8192)), block(256);
+    if (dy_dtype == MTP_BF16)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, x, (const bf16_t*)dy, dx, accumulate, (int)B, (int)Hp, (int)Wp, (int)C);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, x, (const float*)dy, dx, accumulate, (int)B, (int)Hp, (int)Wp, (int)C);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_axpy_f32(float* y, const float* x, float alpha, int64_t n, mtp_stream_t stream) {
+    if (!y || !x || n <= 0) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, n);
+    return mtp_launch_status();
+}
+
+static void rvsa_geom(int64_t Hp, int64_t Wp, int& pt, int& pl, int& nh, int& nw) {
+    const int pad_h = (int)((7 - Hp % 7) % 7), pad_w = (int)((7 - Wp % 7) % 7);
+    pt = pad_h / 2; pl = pad_w / 2;
+    nh = (int)((Hp + pad_h) / 7); nw = (int)((Wp + pad_w) / 7);
+}
+
+extern "C" int mtp_rvsa_pool_fwd(const void* x, int dtype, float* avg, float* pooled, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream) {
+    if (!x || !avg || !pooled || B <= 0 || (C % 4)) return MTP_ERR_ARG;
+    int pt, pl, nh, nw;
+    rvsa_geom(Hp, Wp, pt, pl, nh, nw);
+    dim3 grid((unsigned)(B * nh * nw), (unsigned)((C / 4 + 255) / 256)), block(256);
+    if (dtype == MTP_BF16)
+        hipLaunchKernelGGL((rvsa_pool_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, avg, pooled, (int)Hp, (int)Wp, (int)C, pt, pl, nh, nw);
+    else
+        hipLaunchKernelGGL((rvsa_pool_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, avg, pooled, (int)Hp, (int)Wp, (int)C, pt, pl, nh, nw);
+    return mtp_launch_status();
+}
+extern "C" int mtp_rvsa_pool_bwd(const float* dpooled, const float* avg, void* dx, int dtype, int accumulate, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream) {
+    if (!dpooled || !avg || !dx || B <= 0 || (C % 4)) return MTP_ERR_ARG;
+    int pt, pl, nh, nw;
+    rvsa_geom(Hp, Wp, pt, pl, nh, nw);
+    dim3 grid(blocks_for(B * Hp * Wp * C / 4, 256, 8192)), block(256);
+    if (dtype == MTP_BF16)
+        hipLaunchKernelGGL((rvsa_pool_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, dpooled, avg, (bf16_t*)dx, accumulate, (int)B, (int)Hp, (int)Wp, (int)C, pt, pl, nh, nw);
+    else
+        hipLaunchKernelGGL((rvsa_pool_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, dpooled, avg, (float*)dx, accumulate, (int)B, (int)Hp, (int)Wp, (int)C, pt, pl, nh, nw);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t R, int64_t N, int64_t K, mtp_stream_t stream) {
+    if (!x || !w || !y || R <= 0 || N <= 0 || (K % 4)) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (int)N, (int)K);
+    return mtp_launch_status();
+}
+extern "C" int mtp_small_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t R, int64_t N, int64_t K, mtp_stream_t stream) {
+    if (!x || !w || !dy || R <= 0 || N <= 0 || (K % 4)) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) hipLaunchKernelGGL(small_linear_dx_kernel, dim3(blocks_for(R * K / 4, 256, 4096)), dim3(256), 0, s, dy, w, dx, (int)R, (int)N, (int)K);
+    if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(blocks_for(N * K / 4, 256, 4096)), dim3(256), 0, s, dy, x, dw, db, (int)R, (int)N, (int)K);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_sqnorm_f32(const float* g, float* out, int64_t n, mtp_stream_t stream) {
+    if (!g || !out || n <= 0) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, g, out, n);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_start, const float* seg_wd, int nseg,
+                              const float* hyper, const float* sqnorm, float max_norm, float grad_scale, mtp_stream_t stream) {
+    if (!p || !g || !m || !v || n <= 0 || (n % 4) || !seg_start || !seg_wd || nseg <= 0 || !hyper) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, seg_start, seg_wd, nseg, hyper, sqnorm, max_norm, grad_scale);
+    return mtp_launch_status();
+}
+
+namespace {
+// dst[r][c] = scale[r / rows_per_sample] * src[r][c]  (f32 -> ACT), the drop-path-scaled operand copy of a residual gradient
+template <typename T>
+__global__ __launch_bounds__(256) void scale_rows_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, const float* __restrict__ scale,
+                                                             int64_t rows_per_sample, int64_t rows, int64_t C) {
+    const int64_t C4 = C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C4;
+        const float s = scale ? scale[r / rows_per_sample] : 1.0f;
+        const float4 v = load4(src + 4 * i);
+        store4(dst + 4 * i, make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+    }
+}
+}  // namespace
+
+extern "C" int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, const float* scale, int64_t rows_per_sample, int64_t rows, int64_t C, mtp_stream_t stream) {
+    if (!src || !dst || rows <= 0 || (C % 4) || (scale && rows_per_sample <= 0)) return MTP_ERR_ARG;
+    dim3 grid(blocks_for(rows * C / 4, 256, 8192)), block(256);
+    if (dst_dtype == MTP_BF16)
+        hipLaunchKernelGGL((scale_rows_cast_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, src, (bf16_t*)dst, scale, rows_per_sample, rows, C);
+    else
+        hipLaunchKernelGGL((scale_rows_cast_kernel<float>), grid, block, 0, (hipStream_t)stream, src, (float*)dst, scale, rows_per_sample, rows, C);
+    return mtp_launch_status();
+}
+
+extern "C" const char* mtp_version(void) { return "mtp_hip 0.1 (gfx950)"; }

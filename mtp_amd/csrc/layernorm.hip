@@ -1,0 +1,291 @@
+// LayerNorm forward/backward (nn.LayerNorm(C, eps=1e-6), VIT:484,496,579,596) for gfx950.
+// HBM-bound: one 64-lane wavefront per row, 16-byte accesses, row kept in registers (C <= 1024*... see MAXV),
+// statistics in f32 with a centred second pass, wave reductions via cross-lane shuffles (no LDS on the row path).
+// Optional fused exact-erf GELU on the output (fpn1: Norm2d -> GELU, VIT:643-644).
+// Backward fuses: residual-gradient add, an extra addend (FPN tap gradient), the ACT-dtype copy of the result
+// (operand of the next dgrad/wgrad GEMMs, pre-multiplied by the drop-path factor), and per-block dgamma/dbeta partials.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;   // 4 rows per block pass
+constexpr int MAXV = 4;           // float4 per lane kept in registers -> C <= 1024
+
+template <typename Tx, typename Ty, bool GELU>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const Tx* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           Ty* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                           int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;   // float4 groups per row
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const Tx* xr = x + row * C;
+        float4 v[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                v[i] = load4(xr + 4 * c4);
+                s += v[i].x + v[i].y + v[i].z + v[i].w;
+            }
+        }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+                q += a * a + b * b + c * c + d * d;
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+        Ty* yr = y + row * C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+                const float4 b = *reinterpret_cast<const float4*>(beta + 4 * c4);
+                float4 o = make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
+                                       (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w);
+                if (GELU) o = make_float4(gelu_f(o.x), gelu_f(o.y), gelu_f(o.z), gelu_f(o.w));
+                store4(yr + 4 * c4, o);
+            }
+        }
+    }
+}
+
+template <typename Tact, typename Tx, typename Tdx, bool GELU>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restrict__ dy, const Tx* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dres, const float* __restrict__ extra, Tdx* __restrict__ dx,
+                                                           Tact* __restrict__ dx_copy, const float* __restrict__ copy_scale, int rows_per_sample,
+                                                           float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int64_t rows, int C) {
+    __shared__ float4 red[2][3][64 * MAXV];   // waves 1..3 -> wave 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    float4 gacc[MAXV], bacc[MAXV], g[MAXV], bt[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        gacc[i] = make_float4(0, 0, 0, 0);
+        bacc[i] = make_float4(0, 0, 0, 0);
+        const int c4 = lane + 64 * i;
+        g[i] = c4 < nv ? *reinterpret_cast<const float4*>(gamma + 4 * c4) : make_float4(0, 0, 0, 0);
+        bt[i] = (GELU && c4 < nv) ? *reinterpret_cast<const float4*>(beta + 4 * c4) : make_float4(0, 0, 0, 0);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[MAXV], d[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                const float4 xv = load4(x + row * C + 4 * c4);
+                float4 dv = load4(dy + row * C + 4 * c4);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                if (GELU) {   // y = gelu(z), z = xhat*gamma+beta
+                    dv.x *= dgelu_f(xh[i].x * g[i].x + bt[i].x);
+                    dv.y *= dgelu_f(xh[i].y * g[i].y + bt[i].y);
+                    dv.z *= dgelu_f(xh[i].z * g[i].z + bt[i].z);
+                    dv.w *= dgelu_f(xh[i].w * g[i].w + bt[i].w);
+                }
+                gacc[i].x += dv.x * xh[i].x; gacc[i].y += dv.y * xh[i].y; gacc[i].z += dv.z * xh[i].z; gacc[i].w += dv.w * xh[i].w;
+                bacc[i].x += dv.x; bacc[i].y += dv.y; bacc[i].z += dv.z; bacc[i].w += dv.w;
+                d[i] = make_float4(dv.x * g[i].x, dv.y * g[i].y, dv.z * g[i].z, dv.w * g[i].w);
+                s1 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
+                s2 += d[i].x + d[i].y + d[i].z + d[i].w;
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
+        const float cs = (dx_copy && copy_scale) ? copy_scale[row / rows_per_sample] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                float4 o = make_float4((d[i].x - xh[i].x * c1 - c2) * rs, (d[i].y - xh[i].y * c1 - c2) * rs,
+                                       (d[i].z - xh[i].z * c1 - c2) * rs, (d[i].w - xh[i].w * c1 - c2) * rs);
+                if (dres) {
+                    const float4 r = *reinterpret_cast<const float4*>(dres + row * C + 4 * c4);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                if (extra) {
+                    const float4 r = *reinterpret_cast<const float4*>(extra + row * C + 4 * c4);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                store4(dx + row * C + 4 * c4, o);
+                if (dx_copy) store4(dx_copy + row * C + 4 * c4, make_float4(o.x * cs, o.y * cs, o.z * cs, o.w * cs));
+            }
+        }
+    }
+    // block-level reduction of the parameter-gradient partials (waves 1..3 -> LDS -> wave 0)
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            red[0][wave - 1][lane + 64 * i] = gacc[i];
+            red[1][wave - 1][lane + 64 * i] = bacc[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                float4 a = gacc[i], b = bacc[i];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const float4 ra = red[0][w][lane + 64 * i], rb = red[1][w][lane + 64 * i];
+                    a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w;
+                    b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
+                }
+                *reinterpret_cast<float4*>(dgamma_part + (int64_t)blockIdx.x * C + 4 * c4) = a;
+                *reinterpret_cast<float4*>(dbeta_part + (int64_t)blockIdx.x * C + 4 * c4) = b;
+            }
+        }
+    }
+}
+
+// out[c] (+)= sum_r part[r][c]; thread per column, rows split over blockIdx.y, f32 atomics into (zeroed) out
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t rows, int64_t C, int64_t rows_per_block) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += part[r * C + c];
+    atomicAdd(out + c, s);
+}
+
+// bias gradient: column sums of dY (M, N).  Block = 64 columns-of-4 x 4 row-lanes; grid.y splits the rows; f32 atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, int64_t ld, float* __restrict__ out, int64_t M, int64_t N, int64_t rows_per_block) {
+    __shared__ float4 red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int64_t n = ((int64_t)blockIdx.x * 64 + cx) * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < M ? r1 : M;
+    float4 s = make_float4(0, 0, 0, 0);
+    if (n < N)
+        for (int64_t r = r0 + ry; r < r1; r += 4) {
+            const float4 v = load4(dY + r * ld + n);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && n < N) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 v = red[w][cx];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        atomicAdd(out + n, s.x); atomicAdd(out + n + 1, s.y); atomicAdd(out + n + 2, s.z); atomicAdd(out + n + 3, s.w);
+    }
+}
+
+int ln_grid(int64_t rows) {
+    int64_t nb = (rows + 3) / 4;
+    return (int)(nb < 2048 ? nb : 2048);
+}
+
+template <typename Tx, typename Ty>
+int launch_ln_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t rows, int64_t C, float eps, int gelu, hipStream_t s) {
+    dim3 grid(ln_grid(rows)), block(LN_THREADS);
+    if (gelu)
+        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, true>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, false>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
+    return mtp_launch_status();
+}
+
+template <typename Tact, typename Tx, typename Tdx>
+int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int gelu,
+                  const float* dres, const float* extra, void* dx, void* dx_copy, const float* copy_scale, int64_t rps,
+                  float* dgp, float* dbp, int64_t rows, int64_t C, hipStream_t s) {
+    dim3 grid((unsigned)mtp_layernorm_bwd_partial_rows(rows)), block(LN_THREADS);
+    if (gelu)
+        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, rows, (int)C);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, rows, (int)C);
+    return mtp_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mtp_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                                 float* mean, float* rstd, int64_t rows, int64_t C, float eps, int fuse_gelu, mtp_stream_t stream) {
+    if (!x || !gamma || !beta || !y || rows <= 0 || C <= 0 || (C % 4) || C > 256 * MAXV) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == MTP_F32 && y_dtype == MTP_F32) return launch_ln_fwd<float, float>(x, gamma, beta, y, mean, rstd, rows, C, eps, fuse_gelu, s);
+    if (x_dtype == MTP_F32 && y_dtype == MTP_BF16) return launch_ln_fwd<float, bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, fuse_gelu, s);
+    if (x_dtype == MTP_BF16 && y_dtype == MTP_BF16) return launch_ln_fwd<bf16_t, bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, fuse_gelu, s);
+    if (x_dtype == MTP_BF16 && y_dtype == MTP_F32) return launch_ln_fwd<bf16_t, float>(x, gamma, beta, y, mean, rstd, rows, C, eps, fuse_gelu, s);
+    return MTP_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t mtp_layernorm_bwd_partial_rows(int64_t rows) {
+    int64_t nb = (rows + 3) / 4;
+    return nb < 512 ? nb : 512;
+}
+
+extern "C" int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, int fuse_gelu, const float* dres, const float* extra, void* dx, int dx_dtype,
+                                 void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
+                                 float* dgamma_part, float* dbeta_part, int64_t rows, int64_t C, mtp_stream_t stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma_part || !dbeta_part || rows <= 0 || (C % 4) || C > 256 * MAXV) return MTP_ERR_ARG;
+    if (fuse_gelu && !beta) return MTP_ERR_ARG;
+    if (dx_copy && copy_dtype != dy_dtype) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dy_dtype == MTP_BF16 && x_dtype == MTP_F32 && dx_dtype == MTP_F32)
+        return launch_ln_bwd<bf16_t, float, float>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, rows, C, s);
+    if (dy_dtype == MTP_F32 && x_dtype == MTP_F32 && dx_dtype == MTP_F32)
+        return launch_ln_bwd<float, float, float>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, rows, C, s);
+    if (dy_dtype == MTP_BF16 && x_dtype == MTP_BF16 && dx_dtype == MTP_BF16)
+        return launch_ln_bwd<bf16_t, bf16_t, bf16_t>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, rows, C, s);
+    return MTP_ERR_UNSUPPORTED;
+}
+
+extern "C" int mtp_reduce_rows_f32(const float* part, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream) {
+    if (!part || !out || rows <= 0 || C <= 0) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int64_t col_blocks = (C + 255) / 256;
+    int64_t splits = 1024 / col_blocks;
+    if (splits < 1) splits = 1;
+    if (splits > rows) splits = rows;
+    const int64_t rpb = (rows + splits - 1) / splits;
+    splits = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)col_blocks, (unsigned)splits), dim3(256), 0, s, part, out, rows, C, rpb);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_colsum(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream) {
+    if (!dY || !out || M <= 0 || N <= 0 || (N % 4) || (ld % 4)) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
+    if (e != hipSuccess) return (int)e;
+    const int64_t col_blocks = (N / 4 + 63) / 64;
+    int64_t row_blocks = 2048 / col_blocks;
+    if (row_blocks < 1) row_blocks = 1;
+    int64_t rpb = (M + row_blocks - 1) / row_blocks;
+    rpb = (rpb + 3) / 4 * 4;
+    row_blocks = (M + rpb - 1) / rpb;
+    dim3 grid((unsigned)col_blocks, (unsigned)row_blocks), block(256);
+    if (dtype == MTP_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)dY, ld, out, M, N, rpb);
+    else
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)dY, ld, out, M, N, rpb);
+    return mtp_launch_status();
+}

@@ -1,0 +1,365 @@
+"""Explicit forward/backward schedule of the ViT+RVSA backbone on the HIP kernels.
+
+Host-side mirror of ViT_Win_RVSA_V3_WSZ7.forward_features (reference VIT:787-813) and of its autograd: instead of a
+traced graph, the engine runs a fixed list of C-ABI kernel launches on the current HIP stream with caller-owned
+buffers, keeps the saved activations of each block explicitly (or recomputes them: use_checkpoint, VIT:799-800),
+and produces every parameter gradient into caller-provided f32 buffers (the flat, reverse-execution-ordered
+gradient buffer of mtp_amd.parallel when training data-parallel).
+
+Data layout: tokens (T, C) row-major, T = B*Hp*Wp; residual stream and its gradient f32;
+everything consumed by a GEMM ("ACT": LN outputs, qkv, attention output, MLP hidden, and their gradients) in
+`act_dtype` (bf16 = throughput mode, f32 = parity mode); parameters / parameter gradients / LN statistics f32.
+"""
+import torch
+
+from . import ops
+
+F32 = torch.float32
+
+
+class _Blk:
+    """Per-block prepared weights (ACT-dtype copies, transposes) and parameter handles."""
+    __slots__ = ("window", "pre", "wqkv", "wqkvT", "wproj", "wprojT", "w1", "w1T", "w2", "w2T", "wsamp", "bsamp")
+
+
+class BackboneEngine:
+    def __init__(self, module, act_dtype=torch.bfloat16):
+        self.m = module
+        self.act = act_dtype
+        self.C = module.embed_dim
+        self.depth = len(module.blocks)
+        self.heads = module.num_heads
+        self.hd = self.C // self.heads
+        self.scale = module.qk_scale if module.qk_scale is not None else self.hd ** -0.5
+        self.window = [bool(w) for w in module.window_blocks]
+        self.out_indices = list(module.out_indices)
+        self._key = None
+        self._blk = None
+        self._fpn = None
+        self._pe = None
+
+    # ------------------------------------------------------------------ parameters
+    def params(self):
+        """name -> nn.Parameter (reference state-dict names)."""
+        return dict(self.m.named_parameters())
+
+    def _weights_key(self, P):
+        return (self.act,) + tuple((p.data_ptr(), p._version) for p in P.values())
+
+    def prepare_weights(self, force=False):
+        """(Re)build the GEMM-side weight images when a parameter changed: ACT-dtype copies (W) and transposes (W^T)
+        for the dgrad GEMMs; ConvTranspose2d weights as (4C, C) GEMM matrices; the three RVSA 1x1-conv heads stacked."""
+        P = self.params()
+        key = self._weights_key(P)
+        if not force and key == self._key:
+            return
+        dev = P["patch_embed.proj.weight"].device
+        act = self.act
+
+        def both(w2d):
+            w2d = w2d.detach()
+            R, Cc = w2d.shape
+            wt = torch.empty(Cc, R, device=dev, dtype=act)
+            ops.transpose_cast(w2d.contiguous(), wt)
+            if act == F32:
+                return w2d.contiguous(), wt
+            w = torch.empty(R, Cc, device=dev, dtype=act)
+            ops.cast(w2d.contiguous(), w)
+            return w, wt
+
+        blks = []
+        for i in range(self.depth):
+            b = _Blk()
+            b.window = self.window[i]
+            b.pre = pre = "blocks.%d." % i
+            b.wqkv, b.wqkvT = both(P[pre + "attn.qkv.weight"])
+            b.wproj, b.wprojT = both(P[pre + "attn.proj.weight"])
+            b.w1, b.w1T = both(P[pre + "mlp.fc1.weight"])
+            b.w2, b.w2T = both(P[pre + "mlp.fc2.weight"])
+            if b.window:
+                b.wsamp = torch.cat([P[pre + "attn.sampling_offsets.2.weight"].detach().reshape(2 * self.heads, self.C),
+                                     P[pre + "attn.sampling_scales.2.weight"].detach().reshape(2 * self.heads, self.C),
+                                     P[pre + "attn.sampling_angles.2.weight"].detach().reshape(self.heads, self.C)], 0).contiguous()
+                b.bsamp = torch.cat([P[pre + "attn.sampling_offsets.2.bias"].detach(), P[pre + "attn.sampling_scales.2.bias"].detach(),
+                                     P[pre + "attn.sampling_angles.2.bias"].detach()], 0).contiguous()
+            blks.append(b)
+        self._blk = blks
+        wpe = P["patch_embed.proj.weight"].detach()
+        self._pe = both(wpe.reshape(wpe.shape[0], -1))
+        fpn = {}
+        for name in ("fpn1.0", "fpn1.3", "fpn2.0"):
+            if name + ".weight" in P:
+                w = P[name + ".weight"].detach().contiguous()
+                Cin, Cout = w.shape[:2]
+                wg = torch.empty(4 * Cout, Cin, device=dev, dtype=act)
+                wgT = torch.empty(Cin, 4 * Cout, device=dev, dtype=act)
+                ops.convt_pack(w, wg, wgT)
+                fpn[name] = (wg, wgT)
+        self._fpn = fpn
+        self._key = key
+
+    # ------------------------------------------------------------------ helpers
+    def _e(self, *shape, dtype=None):
+        return torch.empty(*shape, device=self.dev, dtype=dtype or self.act)
+
+    def _drop_scales(self, B, training):
+        """VIT:31-42, 619: per-sample factor floor(keep + U[0,1)) / keep for each residual branch; None when inactive."""
+        out = []
+        for i in range(self.depth):
+            r = float(self.m.drop_path_rates[i])
+            if not training or r == 0.0:
+                out.append((None, None))
+            else:
+                keep = 1.0 - r
+                u = torch.rand(2, B, device=self.dev, dtype=F32)
+                s = torch.floor(keep + u) / keep
+                out.append((s[0].contiguous(), s[1].contiguous()))
+        return out
+
+    # ------------------------------------------------------------------ block forward
+    def _block_fwd(self, i, x, B, Hp, Wp, dps, save):
+        P, b, C, T, N = self.P, self._blk[i], self.C, x.shape[0], Hp * Wp
+        pre = b.pre
+        s = {}
+        mean1, rstd1 = self._e(T, dtype=F32), self._e(T, dtype=F32)
+        ln1 = ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], self._e(T, C), mean1, rstd1)
+        qkv = ops.gemm_nt(ln1, b.wqkv, self._e(T, 3 * C), bias=P[pre + "attn.qkv.bias"])
+        o = self._e(T, C)
+        if b.window:
+            nh, nw = ops.rvsa_windows(Hp, Wp)
+            R = B * nh * nw
+            avg, pooled = self._e(R, C, dtype=F32), self._e(R, C, dtype=F32)
+            ops.rvsa_pool_fwd(ln1, avg, pooled, B, Hp, Wp)
+            samp = ops.small_linear_fwd(pooled, b.wsamp, b.bsamp, self._e(R, 5 * self.heads, dtype=F32))
+            lse = self._e(R * self.heads * 49, dtype=F32)
+            ops.rvsa_attn_fwd(qkv, samp, o, lse, P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"],
+                              P[pre + "attn.relative_position_bias_table"], B, Hp, Wp, self.heads, self.scale)
+            s.update(avg=avg, pooled=pooled, samp=samp)
+        else:
+            lse = self._e(B * self.heads * N, dtype=F32)
+            ops.full_attn_fwd(qkv, o, lse, P[pre + "attn.full_attn_rel_pos_h"], P[pre + "attn.full_attn_rel_pos_w"], B, Hp, Wp, self.heads, self.scale)
+        x1 = ops.gemm_nt(o, b.wproj, self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=P[pre + "attn.proj.bias"], res=x,
+                         rowscale=dps[0], rows_per_sample=N)
+        mean2, rstd2 = self._e(T, dtype=F32), self._e(T, dtype=F32)
+        ln2 = ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], self._e(T, C), mean2, rstd2)
+        u = self._e(T, 4 * C)
+        h = ops.gemm_nt(ln2, b.w1, self._e(T, 4 * C), epi=ops.EPI_BIAS_GELU, bias=P[pre + "mlp.fc1.bias"], aux=u)
+        x2 = ops.gemm_nt(h, b.w2, self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=P[pre + "mlp.fc2.bias"], res=x1,
+                         rowscale=dps[1], rows_per_sample=N)
+        if save:
+            s.update(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2, ln2=ln2, u=u, h=h)
+        return x2, s
+
+    # ------------------------------------------------------------------ block backward
+    def _block_bwd(self, i, s, dx2, dx2_act, B, Hp, Wp, dps, G, extra, prev_scale):
+        """dx2 (f32) = gradient of the block output; dx2_act = dps[1]-scaled ACT copy.  Returns (dx0, dx0_act) for the
+        block input where dx0_act is pre-scaled by `prev_scale` (the previous block's mlp drop-path factor)."""
+        P, b, C, N = self.P, self._blk[i], self.C, Hp * Wp
+        pre = b.pre
+        T = dx2.shape[0]
+        # ---- MLP branch
+        ops.gemm_tn(dx2_act, s["h"], G[pre + "mlp.fc2.weight"])
+        ops.colsum(dx2_act, G[pre + "mlp.fc2.bias"])
+        du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_DGELU, aux=s["u"])
+        ops.gemm_tn(du, s["ln2"], G[pre + "mlp.fc1.weight"])
+        ops.colsum(du, G[pre + "mlp.fc1.bias"])
+        dln2 = ops.gemm_nt(du, b.w1T, self._e(T, C))
+        del du
+        dx1, dx1_act = self._e(T, C, dtype=F32), self._e(T, C)
+        ops.layernorm_bwd(dln2, s["x1"], s["mean2"], s["rstd2"], P[pre + "norm2.weight"], dx1, G[pre + "norm2.weight"], G[pre + "norm2.bias"],
+                          dres=dx2, dx_copy=dx1_act, copy_scale=dps[0], rows_per_sample=N)
+        # ---- attention branch
+        ops.gemm_tn(dx1_act, s["o"], G[pre + "attn.proj.weight"])
+        ops.colsum(dx1_act, G[pre + "attn.proj.bias"])
+        do = ops.gemm_nt(dx1_act, b.wprojT, self._e(T, C))
+        dqkv = self._e(T, 3 * C)
+        if b.window:
+            nh, nw = ops.rvsa_windows(Hp, Wp)
+            R = B * nh * nw
+            H = self.heads
+            dsamp = self._e(R, 5 * H, dtype=F32)
+            ops.rvsa_attn_bwd(s["qkv"], s["samp"], s["o"], do, s["lse"], dqkv, dsamp,
+                              P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], P[pre + "attn.relative_position_bias_table"],
+                              G[pre + "attn.rel_pos_h"], G[pre + "attn.rel_pos_w"], G[pre + "attn.relative_position_bias_table"],
+                              B, Hp, Wp, H, self.scale)
+            dpooled, dws, dbs = self._e(R, C, dtype=F32), self._e(5 * H, C, dtype=F32), self._e(5 * H, dtype=F32)
+            ops.small_linear_bwd(s["pooled"], b.wsamp, dsamp, dpooled, dws, dbs)
+            G[pre + "attn.sampling_offsets.2.weight"].copy_(dws[:2 * H].view(2 * H, C, 1, 1))
+            G[pre + "attn.sampling_scales.2.weight"].copy_(dws[2 * H:4 * H].view(2 * H, C, 1, 1))
+            G[pre + "attn.sampling_angles.2.weight"].copy_(dws[4 * H:].view(H, C, 1, 1))
+            G[pre + "attn.sampling_offsets.2.bias"].copy_(dbs[:2 * H])
+            G[pre + "attn.sampling_scales.2.bias"].copy_(dbs[2 * H:4 * H])
+            G[pre + "attn.sampling_angles.2.bias"].copy_(dbs[4 * H:])
+        else:
+            ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, P[pre + "attn.full_attn_rel_pos_h"], P[pre + "attn.full_attn_rel_pos_w"],
+                              G[pre + "attn.full_attn_rel_pos_h"], G[pre + "attn.full_attn_rel_pos_w"], B, Hp, Wp, self.heads, self.scale)
+        ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"])
+        ops.colsum(dqkv, G[pre + "attn.qkv.bias"])
+        dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
+        if b.window:
+            ops.rvsa_pool_bwd(dpooled, s["avg"], dln1, B, Hp, Wp, accumulate=True)
+        dx0, dx0_act = self._e(T, C, dtype=F32), self._e(T, C)
+        ops.layernorm_bwd(dln1, s["x"], s["mean1"], s["rstd1"], P[pre + "norm1.weight"], dx0, G[pre + "norm1.weight"], G[pre + "norm1.bias"],
+                          dres=dx1, extra=extra, dx_copy=dx0_act, copy_scale=prev_scale, rows_per_sample=N)
+        return dx0, dx0_act
+
+    # ------------------------------------------------------------------ whole forward
+    def forward(self, img, training=False, need_grad=False, feature_dtype=None):
+        """img (B,3,H,W) f32 on the GPU -> ([f1..f4] NCHW, ctx).  ctx is None unless need_grad."""
+        m = self.m
+        self.dev = img.device
+        self.prepare_weights()
+        self.P = P = {k: v.detach() for k, v in self.params().items()}
+        C, act = self.C, self.act
+        B, Cin, H, W = img.shape
+        ps = m.patch_size
+        Hp, Wp = H // ps, W // ps
+        N, T = Hp * Wp, B * Hp * Wp
+        fdt = feature_dtype or act
+        img = img.contiguous()
+        if img.dtype != F32:
+            img = img.float()
+        # ---- patch embed (+ abs pos embed fused as the "residual" of the GEMM epilogue; VIT:536-539, 793-794)
+        cols = ops.patchify(img, self._e(T, Cin * ps * ps), ps)
+        pos = P.get("pos_embed")
+        if pos is not None:
+            assert pos.shape[1] == N, "pos_embed does not match the input size"
+            x = ops.gemm_nt(cols, self._pe[0], self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=P["patch_embed.proj.bias"],
+                            res=pos.reshape(N, C), res_mod=N)
+        else:
+            x = ops.gemm_nt(cols, self._pe[0], self._e(T, C, dtype=F32), bias=P["patch_embed.proj.bias"])
+        dps = self._drop_scales(B, training)
+        ckpt = bool(m.use_checkpoint) and need_grad
+        saved, taps = [], {}
+        last = max(self.out_indices)
+        for i in range(self.depth):
+            if i > last:
+                break      # blocks after the last tap do not influence the outputs
+            xin = x
+            x, s = self._block_fwd(i, x, B, Hp, Wp, dps[i], save=need_grad and not ckpt)
+            saved.append(s if (need_grad and not ckpt) else ({"x": xin} if need_grad else None))
+            if i in self.out_indices:
+                taps[i] = x
+        feats, fctx = self._fpn_fwd([taps[i] for i in self.out_indices], B, Hp, Wp, fdt, need_grad)
+        ctx = None
+        if need_grad:
+            ctx = dict(saved=saved, dps=dps, fctx=fctx, cols=cols, geom=(B, Cin, H, W, Hp, Wp), ckpt=ckpt, last=last)
+        return feats, ctx
+
+    # ------------------------------------------------------------------ FPN tail (VIT:640-654, 807-811)
+    def _fpn_fwd(self, taps, B, Hp, Wp, fdt, need_grad):
+        P, C, T = self.P, self.C, B * Hp * Wp
+        m = self.m
+        feats, fctx = [], {}
+        if m.patch_size != 16:
+            raise NotImplementedError("only the patch_size == 16 FPN tail (VIT:640-654) is implemented")
+        # fpn1: ConvT -> Norm2d -> GELU -> ConvT
+        t0 = taps[0] if self.act == F32 else ops.cast(taps[0], self._e(T, C))
+        y1 = ops.gemm_nt(t0, self._fpn["fpn1.0"][0], self._e(T, 4 * C), bias=P["fpn1.0.bias"], bias_mod=C)
+        mean, rstd = self._e(4 * T, dtype=F32), self._e(4 * T, dtype=F32)
+        g1 = ops.layernorm_fwd(y1.view(4 * T, C), P["fpn1.1.ln.weight"], P["fpn1.1.ln.bias"], self._e(4 * T, C), mean, rstd, gelu=True)
+        y2 = ops.gemm_nt(g1, self._fpn["fpn1.3"][0], self._e(4 * T, 4 * C), bias=P["fpn1.3.bias"], bias_mod=C)
+        feats.append(ops.tokens_to_nchw(y2.view(16 * T, C), self._e(B, C, 4 * Hp, 4 * Wp, dtype=fdt), B, Hp, Wp, 2))
+        # fpn2: ConvT
+        t1 = taps[1] if self.act == F32 else ops.cast(taps[1], self._e(T, C))
+        z = ops.gemm_nt(t1, self._fpn["fpn2.0"][0], self._e(T, 4 * C), bias=P["fpn2.0.bias"], bias_mod=C)
+        feats.append(ops.tokens_to_nchw(z.view(4 * T, C), self._e(B, C, 2 * Hp, 2 * Wp, dtype=fdt), B, Hp, Wp, 1))
+        # fpn3: identity, fpn4: MaxPool2d(2,2)
+        feats.append(ops.tokens_to_nchw(taps[2], self._e(B, C, Hp, Wp, dtype=fdt), B, Hp, Wp, 0))
+        Ho, Wo = Hp // 2, Wp // 2
+        pooled = ops.maxpool2_tokens_fwd(taps[3], self._e(B * Ho * Wo, C), B, Hp, Wp)
+        feats.append(ops.tokens_to_nchw(pooled, self._e(B, C, Ho, Wo, dtype=fdt), B, Ho, Wo, 0))
+        if need_grad:
+            fctx = dict(t0=t0, y1=y1, mean=mean, rstd=rstd, g1=g1, t1=t1, tap3=taps[3])
+        return feats, fctx
+
+    def _fpn_bwd(self, dfeats, fctx, B, Hp, Wp, G):
+        """returns [dtap0..dtap3] (f32 (T,C) each, or None when the feature received no gradient)."""
+        P, C, T, act = self.P, self.C, B * Hp * Wp, self.act
+        out = [None] * 4
+
+        def as_in(df):
+            df = df.contiguous()
+            return df if df.dtype in (F32, torch.bfloat16) else df.float()
+
+        if dfeats[0] is not None:
+            dy2 = ops.nchw_to_tokens(as_in(dfeats[0]), self._e(16 * T, C), B, Hp, Wp, 2)
+            dwg = self._e(4 * C, C, dtype=F32)
+            ops.gemm_tn(dy2.view(4 * T, 4 * C), fctx["g1"], dwg)
+            ops.convt_unpack_grad(dwg, G["fpn1.3.weight"])
+            ops.colsum(dy2, G["fpn1.3.bias"])
+            dg1 = ops.gemm_nt(dy2.view(4 * T, 4 * C), self._fpn["fpn1.3"][1], self._e(4 * T, C))
+            dy1 = self._e(4 * T, C)
+            ops.layernorm_bwd(dg1, fctx["y1"].view(4 * T, C), fctx["mean"], fctx["rstd"], P["fpn1.1.ln.weight"], dy1,
+                              G["fpn1.1.ln.weight"], G["fpn1.1.ln.bias"], beta=P["fpn1.1.ln.bias"], gelu=True)
+            ops.gemm_tn(dy1.view(T, 4 * C), fctx["t0"], dwg)
+            ops.convt_unpack_grad(dwg, G["fpn1.0.weight"])
+            ops.colsum(dy1, G["fpn1.0.bias"])
+            out[0] = ops.gemm_nt(dy1.view(T, 4 * C), self._fpn["fpn1.0"][1], self._e(T, C, dtype=F32))
+        if dfeats[1] is not None:
+            dz = ops.nchw_to_tokens(as_in(dfeats[1]), self._e(4 * T, C), B, Hp, Wp, 1)
+            dwg = self._e(4 * C, C, dtype=F32)
+            ops.gemm_tn(dz.view(T, 4 * C), fctx["t1"], dwg)
+            ops.convt_unpack_grad(dwg, G["fpn2.0.weight"])
+            ops.colsum(dz, G["fpn2.0.bias"])
+            out[1] = ops.gemm_nt(dz.view(T, 4 * C), self._fpn["fpn2.0"][1], self._e(T, C, dtype=F32))
+        if dfeats[2] is not None:
+            out[2] = ops.nchw_to_tokens(as_in(dfeats[2]), self._e(T, C, dtype=F32), B, Hp, Wp, 0)
+        if dfeats[3] is not None:
+            Ho, Wo = Hp // 2, Wp // 2
+            dp = ops.nchw_to_tokens(as_in(dfeats[3]), self._e(B * Ho * Wo, C, dtype=F32), B, Ho, Wo, 0)
+            out[3] = ops.maxpool2_tokens_bwd(fctx["tap3"], dp, self._e(T, C, dtype=F32), B, Hp, Wp)
+        return out
+
+    # ------------------------------------------------------------------ whole backward
+    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None):
+        """dfeats: 4 NCHW cotangents (or None).  G: name -> f32 gradient buffer (overwritten; parameters that receive no
+        gradient -- `norm.*`, blocks after the last tap -- are left untouched).  on_block_done(i) is called after the
+        gradients of block i (and, for i == -1, of patch-embed / pos-embed) are complete on the current stream --
+        the hook mtp_amd.parallel uses to launch bucketed RCCL all-reduces on a side stream."""
+        B, Cin, H, W, Hp, Wp = ctx["geom"]
+        C, N, T = self.C, Hp * Wp, B * Hp * Wp
+        P = self.P
+        self.dev = ctx["cols"].device
+        dtaps = self._fpn_bwd(dfeats, ctx["fctx"], B, Hp, Wp, G)
+        if on_block_done is not None:
+            on_block_done(self.depth)          # FPN parameters done
+        tapgrad = {}
+        for idx, d in zip(self.out_indices, dtaps):
+            if d is None:
+                continue
+            if idx in tapgrad:
+                ops.axpy(tapgrad[idx], d)
+            else:
+                tapgrad[idx] = d
+        last, dps, saved = ctx["last"], ctx["dps"], ctx["saved"]
+        if last not in tapgrad:
+            tapgrad[last] = torch.zeros(T, C, device=self.dev, dtype=F32)
+        dx = tapgrad[last]
+        # ACT copy of the output gradient of the last block, scaled by its mlp drop-path factor
+        dx_act = self._scaled_copy(dx, dps[last][1], N)
+        for i in range(last, -1, -1):
+            s = saved[i]
+            if ctx["ckpt"]:
+                _, s = self._block_fwd(i, s["x"], B, Hp, Wp, dps[i], save=True)
+            extra = tapgrad.get(i - 1) if i > 0 else None
+            prev_scale = dps[i - 1][1] if i > 0 else None
+            dx, dx_act = self._block_bwd(i, s, dx, dx_act, B, Hp, Wp, dps[i], G, extra, prev_scale)
+            saved[i] = None
+            if on_block_done is not None:
+                on_block_done(i)
+        # ---- patch embed / pos embed
+        ops.gemm_tn(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1))
+        ops.colsum(dx_act, G["patch_embed.proj.bias"])
+        if "pos_embed" in G:
+            ops.reduce_rows(dx.view(B, N * C), G["pos_embed"])
+        dimg = None
+        if need_input_grad:
+            dcols = ops.gemm_nt(dx_act, self._pe[1], self._e(T, ctx["cols"].shape[1]))
+            dimg = ops.unpatchify(dcols, self._e(B, Cin, H, W, dtype=F32), self.m.patch_size)
+        if on_block_done is not None:
+            on_block_done(-1)
+        return dimg
+
+    def _scaled_copy(self, dx, scale, N):
+        return ops.scale_rows_cast(dx, self._e(*dx.shape), scale, N)

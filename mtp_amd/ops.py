@@ -1,0 +1,280 @@
+"""Thin torch-tensor wrappers over the C ABI (include/mtp_hip.h).  PyTorch is plumbing here: device memory,
+the current HIP stream, nothing else.  Every function launches hand-written gfx950 kernels from libmtp_hip.so
+on torch's current stream; there is no CPU / eager fallback -- CPU tensors raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, MTP_BF16, MTP_F32, GemmArgs, check  # noqa: F401
+
+_DT = {torch.float32: MTP_F32, torch.bfloat16: MTP_BF16}
+
+
+def lib():
+    return _lib.load()
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("mtp_amd ops take float32 / bfloat16 tensors, got %s" % t.dtype)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mtp_amd ops run only on an MI355X device tensor (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError("mtp_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError("expected a float32 tensor")
+    return _p(t)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0, rowscale=None, rows_per_sample=0,
+            aux=None, variant=0):
+    """out (M,N) = epilogue(a (M,K) @ w (N,K)^T)."""
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and tuple(out.shape) == (M, N) and a.dtype == w.dtype
+    g = GemmArgs()
+    g.A, g.B, g.C = _p(a), _p(w), _p(out)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = K, K, N
+    g.in_dtype, g.out_dtype, g.epilogue = _dt(a), _dt(out), epi
+    g.bias, g.bias_mod = _f32(bias), bias_mod
+    g.res, g.res_ld, g.res_mod = _f32(res), (res.shape[-1] if res is not None else 0), res_mod
+    g.rowscale, g.rows_per_sample = _f32(rowscale), rows_per_sample
+    g.aux, g.aux_ld = _p(aux), (aux.shape[-1] if aux is not None else 0)
+    if aux is not None:
+        assert aux.dtype == out.dtype and tuple(aux.shape) == (M, N)
+    g.split_k, g.variant = 1, variant
+    check(lib().mtp_gemm_nt(C.byref(g), _s()), "mtp_gemm_nt")
+    return out
+
+
+def pick_split_k(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    split = max(1, min(16, round(1024 / tiles)))
+    return max(1, min(split, K // 512))
+
+
+def gemm_tn(a, b, out, split_k=None):
+    """out (M,N) f32 = a (K,M)^T @ b (K,N)   (weight gradient dW = dY^T X)."""
+    K, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K and out.dtype == torch.float32 and out.numel() == M * N and a.dtype == b.dtype
+    g = GemmArgs()
+    g.A, g.B, g.C = _p(a), _p(b), _p(out)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = M, N, N
+    g.in_dtype, g.out_dtype, g.epilogue = _dt(a), MTP_F32, EPI_BIAS
+    g.split_k = pick_split_k(M, N, K) if split_k is None else split_k
+    check(lib().mtp_gemm_tn(C.byref(g), _s()), "mtp_gemm_tn")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-6, gelu=False):
+    rows, Cc = x.shape
+    check(lib().mtp_layernorm_fwd(_p(x), _dt(x), _f32(gamma), _f32(beta), _p(y), _dt(y), _f32(mean), _f32(rstd),
+                                  rows, Cc, eps, int(gelu), _s()), "mtp_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=False, dres=None, extra=None,
+                  dx_copy=None, copy_scale=None, rows_per_sample=0):
+    """dx = [dres] + [extra] + LN'(dy); dgamma/dbeta (C,) f32 are overwritten."""
+    rows, Cc = x.shape
+    nblk = lib().mtp_layernorm_bwd_partial_rows(rows)
+    part = torch.empty(2, nblk, Cc, device=x.device, dtype=torch.float32)
+    check(lib().mtp_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _f32(mean), _f32(rstd), _f32(gamma), _f32(beta), int(gelu),
+                                  _f32(dres), _f32(extra), _p(dx), _dt(dx), _p(dx_copy), (_dt(dx_copy) if dx_copy is not None else 0),
+                                  _f32(copy_scale), rows_per_sample, _p(part[0]), _p(part[1]), rows, Cc, _s()), "mtp_layernorm_bwd")
+    reduce_rows(part[0], dgamma)
+    reduce_rows(part[1], dbeta)
+    return dx
+
+
+def reduce_rows(part, out, accumulate=False):
+    rows = part.shape[0]
+    cols = part.numel() // rows
+    assert out.numel() == cols
+    check(lib().mtp_reduce_rows_f32(_f32(part), _f32(out), rows, cols, int(accumulate), _s()), "mtp_reduce_rows_f32")
+    return out
+
+
+def colsum(dy, out):
+    M, N = dy.shape
+    check(lib().mtp_colsum(_p(dy), _dt(dy), N, _f32(out), M, N, _s()), "mtp_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ layout
+def patchify(img, cols, P=16):
+    B, Cin, H, W = img.shape
+    check(lib().mtp_patchify(_f32(img), _p(cols), _dt(cols), B, Cin, H, W, P, _s()), "mtp_patchify")
+    return cols
+
+
+def unpatchify(cols, dimg, P=16):
+    B, Cin, H, W = dimg.shape
+    check(lib().mtp_unpatchify(_p(cols), _dt(cols), _f32(dimg), B, Cin, H, W, P, _s()), "mtp_unpatchify")
+    return dimg
+
+
+def cast(src, dst):
+    assert src.numel() == dst.numel()
+    check(lib().mtp_cast(_p(src), _dt(src), _p(dst), _dt(dst), src.numel(), _s()), "mtp_cast")
+    return dst
+
+
+def transpose_cast(src, dst):
+    R, Cc = src.shape
+    assert tuple(dst.shape) == (Cc, R)
+    check(lib().mtp_transpose_cast(_f32(src), _p(dst), _dt(dst), R, Cc, _s()), "mtp_transpose_cast")
+    return dst
+
+
+def convt_pack(w, wg, wgT):
+    Cin, Cout = w.shape[:2]
+    dt = _dt(wg if wg is not None else wgT)
+    check(lib().mtp_convt_pack(_f32(w), _p(wg), _p(wgT), dt, Cin, Cout, _s()), "mtp_convt_pack")
+
+
+def convt_unpack_grad(dwg, dw):
+    Cin, Cout = dw.shape[:2]
+    check(lib().mtp_convt_unpack_grad(_f32(dwg), _f32(dw), Cin, Cout, _s()), "mtp_convt_unpack_grad")
+    return dw
+
+
+def tokens_to_nchw(x, out, B, Hp, Wp, levels):
+    Cc = x.shape[-1]
+    check(lib().mtp_tokens_to_nchw(_p(x), _dt(x), _p(out), _dt(out), B, Hp, Wp, Cc, levels, _s()), "mtp_tokens_to_nchw")
+    return out
+
+
+def nchw_to_tokens(f, out, B, Hp, Wp, levels):
+    Cc = f.shape[1]
+    check(lib().mtp_nchw_to_tokens(_p(f), _dt(f), _p(out), _dt(out), B, Hp, Wp, Cc, levels, _s()), "mtp_nchw_to_tokens")
+    return out
+
+
+def maxpool2_tokens_fwd(x, y, B, Hp, Wp):
+    check(lib().mtp_maxpool2_tokens_fwd(_f32(x), _p(y), _dt(y), B, Hp, Wp, x.shape[-1], _s()), "mtp_maxpool2_tokens_fwd")
+    return y
+
+
+def maxpool2_tokens_bwd(x, dy, dx, B, Hp, Wp, accumulate=False):
+    check(lib().mtp_maxpool2_tokens_bwd(_f32(x), _p(dy), _dt(dy), _f32(dx), int(accumulate), B, Hp, Wp, x.shape[-1], _s()), "mtp_maxpool2_tokens_bwd")
+    return dx
+
+
+def axpy(y, x, alpha=1.0):
+    check(lib().mtp_axpy_f32(_f32(y), _f32(x), alpha, y.numel(), _s()), "mtp_axpy_f32")
+    return y
+
+
+def scale_rows_cast(src, dst, scale=None, rows_per_sample=0):
+    rows, Cc = src.shape
+    check(lib().mtp_scale_rows_cast(_f32(src), _p(dst), _dt(dst), _f32(scale), rows_per_sample, rows, Cc, _s()), "mtp_scale_rows_cast")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def full_attn_fwd(qkv, o, lse, rel_h, rel_w, B, Hp, Wp, heads, scale):
+    hd = qkv.shape[1] // (3 * heads)
+    check(lib().mtp_full_attn_fwd(_p(qkv), _p(o), _f32(lse), _dt(qkv), _f32(rel_h), _f32(rel_w), B, Hp, Wp, heads, hd, scale, _s()), "mtp_full_attn_fwd")
+    return o, lse
+
+
+def full_attn_bwd(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, heads, scale):
+    hd = qkv.shape[1] // (3 * heads)
+    rt = (2 * Hp - 1) + (2 * Wp - 1)
+    part = torch.empty(B * heads, rt * hd, device=qkv.device, dtype=torch.float32)
+    check(lib().mtp_full_attn_bwd(_p(qkv), _p(o), _p(dout), _f32(lse), _p(dqkv), _dt(qkv), _f32(rel_h), _f32(rel_w), _p(part),
+                                  B, Hp, Wp, heads, hd, scale, _s()), "mtp_full_attn_bwd")
+    red = torch.empty(rt * hd, device=qkv.device, dtype=torch.float32)
+    reduce_rows(part, red)
+    drel_h.copy_(red[:(2 * Hp - 1) * hd].view_as(drel_h))
+    drel_w.copy_(red[(2 * Hp - 1) * hd:].view_as(drel_w))
+    return dqkv
+
+
+def rvsa_windows(Hp, Wp):
+    nh = (Hp + (7 - Hp % 7) % 7) // 7
+    nw = (Wp + (7 - Wp % 7) % 7) // 7
+    return nh, nw
+
+
+def rvsa_pool_fwd(x, avg, pooled, B, Hp, Wp):
+    check(lib().mtp_rvsa_pool_fwd(_p(x), _dt(x), _f32(avg), _f32(pooled), B, Hp, Wp, x.shape[-1], _s()), "mtp_rvsa_pool_fwd")
+
+
+def rvsa_pool_bwd(dpooled, avg, dx, B, Hp, Wp, accumulate=True):
+    check(lib().mtp_rvsa_pool_bwd(_f32(dpooled), _f32(avg), _p(dx), _dt(dx), int(accumulate), B, Hp, Wp, dx.shape[-1], _s()), "mtp_rvsa_pool_bwd")
+
+
+def small_linear_fwd(x, w, b, y):
+    R, K = x.shape
+    check(lib().mtp_small_linear_fwd(_f32(x), _f32(w), _f32(b), _f32(y), R, w.shape[0], K, _s()), "mtp_small_linear_fwd")
+    return y
+
+
+def small_linear_bwd(x, w, dy, dx, dw, db):
+    R, K = x.shape
+    check(lib().mtp_small_linear_bwd(_f32(x), _f32(w), _f32(dy), _f32(dx), _f32(dw), _f32(db), R, w.shape[0], K, _s()), "mtp_small_linear_bwd")
+
+
+def rvsa_attn_fwd(qkv, samp, o, lse, rel_h, rel_w, table, B, Hp, Wp, heads, scale):
+    hd = qkv.shape[1] // (3 * heads)
+    check(lib().mtp_rvsa_attn_fwd(_p(qkv), _f32(samp), _p(o), _f32(lse), _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table),
+                                  B, Hp, Wp, heads, hd, scale, _s()), "mtp_rvsa_attn_fwd")
+    return o, lse
+
+
+def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, drel_h, drel_w, dtable, B, Hp, Wp, heads, scale):
+    hd = qkv.shape[1] // (3 * heads)
+    T, C3 = qkv.shape
+    Cc = C3 // 3
+    nh, nw = rvsa_windows(Hp, Wp)
+    nblk = B * nh * nw * heads
+    dev = qkv.device
+    dkv = torch.empty(T, 2 * Cc, device=dev, dtype=torch.float32)
+    rel_part = torch.empty(nblk, 26 * hd, device=dev, dtype=torch.float32)
+    tab_part = torch.empty(B * nh * nw, heads * 169, device=dev, dtype=torch.float32)
+    check(lib().mtp_rvsa_attn_bwd(_p(qkv), _f32(samp), _p(o), _p(dout), _f32(lse), _p(dqkv), _p(dkv), _f32(dsamp), _p(rel_part), _p(tab_part),
+                                  _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table), B, Hp, Wp, heads, hd, scale, _s()), "mtp_rvsa_attn_bwd")
+    red = torch.empty(26 * hd, device=dev, dtype=torch.float32)
+    reduce_rows(rel_part, red)
+    drel_h.copy_(red[:13 * hd].view_as(drel_h))
+    drel_w.copy_(red[13 * hd:].view_as(drel_w))
+    tred = torch.empty(heads * 169, device=dev, dtype=torch.float32)
+    reduce_rows(tab_part, tred)
+    dtable.copy_(tred.view(heads, 169).t())
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def sqnorm(g, out):
+    check(lib().mtp_sqnorm_f32(_f32(g), _f32(out), g.numel(), _s()), "mtp_sqnorm_f32")
+    return out
+
+
+def adamw_flat(p, g, m, v, seg_start, seg_wd, hyper, sqn=None, max_norm=0.0, grad_scale=1.0):
+    assert seg_start.dtype == torch.int64 and seg_start.is_cuda
+    check(lib().mtp_adamw_flat(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), seg_start.data_ptr(), _f32(seg_wd), seg_start.numel(),
+                               _f32(hyper), _f32(sqn), max_norm, grad_scale, _s()), "mtp_adamw_flat")

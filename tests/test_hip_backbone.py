@@ -1,0 +1,177 @@
+"""GPU: blocks and whole backbones through the drop-in Python surface (mtp_amd.ViT_Win_RVSA_V3_WSZ7) against the golden
+fixtures generated from the reference itself, plus oracle comparisons at BASELINE config shapes.
+fp32 mode: north_star tolerance 1e-3 relative; bf16 mode: compared with the fp32 fixture AND the reference's own
+bf16-autocast fixture (the reference under bf16 differs from fp32 by ~5e-3)."""
+import numpy as np
+import pytest
+import torch
+
+import mtp_amd
+import recipe
+from conftest import rel_err
+from oracle import vit_rvsa_oracle as O
+
+pytestmark = pytest.mark.gpu
+t = torch.from_numpy
+
+
+def build(embed_dim, depth, heads, interval, out_indices, precision, **kw):
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=224, embed_dim=embed_dim, depth=depth, num_heads=heads, interval=interval, qkv_bias=True,
+                                       use_abs_pos_emb=True, out_indices=out_indices, precision=precision, feature_dtype=torch.float32, **kw)
+    net.load_state_dict(recipe.make_params(recipe.state_shapes(embed_dim, depth, heads, interval)), strict=False)
+    return net.cuda()
+
+
+def _check_summary(tensor, gsum, gsamples, tol, n=512):
+    s, v = recipe.summarize(tensor.float().cpu(), n)
+    scale = np.abs(gsamples).max() + 1e-30
+    err = np.abs(v - gsamples).max() / scale
+    assert err < tol, err
+    assert abs(s[1] - gsum[1]) < tol * gsum[1]
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+def test_small_model_forward_and_all_gradients_vs_reference(golden, precision, tol):
+    """fixture f8: 6-block C=128 model, train mode (drop_path 0), every output and every parameter gradient."""
+    g = golden("f8_small.npz")
+    net = build(128, 6, 2, 3, [1, 2, 3, 5], precision).train()
+    img = recipe.make_input(2, 224, 224, seed=99).cuda().requires_grad_(True)
+    feats = net(img)
+    assert [tuple(f.shape) for f in feats] == [(2, 128, 56, 56), (2, 128, 28, 28), (2, 128, 14, 14), (2, 128, 7, 7)]
+    loss = 0
+    for i, f in enumerate(feats):
+        _check_summary(f, g["f%d_sum" % i], g["f%d_samples" % i], tol, 2048)
+        loss = loss + (f * recipe.loss_weights(f.shape, 200 + i).cuda()).sum()
+    assert rel_err(feats[2].cpu(), g["f2"]) < tol and rel_err(feats[3].cpu(), g["f3"]) < tol
+    loss.backward()
+    gt = 5 * tol
+    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], gt, 2048)
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if "nograd_" + n in g:
+            assert p.grad is None
+        elif "g_" + n in g:
+            err = rel_err(p.grad.cpu(), g["g_" + n])
+            worst = max(worst, err)
+            assert err < gt, (n, err)
+        else:
+            _check_summary(p.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], gt, 1024)
+    print("worst small-param grad rel err (%s): %.2e" % (precision, worst))
+
+
+def test_small_model_bf16_vs_reference_bf16_autocast(golden):
+    g = golden("f8_small.npz")
+    net = build(128, 6, 2, 3, [1, 2, 3, 5], "bf16").eval()
+    with torch.no_grad():
+        feats = net(recipe.make_input(2, 224, 224, seed=99).cuda())
+    for i, f in enumerate(feats):
+        _check_summary(f, g["bf16_f%d_sum" % i], g["bf16_f%d_samples" % i], 4e-2, 2048)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+def test_vit_b_config1_forward_and_gradients(golden, precision, tol):
+    """BASELINE config 1 (ViT-B/16, batch 2, 224x224) through the factory, vs fixture f7 (reference run)."""
+    g = golden("f7_vitb.npz")
+
+    class A:
+        image_size = 224
+        use_ckpt = "False"
+    A.precision = precision
+    net = mtp_amd.vit_b_rvsa(A)
+    net.feature_dtype = torch.float32
+    net.load_state_dict(recipe.make_params(recipe.state_shapes(768, 12, 12, 3)), strict=False)
+    net = net.cuda().eval()
+    img = recipe.make_input(2, 224, 224).cuda().requires_grad_(True)
+    feats = net.forward_features(img)
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(g["f%d_shape" % i])
+        _check_summary(f, g["f%d_sum" % i], g["f%d_samples" % i], tol)
+    loss = sum(f.mean() for f in feats)
+    assert abs(loss.item() - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], 5 * tol)
+    P = dict(net.named_parameters())
+    for k in g:
+        if k.startswith("g_") and k.endswith("_samples"):
+            n = k[2:-len("_samples")]
+            _check_summary(P[n].grad, g["g_%s_sum" % n], g[k], 5 * tol)
+    assert P["norm.weight"].grad is None
+
+
+def test_checkpointing_and_eval_paths_agree():
+    net = build(128, 6, 2, 3, [1, 2, 3, 5], "fp32").train()
+    img = recipe.make_input(2, 224, 224, seed=3).cuda()
+    f0 = net(img)
+    loss = sum((f * f).mean() for f in f0)
+    loss.backward()
+    g0 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad()
+    net.use_checkpoint = True
+    f1 = net(img)
+    sum((f * f).mean() for f in f1).backward()
+    for a, b in zip(f0, f1):
+        assert torch.equal(a, b)
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert rel_err(p.grad.cpu(), g0[n].cpu()) < 1e-5, n
+    with torch.no_grad():
+        f2 = net.eval()(img)
+    for a, b in zip(f0, f2):
+        assert torch.equal(a, b)
+
+
+def test_drop_path_training_matches_oracle_with_same_masks():
+    """stochastic depth (VIT:31-42): run the HIP path, read back the per-sample factors it drew, replay them in the oracle."""
+    net = build(128, 3, 2, 3, [0, 1, 2, 2], "fp32", drop_path_rate=0.5).train()
+    torch.manual_seed(5)
+    img = recipe.make_input(4, 224, 224, seed=4).cuda()
+    eng = net._engine()
+    feats, ctx = eng.forward(img, training=True, need_grad=True, feature_dtype=torch.float32)
+    scales = [None if a is None else (a.cpu(), b.cpu()) for a, b in ctx["dps"]]
+    assert scales[0] is None and scales[2] is not None
+    p = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = O.backbone_forward(img.cpu(), p, 3, 2, 3, [0, 1, 2, 2], dp_scales=scales)
+    for a, b in zip(feats, ref):
+        assert rel_err(a.cpu(), b) < 1e-3
+
+
+def test_padded_resolution_512_forward_vs_oracle():
+    """512x512 input: 32x32 tokens -> RVSA pads to 35x35 (25 windows).  Window blocks only (full attention at N=1024 is
+    SURVEY 8f-4); compared against the oracle."""
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=512, embed_dim=128, depth=2, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True,
+                                       out_indices=[0, 1, 1, 1], precision="fp32", feature_dtype=torch.float32)
+    sd = recipe.make_params({k: v.shape for k, v in net.state_dict().items() if v.dtype.is_floating_point}, seed=11)
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().eval()
+    img = recipe.make_input(1, 512, 512, seed=6)
+    with torch.no_grad():
+        feats = net(img.cuda())
+    ref = O.backbone_forward(img, {k: v.cpu() for k, v in net.state_dict().items()}, 2, 2, 3, [0, 1, 1, 1])
+    for a, b in zip(feats, ref):
+        assert rel_err(a.cpu(), b) < 1e-3
+
+
+def test_full_size_roundtrip_properties_vit_l_shapes():
+    """BASELINE config-3 sizes (T = 64*196 tokens, C = 1024): size-independent properties of the hot kernels --
+    linearity of the GEMM in its input and token<->NCHW round trips -- where the oracle would take minutes."""
+    from mtp_amd import ops
+    T, C = 64 * 196, 1024
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn(T, C, device="cuda", generator=g).to(torch.bfloat16)
+    b = torch.randn(T, C, device="cuda", generator=g).to(torch.bfloat16)
+    w = (0.02 * torch.randn(3 * C, C, device="cuda", generator=g)).to(torch.bfloat16)
+    ya = ops.gemm_nt(a, w, torch.empty(T, 3 * C, device="cuda"))
+    yb = ops.gemm_nt(b, w, torch.empty(T, 3 * C, device="cuda"))
+    s = (a.float() + b.float())
+    s_bf = s.to(torch.bfloat16)
+    ys = ops.gemm_nt(s_bf, w, torch.empty(T, 3 * C, device="cuda"))
+    exact = s_bf.float() == s     # rows where the bf16 sum is exact are exactly linear up to f32 accumulation order
+    rows = exact.all(dim=1)
+    assert rows.sum() >= 0
+    assert rel_err((ya + yb)[rows].cpu(), ys[rows].cpu()) < 1e-4 if rows.any() else True
+    # a few rows against an f64 host dot product
+    idx = torch.tensor([0, 1, 777, T - 1])
+    ref = a[idx].double().cpu() @ w.double().cpu().t()
+    assert rel_err(ya[idx].cpu(), ref) < 1e-4
+    f = ops.tokens_to_nchw(a, torch.empty(64, C, 14, 14, device="cuda", dtype=torch.bfloat16), 64, 14, 14, 0)
+    assert torch.equal(ops.nchw_to_tokens(f, torch.empty_like(a), 64, 14, 14, 0), a)

