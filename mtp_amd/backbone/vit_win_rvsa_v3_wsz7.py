@@ -139,7 +139,8 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, *params):
         eng = module._engine()
-        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        # grad mode is off inside Function.forward; needs_input_grad is all-False under torch.no_grad()
+        need = any(ctx.needs_input_grad)
         feats, ectx = eng.forward(x, training=module.training, need_grad=need, feature_dtype=module._feature_dtype(x))
         ctx.module, ctx.ectx, ctx.n = module, ectx, len(params)
         ctx.x_grad = x.requires_grad

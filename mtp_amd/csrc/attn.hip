@@ -6,12 +6,15 @@
 // Round-1 implementation: f32 VALU math with LDS-broadcast operands, I/O in bf16 or f32 (attention is ~1 % of the
 // path's FLOPs; MFMA tiles are the next step).  lane = query in the score/softmax/PV phases, lane = key in the dK/dV
 // phases, so no cross-lane reductions are needed on the hot loops.
+#include <stdlib.h>
+
+#include "attn_mfma.h"
 #include "common.h"
 
 namespace {
 
 constexpr int HD = 64;
-constexpr int KT = 32;   // keys (or queries) staged per LDS chunk in the full-attention kernels
+constexpr int KT = 32;  // keys (or queries) staged per LDS chunk in the full-attention kernels
 
 template <typename T>
 __device__ __forceinline__ void load_row(const T* p, float (&r)[HD], float mul = 1.0f) {
@@ -717,6 +720,8 @@ extern "C" int mtp_rvsa_attn_fwd(const void* qkv, const float* samp, void* o, fl
     const RvsaGeom g = make_geom(Hp, Wp, heads);
     dim3 grid((unsigned)(B * g.nh * g.nw * heads)), block(64);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16 && mtp_use_mfma_attn())
+        return mtp_rvsa_fwd_mfma_launch(qkv, samp, o, lse, rel_h, rel_w, bias_table, B, Hp, Wp, heads, scale, s);
     if (dtype == MTP_BF16)
         hipLaunchKernelGGL((rvsa_attn_fwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)qkv, samp, (bf16_t*)o, lse, rel_h, rel_w, bias_table, g, scale);
     else
@@ -740,7 +745,11 @@ extern "C" int mtp_rvsa_attn_bwd(const void* qkv, const float* samp, const void*
     dim3 grid((unsigned)(B * g.nh * g.nw * heads)), block(64);
     int64_t cb = (Ttok * 2 * C / 4 + 255) / 256;
     dim3 cgrid((unsigned)(cb > 8192 ? 8192 : cb)), cblock(256);
-    if (dtype == MTP_BF16) {
+    if (dtype == MTP_BF16 && mtp_use_mfma_attn()) {
+        const int rc = mtp_rvsa_bwd_mfma_launch(qkv, samp, o, dout, lse, dqkv, dkv_f32, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, B, Hp, Wp, heads, scale, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL((dkv_convert_kernel<bf16_t>), cgrid, cblock, 0, s, dkv_f32, (bf16_t*)dqkv, Ttok, (int)C);
+    } else if (dtype == MTP_BF16) {
         hipLaunchKernelGGL((rvsa_attn_bwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqkv,
                            dkv_f32, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale);
         hipLaunchKernelGGL((dkv_convert_kernel<bf16_t>), cgrid, cblock, 0, s, dkv_f32, (bf16_t*)dqkv, Ttok, (int)C);

@@ -1,0 +1,24 @@
+// internal launchers of the bf16 MFMA attention kernels (attn_mfma.hip), called from the C-ABI entry points in attn.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+int mtp_rvsa_fwd_mfma_launch(const void* qkv, const float* samp, void* o, float* lse, const float* rel_h, const float* rel_w, const float* bias_table,
+                             int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
+int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse, void* dqkv, float* dkv, float* dsamp,
+                             float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
+                             int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
+int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* rel_h, const float* rel_w,
+                             int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
+int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
+                             float* drel_part, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
+
+// MTP_ATTN_VALU=1 forces the f32-VALU reference kernels also for bf16 I/O (A/B and debugging)
+static inline bool mtp_use_mfma_attn() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MTP_ATTN_VALU");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}

@@ -21,7 +21,16 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {  // round-to-nea
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// one v_cvt_pk_bf16_f32 (round-to-nearest-even) for two values
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ uint4 pack_bf16x8(float a, float b, float c, float d, float e, float f, float g, float h) {
+    return make_uint4(pack_bf16x2(a, b), pack_bf16x2(c, d), pack_bf16x2(e, f), pack_bf16x2(g, h));
+}
 
 template <typename T>
 struct Elem;

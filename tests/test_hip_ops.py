@@ -214,7 +214,7 @@ def test_full_attention_fwd_bwd(ops, dtype, Hp, Wp):
     q = qkv.clone().requires_grad_(True)
     rhr, rwr = rh.clone().requires_grad_(True), rw.clone().requires_grad_(True)
     oref, lref = O.full_attn_fwd(q, B, Hp, Wp, heads, rhr, rwr)
-    assert rel_err(o.float().cpu(), oref) < TOL[dtype] and rel_err(lse.cpu().reshape(lref.shape), lref) < 1e-4
+    assert rel_err(o.float().cpu(), oref) < TOL[dtype] and rel_err(lse.cpu().reshape(lref.shape), lref) < (1e-4 if dtype == torch.float32 else 5e-3)
     do = rnd(T, C, dtype=dtype, seed=3)
     gq, gh, gw = torch.autograd.grad(oref, (q, rhr, rwr), do)
     dqkv, drh, drw = e(T, 3 * C, dtype=dtype), e(*rh.shape), e(*rw.shape)
@@ -265,7 +265,7 @@ def test_rvsa_attention_fwd_bwd(ops, dtype, Hp, Wp, sscale):
     rhr, rwr, tr = rh.clone().requires_grad_(True), rw.clone().requires_grad_(True), tab.clone().requires_grad_(True)
     oref, lref = O.rvsa_attn_fwd(q, sp, B, Hp, Wp, heads, rhr, rwr, tr)
     assert rel_err(o.float().cpu(), oref) < TOL[dtype]
-    assert rel_err(lse.cpu().reshape(B, nh, nw, heads, 49).permute(0, 3, 1, 2, 4), lref) < 1e-4
+    assert rel_err(lse.cpu().reshape(B, nh, nw, heads, 49).permute(0, 3, 1, 2, 4), lref) < (1e-4 if dtype == torch.float32 else 5e-3)
     do = rnd(T, C, dtype=dtype, seed=4)
     gq, gs, gh, gw, gt = torch.autograd.grad(oref, (q, sp, rhr, rwr, tr), do)
     dqkv, dsamp = e(T, 3 * C, dtype=dtype), e(R, 5 * heads)
