@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of one pretrain step of the ViT-L + RVSA backbone (224^2, bf16) on N MI355X.
+
+A "step" = backbone forward + backward of the MTP shared encoder on one synthetic batch (B=64 images per GPU),
+bucketed RCCL gradient all-reduce (N > 1, overlapped with the backward on a side stream), clip_grad_norm_(5) and AdamW --
+the reference's step recipe (main_pretrain.py:721-788) with `loss = sum(mean(f))` over the 4 feature maps standing in
+for the three task decoders (they live in un-vendored mmseg/mmdet/mmrotate).  Inputs are resident in HBM.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant GEMM kernel family, HIP-event timed inside the timed region) and, at
+N=1, `cpu_baseline` (the oracle -- a CPU port of the reference path -- timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
+FWD_GF_PER_IMAGE = {"vit_l": 129.97, "vit_b": 39.78}   # BASELINE.md section 4 (dense contractions, forward)
+
+
+class GemmTimer:
+    """HIP-event timing of every GEMM launch inside the timed region (events on the launch stream = torch's current stream)."""
+
+    def __init__(self, ops):
+        self.ops, self.rec, self.on = ops, [], False
+        self._nt, self._tn = ops.gemm_nt, ops.gemm_tn
+
+    def install(self):
+        def nt(a, w, out, *args, **kw):
+            if not self.on:
+                return self._nt(a, w, out, *args, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self._nt(a, w, out, *args, **kw)
+            e.record()
+            self.rec.append(("gemm_nt", 2.0 * a.shape[0] * w.shape[0] * a.shape[1], s, e))
+            return r
+
+        def tn(a, b, out, *args, **kw):
+            if not self.on:
+                return self._tn(a, b, out, *args, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self._tn(a, b, out, *args, **kw)
+            e.record()
+            self.rec.append(("gemm_tn", 2.0 * a.shape[0] * a.shape[1] * b.shape[1], s, e))
+            return r
+        self.ops.gemm_nt, self.ops.gemm_tn = nt, tn
+
+    def summary(self):
+        fam = {}
+        for name, fl, s, e in self.rec:
+            d = fam.setdefault(name, [0.0, 0.0, 0])
+            d[0] += fl
+            d[1] += s.elapsed_time(e) * 1e-3
+            d[2] += 1
+        return {k: dict(flops=v[0], seconds=v[1], launches=v[2]) for k, v in fam.items()}
+
+
+def cpu_baseline(model, seconds_budget=25.0):
+    """The oracle (CPU port of the reference path, pinned to the reference's golden vectors) timed on the host cores:
+    ViT fwd+bwd, fp32, small batch -- a bounded sample of the same workload.  Baseline, not target."""
+    import recipe
+    from oracle import vit_rvsa_oracle as O
+    cfg = dict(vit_l=(1024, 24, 16, 6, [7, 11, 15, 23]), vit_b=(768, 12, 12, 3, [3, 5, 7, 11]))[model]
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    B = 4
+    p = {k: v.requires_grad_(True) for k, v in recipe.make_params(recipe.state_shapes(cfg[0], cfg[1], cfg[2], cfg[3])).items()}
+    img = recipe.make_input(B, 224, 224)
+
+    def one():
+        feats = O.backbone_forward(img, p, cfg[1], cfg[2], cfg[3], cfg[4])
+        sum(f.mean() for f in feats).backward()
+        for v in p.values():
+            v.grad = None
+    t0 = time.time()
+    one()
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t0 + warm) < seconds_budget and n < 5:
+        one()
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=B / dt, unit="images/sec", cores=threads, kind="port",
+                sample="oracle (torch CPU fp32 restatement of the reference path) %s fwd+bwd, batch %d, %d timed iters after 1 warm-up, %d of %d host threads"
+                       % (model, B, n, threads, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="vit_l", choices=["vit_l", "vit_b"])
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import mtp_amd
+    from mtp_amd import ops
+    from mtp_amd.parallel import DataParallelTrainer
+    ops.lib()
+
+    class A:
+        image_size = 224
+        use_ckpt = "False"
+        precision = args.precision
+    torch.manual_seed(2023)    # identical initial replicas (main_pretrain.py:107)
+    net = (mtp_amd.vit_l_rvsa if args.model == "vit_l" else mtp_amd.vit_b_rvsa)(A)
+    with torch.no_grad():      # zero-initialised tables re-drawn N(0, 0.02^2) so no branch is trivially zero
+        for n, p in net.named_parameters():
+            if "rel_pos" in n:
+                p.normal_(0, 0.02)
+    net = net.cuda().train()
+    fdt = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    trainer = DataParallelTrainer(net, lr=6e-5, weight_decay=0.05, max_norm=5.0, total_steps=1000, feature_dtype=fdt)
+    torch.manual_seed(2023 + rank)   # per-rank data / drop-path streams (main_pretrain.py:517)
+    B = args.batch
+    img = torch.randn(B, 3, 224, 224, device="cuda")
+
+    def loss_and_grads(feats):
+        leaves = [f.detach().requires_grad_(True) for f in feats]
+        loss = sum(f.float().mean() for f in leaves)
+        loss.backward()
+        return loss.detach(), [f.grad for f in leaves]
+
+    timer = GemmTimer(ops)
+    if not args.no_gemm_timer:
+        timer.install()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(img, loss_and_grads)
+    sync()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(img, loss_and_grads)
+    sync()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        fams = timer.summary()
+        roof = None
+        if fams:
+            dom = max(fams, key=lambda k: fams[k]["seconds"])
+            d = fams[dom]
+            ach = d["flops"] / d["seconds"] / 1e12
+            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
+                        unit="TFLOP/s", frac=round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4), traffic=None,
+                        avg_launch_us=round(d["seconds"] / d["launches"] * 1e6, 1), launches_per_step=d["launches"] // args.steps,
+                        families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / args.steps * 1e3, 2))
+                                  for k, v in fams.items()})
+        gf = FWD_GF_PER_IMAGE[args.model] * 3.0
+        out = {
+            "metric": "images/sec pretrain step (ViT-L+RVSA, 224^2, bf16)" if args.model == "vit_l" else "images/sec pretrain step (ViT-B+RVSA, 224^2)",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "%s + RVSA backbone fwd+bwd + grad all-reduce + clip + AdamW, 224x224, batch %d per GPU (BASELINE configs[2]/[3])"
+                                   % ("ViT-L" if args.model == "vit_l" else "ViT-B", B),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss)},
+            "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""CPU, world_size 2, gloo: the N > 1 path of mtp_amd.parallel -- flat reverse-execution-order layout, bucket partition,
+bucketed all-reduce == one big all-reduce, unused parameters excluded statically, optimizer schedule/segments."""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import mtp_amd
+from mtp_amd.parallel import ALIGN, FlatAdamW, FlatParams, GradReducer, execution_order
+
+
+def small():
+    torch.manual_seed(0)
+    return mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
+
+
+def test_execution_order_and_layout():
+    net = small()
+    ref = {n: p.detach().clone() for n, p in net.named_parameters()}
+    flat = FlatParams(net, unused=net._unused_params)
+    order, groups = execution_order([n for n, _ in net.named_parameters()], 6)
+    assert order[0].startswith("fpn") and order[-1].startswith("norm.")
+    gids = [flat.groups[n] for n in flat.names if flat.groups[n] is not None]
+    assert gids == sorted(gids, reverse=True)                      # FPN (6), blocks 5..0, embed (-1)
+    assert all(flat.groups[n] is None for n in ("norm.weight", "norm.bias"))
+    for n, p in net.named_parameters():                            # parameters are now views of the flat buffer, values kept
+        assert torch.equal(p.data, ref[n]) and flat.offsets[n] % ALIGN == 0
+        assert p.data.data_ptr() == flat.data.data_ptr() + 4 * flat.offsets[n]
+    assert flat.offsets["norm.weight"] >= flat.reduced              # never all-reduced / never stepped
+    assert set(flat.G) == set(ref) - {"norm.weight", "norm.bias"}
+    for bb in (1, 1 << 20, 1 << 40):
+        bk = flat.buckets(bb)
+        assert bk[0][1] == 0 and bk[-1][2] == flat.reduced and bk[-1][0] == -1
+        assert all(a[2] == b[1] for a, b in zip(bk, bk[1:]))        # disjoint cover of [0, reduced)
+    assert len(flat.buckets(1)) == 8 and len(flat.buckets(1 << 40)) == 1
+    st, wd = flat.weight_decay_segments(0.05)
+    by = dict(zip(flat.names, wd.tolist()))
+    assert by["pos_embed"] == 0 and by["blocks.0.attn.qkv.bias"] == 0 and by["blocks.0.norm1.weight"] == 0
+    assert by["blocks.0.attn.qkv.weight"] == pytest.approx(0.05) and by["blocks.0.attn.rel_pos_h"] == pytest.approx(0.05)
+    assert st.tolist() == sorted(st.tolist()) and all(s % 4 == 0 for s in st.tolist())
+
+
+def test_cosine_schedule_and_bias_correction():
+    class F:
+        pass
+    net = small()
+    flat = FlatParams(net, unused=net._unused_params)
+    opt = FlatAdamW.__new__(FlatAdamW)
+    opt.lr0, opt.betas, opt.eps, opt.total_steps, opt.t = 6e-5, (0.9, 0.999), 1e-8, 100, 0
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=6e-5), T_max=100)
+    for t in range(1, 6):
+        opt.t = t
+        hv = opt.hyper_values()
+        assert hv[0] == pytest.approx(sched.get_last_lr()[0], rel=1e-9)
+        assert hv[4] == pytest.approx(1 - 0.9 ** t) and hv[5] == pytest.approx(1 - 0.999 ** t)
+        sched.optimizer.step()
+        sched.step()
+    assert flat.total >= flat.reduced > 0 and math.isfinite(opt.lr_at(1000))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = small()
+        flat = FlatParams(net, unused=net._unused_params)
+        g = torch.Generator().manual_seed(100 + rank)
+        flat.grad.copy_(torch.randn(flat.total, generator=g))
+        local = flat.grad.clone()
+        ref = local.clone()
+        dist.all_reduce(ref)                                   # the single-tensor reference
+        red = GradReducer(flat, bucket_bytes=1 << 20)
+        assert red.world == world and len(red.buckets) > 2
+        order = [6] + list(range(5, -1, -1)) + [-1]             # the engine's completion order
+        for gid in order:
+            red.on_block_done(gid)
+        red.finish()
+        ok = torch.equal(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        q.put((rank, bool(ok), red.bytes_reduced == flat.reduced * 4))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_single_allreduce_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True, True), (1, True, True)]
