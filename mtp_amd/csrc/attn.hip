@@ -674,6 +674,10 @@ extern "C" int mtp_full_attn_fwd(const void* qkv, void* o, float* lse, int dtype
                                  int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream) {
     if (!qkv || !o || !lse || !rel_h || !rel_w || B <= 0 || Hp <= 0 || Wp <= 0 || heads <= 0) return MTP_ERR_ARG;
     if (hd != HD) return MTP_ERR_UNSUPPORTED;
+    if (dtype == MTP_BF16 && mtp_use_mfma_attn()) {
+        const int rc = mtp_full_fwd_mfma_launch(qkv, o, lse, rel_h, rel_w, B, Hp, Wp, heads, scale, (hipStream_t)stream);
+        if (rc != MTP_ERR_UNSUPPORTED) return rc;   // larger token grids fall through to the generic kernel
+    }
     const int N = (int)(Hp * Wp);
     const size_t lds = sizeof(float) * (size_t)(2 * KT * HD + (Hp + Wp) * 256 + KT * 256);
     if (lds > 160 * 1024) return MTP_ERR_UNSUPPORTED;
@@ -694,6 +698,10 @@ extern "C" int mtp_full_attn_bwd(const void* qkv, const void* o, const void* dou
                                  int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream) {
     if (!qkv || !o || !dout || !lse || !dqkv || !rel_h || !rel_w || !drel_part || B <= 0 || heads <= 0) return MTP_ERR_ARG;
     if (hd != HD) return MTP_ERR_UNSUPPORTED;
+    if (dtype == MTP_BF16 && mtp_use_mfma_attn()) {
+        const int rc = mtp_full_bwd_mfma_launch(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_part, B, Hp, Wp, heads, scale, (hipStream_t)stream);
+        if (rc != MTP_ERR_UNSUPPORTED) return rc;
+    }
     const int N = (int)(Hp * Wp);
     if (N > 256 || (2 * Hp - 1) + (2 * Wp - 1) > 4 * MAXR) return MTP_ERR_UNSUPPORTED;   // single-workgroup backward (224^2..256^2 inputs)
     const size_t lds = sizeof(float) * (size_t)(2 * (Hp + Wp) * 256 + 512 + 2 * KT * HD);

@@ -91,23 +91,30 @@ __device__ __forceinline__ uint4 table_frag_t(const float* __restrict__ tab, int
 
 // lane = key: bilinear gather of this key's K/V rows (f32 blend of <= 4 bf16 token rows)
 __device__ __forceinline__ void gather_kv(const RvsaGeom& g, const Sample& s, const bf16_t* __restrict__ base, int64_t ld, int C, float (&ks)[HD], float (&vs)[HD]) {
+    // branch-free: an out-of-map neighbour reads token 0 with weight 0 (a branch around the loads would make hipcc wait for
+    // every neighbour separately; this way all 64 row loads are in flight together)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float w;
         const int tok = neighbour(g, s.x0, s.y0, s.fx, s.fy, k, w);
-        if (tok >= 0) {
+        const int tc = tok >= 0 ? tok : 0;
+        w = tok >= 0 ? w : 0.f;
 #pragma unroll
-            for (int i = 0; i < HD / 8; ++i) {
-                float t[8];
-                load8(base + C + (int64_t)tok * ld + 8 * i, t);
+        for (int i = 0; i < HD / 8; ++i) {
+            float t[8];
+            load8(base + C + (int64_t)tc * ld + 8 * i, t);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ks[8 * i + e] += w * t[e];
-                load8(base + 2 * C + (int64_t)tok * ld + 8 * i, t);
+            for (int e = 0; e < 8; ++e) ks[8 * i + e] += w * t[e];
+            load8(base + 2 * C + (int64_t)tc * ld + 8 * i, t);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) vs[8 * i + e] += w * t[e];
-            }
+            for (int e = 0; e < 8; ++e) vs[8 * i + e] += w * t[e];
         }
     }
+}
+__device__ __attribute__((aligned(16))) const uint4 g_zero16a = {0u, 0u, 0u, 0u};
+// 16-byte fragment of row `tok` (or zeros when tok < 0) without a branch around the load
+__device__ __forceinline__ uint4 row_frag(const bf16_t* __restrict__ rows, int64_t ld, int tok, int e0) {
+    return ldg16(tok >= 0 ? reinterpret_cast<const char*>(rows + (int64_t)tok * ld + e0) : reinterpret_cast<const char*>(&g_zero16a));
 }
 __device__ __forceinline__ void put_row_swz(char* img, int row, const float (&v)[HD]) {
 #pragma unroll
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(64) void rvsa_fwd_mfma_kernel(const bf16_t* __restr
         qtok[qt] = n < 49 ? query_token(g, n, wi, wj) : -1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            qf[qt][ks] = qtok[qt] >= 0 ? *reinterpret_cast<const uint4*>(base + (int64_t)qtok[qt] * ld + ks * 32 + gq * 8) : make_uint4(0, 0, 0, 0);
+            qf[qt][ks] = row_frag(base, ld, qtok[qt], ks * 32 + gq * 8);
     }
     // ---- QR[t*13 + r][query] = q . rel_t[r]
 #pragma unroll
@@ -214,12 +221,10 @@ __global__ __launch_bounds__(64) void rvsa_fwd_mfma_kernel(const bf16_t* __restr
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = 16 * kt + 4 * gq + r;
-                float v = -INFINITY;
-                if (key < 49) {
-                    const int ak = (key * 37) >> 8, bk = key - 7 * ak, dh = aq - ak + 6, dw = bq - bk + 6;
-                    v = scale * s[kt][qt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
-                }
+                const int key = 16 * kt + 4 * gq + r, kc = key < 48 ? key : 48;   // branch-free: clamped indices + select
+                const int ak = (kc * 37) >> 8, bk = kc - 7 * ak, dh = aq - ak + 6, dw = bq - bk + 6;
+                float v = scale * s[kt][qt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
+                v = key < 49 ? v : -INFINITY;
                 s[kt][qt][r] = v;
                 m = fmaxf(m, v);
             }
@@ -325,15 +330,17 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
     {   // ---- lane = query: delta = dO . O, lse
         float dl = 0.f, ls = 0.f;
         const int tok = lane < 49 ? query_token(g, lane, wi, wj) : -1;
-        if (tok >= 0) {
+        {
+            const int tc = tok >= 0 ? tok : 0;
 #pragma unroll
             for (int i = 0; i < HD / 8; ++i) {
                 float a[8], c[8];
-                load8(dob + (int64_t)tok * C + 8 * i, a);
-                load8(o + ((int64_t)b * N + tok) * C + h * HD + 8 * i, c);
+                load8(dob + (int64_t)tc * C + 8 * i, a);
+                load8(o + ((int64_t)b * N + tc) * C + h * HD + 8 * i, c);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dl += a[e] * c[e];
             }
+            dl = tok >= 0 ? dl : 0.f;
         }
         if (lane < 49) ls = lse[(int64_t)blockIdx.x * 49 + lane];
         delta[lane] = dl;
@@ -348,8 +355,8 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
         qtok[qt] = n < 49 ? query_token(g, n, wi, wj) : -1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qf[qt][ks] = qtok[qt] >= 0 ? *reinterpret_cast<const uint4*>(base + (int64_t)qtok[qt] * ld + ks * 32 + gq * 8) : make_uint4(0, 0, 0, 0);
-            dof[qt][ks] = qtok[qt] >= 0 ? *reinterpret_cast<const uint4*>(dob + (int64_t)qtok[qt] * C + ks * 32 + gq * 8) : make_uint4(0, 0, 0, 0);
+            qf[qt][ks] = row_frag(base, ld, qtok[qt], ks * 32 + gq * 8);
+            dof[qt][ks] = row_frag(dob, C, qtok[qt], ks * 32 + gq * 8);
         }
     }
 #pragma unroll
@@ -403,16 +410,14 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = 16 * kt + 4 * gq + r;
-                    float ds = 0.f;
-                    if (key < 49 && n < 49) {
-                        const int ak = (key * 37) >> 8, bk = key - 7 * ak, dh = aq - ak + 6, dw = bq - bk + 6;
-                        const float v = scale * sT[kt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
-                        ds = __expf(v - ls) * (dpT[kt][r] - dl);
-                        atomicAdd(&dQR[dh * 64 + n], ds);
-                        atomicAdd(&dQR[(13 + dw) * 64 + n], ds);
-                        atomicAdd(&dtab[dh * 13 + dw], ds);
-                    }
+                    const int key = 16 * kt + 4 * gq + r, kc = key < 48 ? key : 48;
+                    const int ak = (kc * 37) >> 8, bk = kc - 7 * ak, dh = aq - ak + 6, dw = bq - bk + 6;
+                    const float v = scale * sT[kt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
+                    float ds = __expf(fminf(v - ls, 30.f)) * (dpT[kt][r] - dl);
+                    ds = (key < 49 && n < 49) ? ds : 0.f;      // masked pairs add 0 (branch-free LDS atomics)
+                    atomicAdd(&dQR[dh * 64 + n], ds);
+                    atomicAdd(&dQR[(13 + dw) * 64 + n], ds);
+                    atomicAdd(&dtab[dh * 13 + dw], ds);
                     sT[kt][r] = ds * scale;
                 }
             uint4 dsf[2];
@@ -448,8 +453,8 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
         uint4 rq[8], rd[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            rq[c] = tok >= 0 ? *reinterpret_cast<const uint4*>(base + (int64_t)tok * ld + 8 * c) : make_uint4(0, 0, 0, 0);
-            rd[c] = tok >= 0 ? *reinterpret_cast<const uint4*>(dob + (int64_t)tok * C + 8 * c) : make_uint4(0, 0, 0, 0);
+            rq[c] = row_frag(base, ld, tok, 8 * c);
+            rd[c] = row_frag(dob, C, tok, 8 * c);
         }
         put_col_t_bits(Qt, lane, rq);
         put_col_t_bits(dOt, lane, rd);
@@ -519,16 +524,13 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
             for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = 16 * qt + 4 * gq + r;
-                    float p = 0.f, ds = 0.f;
-                    if (n < 49 && key < 49) {
-                        const int aq = (n * 37) >> 8, bq = n - 7 * aq, dh = aq - ak + 6, dw = bq - bk + 6;
-                        const float v = scale * sB[qt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
-                        p = __expf(v - lses[n]);
-                        ds = p * (dpB[qt][r] - delta[n]) * scale;
-                    }
+                    const int n = 16 * qt + 4 * gq + r, nc = n < 48 ? n : 48;
+                    const int aq = (nc * 37) >> 8, bq = nc - 7 * aq, dh = aq - ak + 6, dw = bq - bk + 6;
+                    const float v = scale * sB[qt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
+                    float p = __expf(fminf(v - lses[n], 30.f));
+                    p = (n < 49 && key < 49) ? p : 0.f;
                     sB[qt][r] = p;
-                    dpB[qt][r] = ds;
+                    dpB[qt][r] = p * (dpB[qt][r] - delta[n]) * scale;
                 }
             uint4 pfb[2], dsfb[2];
 #pragma unroll
@@ -547,7 +549,41 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
                     dvs[dt] = mma(dotf[dt][kk], pfb[kk], dvs[dt]);
                 }
             }
-            // ---- scatter through this key's bilinear footprint + coordinate gradients
+            // ---- scatter: the SAME products in the other orientation (operands swapped: lane = (d = 16dt + fr; keys 4gq + r)) so that
+            //      one atomic instruction covers 16 consecutive channels (64 B) of 4 tokens instead of 4-byte pieces of 16 tokens
+            {
+                f32x4_t dk2[4], dv2[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dk2[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    dv2[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        dk2[dt] = mma(dsfb[kk], qtf[dt][kk], dk2[dt]);
+                        dv2[dt] = mma(pfb[kk], dotf[dt][kk], dv2[dt]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key2 = 16 * kt + 4 * gq + r, k2 = key2 < 48 ? key2 : 48;
+                    const float fx2 = smp[0 * 64 + k2], fy2 = smp[1 * 64 + k2];
+                    const int x02 = __float_as_int(smp[2 * 64 + k2]), y02 = __float_as_int(smp[3 * 64 + k2]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float w;
+                        const int tok = key2 < 49 ? neighbour(g, x02, y02, fx2, fy2, k, w) : -1;
+                        if (tok >= 0) {
+                            float* drow = dkv + ((int64_t)b * N + tok) * (2 * C) + h * HD + fr;
+#pragma unroll
+                            for (int dt = 0; dt < 4; ++dt) {
+                                atomicAdd(drow + 16 * dt, w * dk2[dt][r]);
+                                atomicAdd(drow + C + 16 * dt, w * dv2[dt][r]);
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- coordinate gradients of this lane's key (16kt + fr)
             const float fx = smp[0 * 64 + kc], fy = smp[1 * 64 + kc];
             const int x0 = __float_as_int(smp[2 * 64 + kc]), y0 = __float_as_int(smp[3 * 64 + kc]);
             float dix = 0.f, diy = 0.f;
@@ -556,21 +592,17 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
                 float w;
                 const int tok = key < 49 ? neighbour(g, x0, y0, fx, fy, k, w) : -1;
                 float dot = 0.f;
-                if (tok >= 0) {
-                    float* dkrow = dkv + ((int64_t)b * N + tok) * (2 * C) + h * HD + 4 * gq;
-                    const bf16_t* krow = base + C + (int64_t)tok * ld + 4 * gq;
-                    const bf16_t* vrow = base + 2 * C + (int64_t)tok * ld + 4 * gq;
+                {   // loads unconditional on a clamped token (see gather_kv); only the atomics are predicated
+                    const int tc = tok >= 0 ? tok : 0;
+                    const bf16_t* krow = base + C + (int64_t)tc * ld + 4 * gq;
+                    const bf16_t* vrow = base + 2 * C + (int64_t)tc * ld + 4 * gq;
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
                         const float4 kv = load4(krow + 16 * dt), vv = load4(vrow + 16 * dt);
                         dot += dks[dt][0] * kv.x + dks[dt][1] * kv.y + dks[dt][2] * kv.z + dks[dt][3] * kv.w
                              + dvs[dt][0] * vv.x + dvs[dt][1] * vv.y + dvs[dt][2] * vv.z + dvs[dt][3] * vv.w;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            atomicAdd(dkrow + 16 * dt + r, w * dks[dt][r]);
-                            atomicAdd(dkrow + C + 16 * dt + r, w * dvs[dt][r]);
-                        }
                     }
+                    dot = tok >= 0 ? dot : 0.f;
                 }
                 dot += __shfl_xor(dot, 16, 64);
                 dot += __shfl_xor(dot, 32, 64);

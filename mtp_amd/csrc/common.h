@@ -79,6 +79,18 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&o)[8]) {
     *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
 }
 
+// 16-byte load that is guaranteed to be a global_load (not flat_load): needed when the pointer comes out of a select
+// (a flat load also counts on lgkmcnt and forces a vmcnt(0) before the next LDS access)
+__device__ __forceinline__ uint4 ldg16(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const u32x4_t v = *(const __attribute__((address_space(1))) u32x4_t*)(uintptr_t)p;
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
 // exact-erf GELU (nn.GELU default) and its derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_f(float x) {

@@ -296,20 +296,24 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __res
     }
 }
 // dw (N,K) = dy^T x ; db[n] = sum_r dy[r][n]
+// rows split over blockIdx.y (16 rows per block) with f32 atomics into the zeroed outputs: the op is tiny (80 x 1024 outputs)
+// and a single pass over all R rows per thread left the chip idle for 100 us
 __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K) {
     const int K4 = K / 4;
+    const int r0 = blockIdx.y * 16, r1 = (r0 + 16) < R ? (r0 + 16) : R;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)N * K4; i += (int64_t)gridDim.x * 256) {
         const int k4 = (int)(i % K4), n = (int)(i / K4);
         float4 s = make_float4(0, 0, 0, 0);
         float sb = 0.f;
-        for (int r = 0; r < R; ++r) {
+        for (int r = r0; r < r1; ++r) {
             const float d = dy[(int64_t)r * N + n];
             const float4 xv = load4(x + (int64_t)r * K + 4 * k4);
             s.x += d * xv.x; s.y += d * xv.y; s.z += d * xv.z; s.w += d * xv.w;
             sb += d;
         }
-        store4(dw + (int64_t)n * K + 4 * k4, s);
-        if (k4 == 0 && db) db[n] = sb;
+        float* o = dw + (int64_t)n * K + 4 * k4;
+        atomicAdd(o, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
+        if (k4 == 0 && db) atomicAdd(db + n, sb);
     }
 }
 
@@ -505,7 +509,11 @@ extern "C" int mtp_small_linear_bwd(const float* x, const float* w, const float*
     if (!x || !w || !dy || R <= 0 || N <= 0 || (K % 4)) return MTP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (dx) hipLaunchKernelGGL(small_linear_dx_kernel, dim3(blocks_for(R * K / 4, 256, 4096)), dim3(256), 0, s, dy, w, dx, (int)R, (int)N, (int)K);
-    if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(blocks_for(N * K / 4, 256, 4096)), dim3(256), 0, s, dy, x, dw, db, (int)R, (int)N, (int)K);
+    if (dw) {
+        (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)(N * K), s);
+        if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s);
+        hipLaunchKernelGGL(small_linear_dw_kernel, dim3(blocks_for(N * K / 4, 256, 4096), (unsigned)((R + 15) / 16)), dim3(256), 0, s, dy, x, dw, db, (int)R, (int)N, (int)K);
+    }
     return mtp_launch_status();
 }
 

@@ -44,6 +44,9 @@ struct Mma<float> {
     }
 };
 
+// 16 zero bytes in HBM: out-of-range tile elements load from here (address select BEFORE the load keeps it branch-free)
+__device__ __attribute__((aligned(16))) const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
 
 // bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous range of tiles
@@ -71,7 +74,20 @@ struct KArgs {
     int k_tiles;          // total k tiles
     int k_tiles_per_split;
     int atomic_out;
+    int64_t split_stride;   // TN split-K with workspace: partial tile of split z lives at C + z*split_stride (f32 elements)
 };
+
+// out[i] = sum_s part[s][i]   (float4 granules; deterministic split-K reduction)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n4, int split) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
+        for (int z = 1; z < split; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(part + 4 * (i + (int64_t)z * n4));
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + 4 * i) = s;
+    }
+}
 
 // ---- one 128x128 tile's worth of MFMAs out of one LDS stage ------------------------------------------------------
 template <typename T>
@@ -97,42 +113,62 @@ template <typename Tout, int EPI>
 __device__ __forceinline__ void epilogue(const KArgs& p, f32x4_t (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
     const int fr = lane & 15, g = lane >> 4;
     Tout* C = reinterpret_cast<Tout*>(p.C);
+    // All epilogue LOADS are unconditional on clamped addresses (a branch around a load makes hipcc wait for it inside
+    // the branch: 16 serialised HBM latencies per tile); only the stores are predicated.
+    int nn[4];
+    bool nok[4];
+    float4 bias[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + g * 4;
+        nok[ni] = n < p.N;
+        nn[ni] = nok[ni] ? n : 0;
+        const float* bp = (EPI != MTP_EPI_DGELU && p.bias) ? p.bias + (p.bias_mod > 0 ? nn[ni] % p.bias_mod : nn[ni]) : reinterpret_cast<const float*>(&g_zero16);
+        const uint4 b = ldg16(bp);
+        bias[ni] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + fr;
-        if (m >= p.M) continue;
+        const bool mok = m < p.M;
+        const int mc = mok ? m : 0;
+        if (p.atomic_out) {   // split-K weight gradient: f32 atomics into a zeroed buffer
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                if (mok && nok[ni]) {
+                    float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nn[ni];
+                    atomicAdd(c + 0, acc[ni][mi][0]); atomicAdd(c + 1, acc[ni][mi][1]); atomicAdd(c + 2, acc[ni][mi][2]); atomicAdd(c + 3, acc[ni][mi][3]);
+                }
+            continue;
+        }
         float rs = 1.0f;
-        const float* resrow = nullptr;
+        float4 side[4];
         if (EPI == MTP_EPI_BIAS_RES) {
-            if (p.rowscale) rs = p.rowscale[m / p.rows_per_sample];
-            resrow = p.res + (int64_t)(p.res_mod > 0 ? m % p.res_mod : m) * p.res_ld;
+            const float* rsp = p.rowscale ? p.rowscale + mc / p.rows_per_sample : nullptr;
+            const float* resrow = p.res + (int64_t)(p.res_mod > 0 ? mc % p.res_mod : mc) * p.res_ld;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const uint4 r = ldg16(resrow + nn[ni]);
+                side[ni] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+            }
+            if (rsp) rs = *rsp;
+        } else if (EPI == MTP_EPI_DGELU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) side[ni] = load4(reinterpret_cast<const Tout*>(p.aux) + (int64_t)mc * p.aux_ld + nn[ni]);
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + g * 4;
-            if (n >= p.N) continue;
-            float4 v = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
-            if (p.atomic_out) {   // split-K weight gradient: f32 atomics into a zeroed buffer
-                float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-                atomicAdd(c + 0, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w);
-                continue;
-            }
-            if (EPI != MTP_EPI_DGELU && p.bias) {
-                const int bn = p.bias_mod > 0 ? n % p.bias_mod : n;
-                float4 b = *reinterpret_cast<const float4*>(p.bias + bn);
-                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-            }
+            float4 v = make_float4(acc[ni][mi][0] + bias[ni].x, acc[ni][mi][1] + bias[ni].y, acc[ni][mi][2] + bias[ni].z, acc[ni][mi][3] + bias[ni].w);
+            const bool ok = mok && nok[ni];
             if (EPI == MTP_EPI_BIAS_GELU) {
-                store4(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, v);
+                if (ok) store4(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + nn[ni], v);
                 v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
             } else if (EPI == MTP_EPI_DGELU) {
-                float4 u = load4(reinterpret_cast<const Tout*>(p.aux) + (int64_t)m * p.aux_ld + n);
-                v = make_float4(v.x * dgelu_f(u.x), v.y * dgelu_f(u.y), v.z * dgelu_f(u.z), v.w * dgelu_f(u.w));
+                v = make_float4(v.x * dgelu_f(side[ni].x), v.y * dgelu_f(side[ni].y), v.z * dgelu_f(side[ni].z), v.w * dgelu_f(side[ni].w));
             } else if (EPI == MTP_EPI_BIAS_RES) {
-                float4 r = *reinterpret_cast<const float4*>(resrow + n);
-                v = make_float4(r.x + rs * v.x, r.y + rs * v.y, r.z + rs * v.z, r.w + rs * v.w);
+                v = make_float4(side[ni].x + rs * v.x, side[ni].y + rs * v.y, side[ni].z + rs * v.z, side[ni].w + rs * v.w);
             }
-            store4(C + (int64_t)m * p.ldc + n, v);
+            if (ok) store4(C + (int64_t)m * p.ldc + nn[ni], v);
         }
     }
 }
@@ -164,6 +200,7 @@ __device__ __forceinline__ void stage_nt_glds(const KArgs& p, char* sA, char* sB
 template <typename T>
 struct NtRegs {
     uint4 a[4], b[4];
+    uint32_t ok;    // bits 0-3: a[i] in range, bits 4-7: b[i] in range
 };
 template <typename T>
 __device__ __forceinline__ void load_nt_regs(const KArgs& p, NtRegs<T>& r, int m0, int n0, int kt, int tid) {
@@ -171,13 +208,20 @@ __device__ __forceinline__ void load_nt_regs(const KArgs& p, NtRegs<T>& r, int m
     const int c = tid & 7;
     const int k = kt * 8 * E + c * E;
     const bool kok = k < p.K;
+    uint32_t okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 3) + 32 * i;
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        r.a[i] = (kok && m0 + row < p.M) ? *reinterpret_cast<const uint4*>(p.A + ((int64_t)(m0 + row) * p.lda + k) * (int64_t)sizeof(T)) : z;
-        r.b[i] = (kok && n0 + row < p.N) ? *reinterpret_cast<const uint4*>(p.B + ((int64_t)(n0 + row) * p.ldb + k) * (int64_t)sizeof(T)) : z;
+        const bool oka = kok && (m0 + row < p.M), okb = kok && (n0 + row < p.N);
+        okm |= (oka ? (1u << i) : 0u) | (okb ? (16u << i) : 0u);
+        r.a[i] = ldg16(p.A + (oka ? ((int64_t)(m0 + row) * p.lda + k) * (int64_t)sizeof(T) : 0));
+        r.b[i] = ldg16(p.B + (okb ? ((int64_t)(n0 + row) * p.ldb + k) * (int64_t)sizeof(T) : 0));
     }
+    r.ok = okm;
+}
+__device__ __forceinline__ uint4 mask4(const uint4& v, uint32_t okm, int e) {
+    const uint32_t m = (okm >> e) & 1u ? 0xffffffffu : 0u;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
 }
 template <typename T>
 __device__ __forceinline__ void store_nt_regs(const NtRegs<T>& r, char* sA, char* sB, int tid) {
@@ -185,8 +229,8 @@ __device__ __forceinline__ void store_nt_regs(const NtRegs<T>& r, char* sA, char
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 3) + 32 * i;
-        *reinterpret_cast<uint4*>(sA + lds_off(row, c)) = r.a[i];
-        *reinterpret_cast<uint4*>(sB + lds_off(row, c)) = r.b[i];
+        *reinterpret_cast<uint4*>(sA + lds_off(row, c)) = mask4(r.a[i], r.ok, i);
+        *reinterpret_cast<uint4*>(sB + lds_off(row, c)) = mask4(r.b[i], r.ok, 4 + i);
     }
 }
 
@@ -223,9 +267,11 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             __syncthreads();
             char* cur = smem + (kt & 1) * STAGE_BYTES;
             char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            if (kt + 1 < nk) load_nt_regs<T>(p, r, m0, n0, kt + 1, tid);
+            load_nt_regs<T>(p, r, m0, n0, kt + 1 < nk ? kt + 1 : kt, tid);   // unconditional prefetch (see gemm_tn_kernel)
+            __builtin_amdgcn_sched_barrier(0);
             compute_stage<T>(cur, cur + OPER_BYTES, acc, wm, wn, lane);
-            if (kt + 1 < nk) store_nt_regs<T>(r, nxt, nxt + OPER_BYTES, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            store_nt_regs<T>(r, nxt, nxt + OPER_BYTES, tid);
         }
     }
     epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
@@ -249,9 +295,10 @@ struct TnItems<float> {
 template <typename T>
 struct TnRegs {
     uint4 v[TnItems<T>::kItems][Elem<T>::kPerChunk];
+    uint32_t ok[TnItems<T>::kItems];   // bit e: row e of the block is in range (else it is zeroed in the store phase)
 };
 
-template <typename T>
+template <typename T, bool FULL>
 __device__ __forceinline__ void load_tn_regs(const KArgs& p, TnRegs<T>& r, int m0, int n0, int kt, int tid) {
     constexpr int E = Elem<T>::kPerChunk;
     constexpr int NB = 8 * (BM / E);   // blocks per operand
@@ -264,14 +311,31 @@ __device__ __forceinline__ void load_tn_regs(const KArgs& p, TnRegs<T>& r, int m
         const int64_t ld = oper ? p.ldb : p.lda;
         const int x = (oper ? n0 : m0) + xb * E;
         const int xlim = oper ? p.N : p.M;
+        // Unconditional loads from CLAMPED OFFSETS; out-of-range rows are zeroed later, in the store phase.  (`cond ? load : 0`
+        // makes hipcc branch around every load with a vmcnt(0) inside; a select between two POINTERS is lowered to exec-masked
+        // blocks as well; a select on the loaded VALUE here would pull the vmcnt wait in front of the MFMAs.)
+        // FULL (every tile complete: the training shapes) has no predicates at all -- hipcc keeps re-introducing exec-masked
+        // blocks + early vmcnt waits around predicated loads, whichever way the predicate is written.
+        uint32_t okm = 0;
+        if (FULL) {
+            const char* base = src + ((int64_t)(kt * 8 * E + kb * E) * ld + x) * (int64_t)sizeof(T);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int k = kt * 8 * E + kb * E + e;
-            r.v[it][e] = (k < p.K && x < xlim) ? *reinterpret_cast<const uint4*>(src + ((int64_t)k * ld + x) * (int64_t)sizeof(T))
-                                              : make_uint4(0, 0, 0, 0);
+            for (int e = 0; e < E; ++e) r.v[it][e] = ldg16(base + (int64_t)e * ld * (int64_t)sizeof(T));
+            okm = 0xffu;
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int k = kt * 8 * E + kb * E + e;
+                const bool ok = (k < p.K) && (x < xlim);
+                okm |= ok ? (1u << e) : 0u;
+                const int64_t off = ok ? ((int64_t)k * ld + x) * (int64_t)sizeof(T) : 0;
+                r.v[it][e] = ldg16(src + off);
+            }
         }
+        r.ok[it] = okm;
     }
 }
+
 
 __device__ __forceinline__ uint32_t dw(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
@@ -289,7 +353,9 @@ __device__ __forceinline__ void store_tn_regs<float>(const TnRegs<float>& r, cha
         char* s = st + oper * OPER_BYTES;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {   // out row f = column f of the 4x4 block
-            uint4 o = make_uint4(dw(r.v[it][0], f), dw(r.v[it][1], f), dw(r.v[it][2], f), dw(r.v[it][3], f));
+            const uint32_t okm = r.ok[it];
+            uint4 o = make_uint4((okm & 1u) ? dw(r.v[it][0], f) : 0u, (okm & 2u) ? dw(r.v[it][1], f) : 0u,
+                                 (okm & 4u) ? dw(r.v[it][2], f) : 0u, (okm & 8u) ? dw(r.v[it][3], f) : 0u);
             *reinterpret_cast<uint4*>(s + lds_off(xb * E + f, kb)) = o;
         }
     }
@@ -301,12 +367,15 @@ __device__ __forceinline__ void store_tn_regs<bf16_t>(const TnRegs<bf16_t>& r, c
     const int oper = tid / NB, blk = tid % NB;
     const int kb = blk & 7, xb = blk >> 3;
     char* s = st + oper * OPER_BYTES;
+    uint4 v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = mask4(r.v[0][e], r.ok[0], e);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {       // source dword d holds columns f = 2d (lo half), 2d+1 (hi half)
         uint32_t lo[4], hi[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // output dword q holds k = 2q (lo), 2q+1 (hi)
-            const uint32_t e0 = dw(r.v[0][2 * q], d), e1 = dw(r.v[0][2 * q + 1], d);
+            const uint32_t e0 = dw(v[2 * q], d), e1 = dw(v[2 * q + 1], d);
             lo[q] = (e0 & 0xffffu) | (e1 << 16);
             hi[q] = (e0 >> 16) | (e1 & 0xffff0000u);
         }
@@ -315,7 +384,7 @@ __device__ __forceinline__ void store_tn_regs<bf16_t>(const TnRegs<bf16_t>& r, c
     }
 }
 
-template <typename T>
+template <typename T, bool FULL>
 __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_kernel(KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -326,6 +395,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     int kt1 = kt0 + p.k_tiles_per_split;
     kt1 = kt1 < p.k_tiles ? kt1 : p.k_tiles;
     if (kt0 >= kt1) return;
+    p.C += (int64_t)blockIdx.y * p.split_stride * (int64_t)sizeof(float);
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -334,15 +404,20 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     TnRegs<T> r;
-    load_tn_regs<T>(p, r, m0, n0, kt0, tid);
+    load_tn_regs<T, FULL>(p, r, m0, n0, kt0, tid);
     store_tn_regs<T>(r, smem, tid);
     for (int kt = kt0; kt < kt1; ++kt) {
         __syncthreads();
         char* cur = smem + ((kt - kt0) & 1) * STAGE_BYTES;
         char* nxt = smem + ((kt - kt0 + 1) & 1) * STAGE_BYTES;
-        if (kt + 1 < kt1) load_tn_regs<T>(p, r, m0, n0, kt + 1, tid);
+        // The prefetch is UNCONDITIONAL (the last iteration re-loads its own tile into the idle buffer): an `if` around it
+        // turns the registers into loop phis and hipcc copies them -- i.e. waits for the loads -- before the MFMAs.
+        const int ktn = kt + 1 < kt1 ? kt + 1 : kt;
+        load_tn_regs<T, FULL>(p, r, m0, n0, ktn, tid);
+        __builtin_amdgcn_sched_barrier(0);   // keep the 8 global loads ahead of the MFMAs (hipcc otherwise sinks them to their use)
         compute_stage<T>(cur, cur + OPER_BYTES, acc, wm, wn, lane);
-        if (kt + 1 < kt1) store_tn_regs<T>(r, nxt, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tn_regs<T>(r, nxt, tid);
     }
     epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -365,6 +440,7 @@ int fill_common(const mtp_gemm_args* a, KArgs& k) {
     k.k_tiles = (int)((a->K + 8 * E - 1) / (8 * E));
     k.k_tiles_per_split = k.k_tiles;
     k.atomic_out = 0;
+    k.split_stride = 0;
     return 0;
 }
 
@@ -400,15 +476,35 @@ int launch_tn(const mtp_gemm_args* a, hipStream_t stream) {
     if (split > k.k_tiles) split = k.k_tiles;
     k.k_tiles_per_split = (k.k_tiles + split - 1) / split;
     split = (k.k_tiles + k.k_tiles_per_split - 1) / k.k_tiles_per_split;
-    k.atomic_out = split > 1;
+    // split-K: with a caller workspace (args.aux, split*M*N f32) every split stores its partial tile and a second kernel
+    // sums them (deterministic; f32 atomics run at only ~80 G lane-ops/s and were slower than the GEMM itself);
+    // without a workspace fall back to atomics into the zeroed output.
+    const bool use_ws = split > 1 && a->aux != nullptr;
+    k.atomic_out = split > 1 && !use_ws;
+    k.split_stride = 0;
     if (split > 1) {
         if (a->ldc != a->N) return MTP_ERR_ARG;
-        hipError_t e = hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * (size_t)a->N, stream);
-        if (e != hipSuccess) return (int)e;
+        if (use_ws) {
+            if ((uintptr_t)a->aux & 15) return MTP_ERR_ARG;
+            k.C = (char*)a->aux;
+            k.split_stride = (int64_t)a->M * a->N;
+        } else {
+            hipError_t e = hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * (size_t)a->N, stream);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n, split), block(NT_THREADS);
-    hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, block, LDS_BYTES, stream, k);
+    const bool full = (a->K % (8 * E) == 0) && (a->M % BM == 0) && (a->N % BN == 0);
+    if (full)
+        hipLaunchKernelGGL((gemm_tn_kernel<T, true>), grid, block, LDS_BYTES, stream, k);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<T, false>), grid, block, LDS_BYTES, stream, k);
+    if (use_ws) {
+        const int64_t n4 = (int64_t)a->M * a->N / 4;
+        int64_t nb = (n4 + 255) / 256;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, stream, (const float*)a->aux, (float*)a->C, n4, split);
+    }
     return mtp_launch_status();
 }
 

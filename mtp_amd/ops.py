@@ -67,12 +67,13 @@ def gemm_nt(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0,
 
 
 def pick_split_k(M, N, K):
+    """enough (tile, split) work items for >= 2 resident workgroups on each of the 256 CUs"""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    split = max(1, min(16, round(1024 / tiles)))
-    return max(1, min(split, K // 512))
+    split = max(1, min(16, -(-640 // tiles)))
+    return max(1, min(split, K // 1024))
 
 
-def gemm_tn(a, b, out, split_k=None):
+def gemm_tn(a, b, out, split_k=None, use_workspace=True):
     """out (M,N) f32 = a (K,M)^T @ b (K,N)   (weight gradient dW = dY^T X)."""
     K, M = a.shape
     N = b.shape[1]
@@ -83,6 +84,9 @@ def gemm_tn(a, b, out, split_k=None):
     g.lda, g.ldb, g.ldc = M, N, N
     g.in_dtype, g.out_dtype, g.epilogue = _dt(a), MTP_F32, EPI_BIAS
     g.split_k = pick_split_k(M, N, K) if split_k is None else split_k
+    if g.split_k > 1 and use_workspace:
+        ws = torch.empty(g.split_k * M * N, device=out.device, dtype=torch.float32)   # split-K partials (summed by the callee)
+        g.aux = _p(ws)
     check(lib().mtp_gemm_tn(C.byref(g), _s()), "mtp_gemm_tn")
     return out
 
