@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtp_hip.so")
+LIB_PATH = os.environ.get("MTP_HIP_LIB") or os.path.join(_HERE, "libmtp_hip.so")   # MTP_HIP_LIB: A/B builds of the same ABI
 
 MTP_F32, MTP_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU = 0, 1, 2, 3

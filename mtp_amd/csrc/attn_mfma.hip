@@ -413,12 +413,18 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
                     const int key = 16 * kt + 4 * gq + r, kc = key < 48 ? key : 48;
                     const int ak = (kc * 37) >> 8, bk = kc - 7 * ak, dh = aq - ak + 6, dw = bq - bk + 6;
                     const float v = scale * sT[kt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
-                    float ds = __expf(fminf(v - ls, 30.f)) * (dpT[kt][r] - dl);
-                    ds = (key < 49 && n < 49) ? ds : 0.f;      // masked pairs add 0 (branch-free LDS atomics)
+                    float p = __expf(fminf(v - ls, 30.f));
+                    p = (key < 49 && n < 49) ? p : 0.f;        // masked pairs contribute 0 (branch-free LDS atomics)
+                    const float ds = p * (dpT[kt][r] - dl);
                     atomicAdd(&dQR[dh * 64 + n], ds);
                     atomicAdd(&dQR[(13 + dw) * 64 + n], ds);
                     atomicAdd(&dtab[dh * 13 + dw], ds);
                     sT[kt][r] = ds * scale;
+                    // P^T / dS^T images for the key-major phase (Ks/Vs are dead: their fragments live in kf/vf): [key][query] bf16,
+                    // 16-byte slots XOR-swizzled by the key so the 8-byte operand reads of phase B are conflict-free
+                    const int off = key * 128 + ((n * 2) ^ ((key & 7) << 4));
+                    *reinterpret_cast<uint16_t*>(Ks + off) = (uint16_t)f32_to_bf16_bits(p);
+                    *reinterpret_cast<uint16_t*>(Vs + off) = (uint16_t)f32_to_bf16_bits(ds * scale);
                 }
             uint4 dsf[2];
 #pragma unroll
@@ -502,41 +508,15 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
 #pragma unroll 1
         for (int kt = 0; kt < 4; ++kt) {
             const int key = 16 * kt + fr, kc = key < 48 ? key : 48;
-            const int ak = (kc * 37) >> 8, bk = kc - 7 * ak;
-            uint4 kfb[2], vfb[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                kfb[ks] = ld16(Ks + swz(key, ks * 4 + gq));
-                vfb[ks] = ld16(Vs + swz(key, ks * 4 + gq));
-            }
-            f32x4_t sB[4], dpB[4];
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                sB[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                dpB[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    sB[qt] = mma(qf[qt][ks], kfb[ks], sB[qt]);      // D[query = 16qt + 4gq + r][key = 16kt + fr]
-                    dpB[qt] = mma(dof[qt][ks], vfb[ks], dpB[qt]);
-                }
-            }
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = 16 * qt + 4 * gq + r, nc = n < 48 ? n : 48;
-                    const int aq = (nc * 37) >> 8, bq = nc - 7 * aq, dh = aq - ak + 6, dw = bq - bk + 6;
-                    const float v = scale * sB[qt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
-                    float p = __expf(fminf(v - lses[n], 30.f));
-                    p = (n < 49 && key < 49) ? p : 0.f;
-                    sB[qt][r] = p;
-                    dpB[qt][r] = p * (dpB[qt][r] - delta[n]) * scale;
-                }
+            // P and scale*dS of this key row, written by phase A into the (dead) Ks / Vs regions: operands for queries
+            // perm(gq, e) = {32kk + 4gq + e, 32kk + 16 + 4gq + e}  (no recomputation of S / exp in the key-major orientation)
             uint4 pfb[2], dsfb[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                pfb[kk] = pack_bf16x8(sB[2 * kk][0], sB[2 * kk][1], sB[2 * kk][2], sB[2 * kk][3], sB[2 * kk + 1][0], sB[2 * kk + 1][1], sB[2 * kk + 1][2], sB[2 * kk + 1][3]);
-                dsfb[kk] = pack_bf16x8(dpB[2 * kk][0], dpB[2 * kk][1], dpB[2 * kk][2], dpB[2 * kk][3], dpB[2 * kk + 1][0], dpB[2 * kk + 1][1], dpB[2 * kk + 1][2], dpB[2 * kk + 1][3]);
+                const int o0 = key * 128 + (((32 * kk + 4 * gq) * 2) ^ ((key & 7) << 4));
+                const int o1 = key * 128 + (((32 * kk + 16 + 4 * gq) * 2) ^ ((key & 7) << 4));
+                pfb[kk] = ld8x2(Ks + o0, Ks + o1);
+                dsfb[kk] = ld8x2(Vs + o0, Vs + o1);
             }
             f32x4_t dks[4], dvs[4];   // [dt]: lane (key = 16kt + fr; d = 16dt + 4gq + r)
 #pragma unroll
@@ -651,7 +631,8 @@ int mtp_rvsa_fwd_mfma_launch(const void* qkv, const float* samp, void* o, float*
     return mtp_launch_status();
 }
 
-int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse, void* dqkv, float* dkv, float* dsamp,
+// single-wave-per-problem backward (kept for A/B; the shipped launcher is the 4-wave kernel in attn_rvsa_bwd4.hip)
+int mtp_rvsa_bwd1_mfma_launch(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse, void* dqkv, float* dkv, float* dsamp,
                              float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     const RvsaGeom g = make_geom(Hp, Wp, heads);

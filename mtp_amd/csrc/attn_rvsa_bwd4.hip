@@ -1,0 +1,471 @@
+// 4-wave variant of the RVSA backward (see attn_mfma.hip for the algorithm and the single-wave forward).
+#include "attn_mfma.h"
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int TP = 136;   // byte pitch of the transposed [d][key|query] bf16 images (128 + 8: conflict-free 8-byte reads)
+
+struct RvsaGeom {
+    int Hp, Wp, He, We, pad_t, pad_l, nh, nw, heads;
+    float inv_div_x, inv_div_y;
+};
+struct Sample {
+    float fx, fy;
+    int x0, y0;
+    float rx, ry, cs, sn, relx, rely;
+};
+
+__device__ __forceinline__ Sample make_sample(const RvsaGeom& g, const float* __restrict__ sp, int h, int wi, int wj, int a, int bb) {
+    Sample s;
+    const int H = g.heads;
+    const float offx = sp[2 * h] * g.inv_div_x, offy = sp[2 * h + 1] * g.inv_div_y;
+    const float sx = sp[2 * H + 2 * h] + 1.0f, sy = sp[2 * H + 2 * h + 1] + 1.0f;
+    const float ang = sp[4 * H + h];
+    const float stepx = 2.0f / (float)(g.We - 1), stepy = 2.0f / (float)(g.He - 1);
+    const float cenx = -1.0f + stepx * (float)(7 * wj + 3), ceny = -1.0f + stepy * (float)(7 * wi + 3);
+    s.relx = (float)(bb - 3) * stepx;
+    s.rely = (float)(a - 3) * stepy;
+    s.rx = s.relx * sx;
+    s.ry = s.rely * sy;
+    s.cs = cosf(ang);
+    s.sn = sinf(ang);
+    const float gx = cenx + (s.rx * s.cs - s.ry * s.sn) + offx;
+    const float gy = ceny + (s.ry * s.cs + s.rx * s.sn) + offy;
+    float ix = (gx + 1.0f) * 0.5f * (float)(g.We - 1), iy = (gy + 1.0f) * 0.5f * (float)(g.He - 1);
+    ix = fminf(fmaxf(ix, -4.0f), (float)g.We + 4.0f);
+    iy = fminf(fmaxf(iy, -4.0f), (float)g.He + 4.0f);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    s.x0 = (int)fx0; s.y0 = (int)fy0;
+    s.fx = ix - fx0; s.fy = iy - fy0;
+    return s;
+}
+__device__ __forceinline__ int neighbour(const RvsaGeom& g, int x0, int y0, float fx, float fy, int k, float& w) {
+    const int dx = k & 1, dy = k >> 1;
+    const int xi = x0 + dx, yi = y0 + dy;
+    w = (dx ? fx : 1.0f - fx) * (dy ? fy : 1.0f - fy);
+    const int tx = xi - g.pad_l, ty = yi - g.pad_t;
+    if (xi < 0 || xi > g.We - 1 || yi < 0 || yi > g.He - 1 || tx < 0 || tx >= g.Wp || ty < 0 || ty >= g.Hp) return -1;
+    return ty * g.Wp + tx;
+}
+__device__ __forceinline__ int query_token(const RvsaGeom& g, int n, int wi, int wj) {   // n < 49
+    const int a = n / 7, bb = n - 7 * a;
+    const int ty = 7 * wi + a - g.pad_t, tx = 7 * wj + bb - g.pad_l;
+    return (ty >= 0 && ty < g.Hp && tx >= 0 && tx < g.Wp) ? ty * g.Wp + tx : -1;
+}
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint4 ld16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 ld8x2(const char* p0, const char* p1) {   // two 8-byte LDS reads -> one 8 x bf16 operand
+    const uint2 a = *reinterpret_cast<const uint2*>(p0), b = *reinterpret_cast<const uint2*>(p1);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+// 8 f32 table values (row r, elements e0..e0+7) -> bf16 operand; zero when the row is out of range
+__device__ __forceinline__ uint4 table_frag(const float* __restrict__ tab, int r, int rows, int e0) {
+    if (r >= rows) return make_uint4(0, 0, 0, 0);
+    const float4 a = *reinterpret_cast<const float4*>(tab + r * HD + e0), b = *reinterpret_cast<const float4*>(tab + r * HD + e0 + 4);
+    return pack_bf16x8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+// transposed table operand: lane (d, g) -> tab[8g+e][d], e = 0..7
+__device__ __forceinline__ uint4 table_frag_t(const float* __restrict__ tab, int d, int rows, int r0) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (r0 + e) < rows ? tab[(r0 + e) * HD + d] : 0.f;
+    return pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+
+// lane = key: bilinear gather of this key's K/V rows (f32 blend of <= 4 bf16 token rows)
+__device__ __forceinline__ void gather_kv(const RvsaGeom& g, const Sample& s, const bf16_t* __restrict__ base, int64_t ld, int C, float (&ks)[HD], float (&vs)[HD]) {
+    // branch-free: an out-of-map neighbour reads token 0 with weight 0 (a branch around the loads would make hipcc wait for
+    // every neighbour separately; this way all 64 row loads are in flight together)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float w;
+        const int tok = neighbour(g, s.x0, s.y0, s.fx, s.fy, k, w);
+        const int tc = tok >= 0 ? tok : 0;
+        w = tok >= 0 ? w : 0.f;
+#pragma unroll
+        for (int i = 0; i < HD / 8; ++i) {
+            float t[8];
+            load8(base + C + (int64_t)tc * ld + 8 * i, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ks[8 * i + e] += w * t[e];
+            load8(base + 2 * C + (int64_t)tc * ld + 8 * i, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vs[8 * i + e] += w * t[e];
+        }
+    }
+}
+__device__ __attribute__((aligned(16))) const uint4 g_zero16a = {0u, 0u, 0u, 0u};
+// 16-byte fragment of row `tok` (or zeros when tok < 0) without a branch around the load
+__device__ __forceinline__ uint4 row_frag(const bf16_t* __restrict__ rows, int64_t ld, int tok, int e0) {
+    return ldg16(tok >= 0 ? reinterpret_cast<const char*>(rows + (int64_t)tok * ld + e0) : reinterpret_cast<const char*>(&g_zero16a));
+}
+__device__ __forceinline__ void put_row_swz(char* img, int row, const float (&v)[HD]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<uint4*>(img + swz(row, c)) = pack_bf16x8(v[8 * c], v[8 * c + 1], v[8 * c + 2], v[8 * c + 3], v[8 * c + 4], v[8 * c + 5], v[8 * c + 6], v[8 * c + 7]);
+}
+__device__ __forceinline__ void put_col_t(char* img, int col, const float (&v)[HD]) {   // img[d][col] = v[d]
+#pragma unroll
+    for (int d = 0; d < HD; ++d) *reinterpret_cast<uint16_t*>(img + d * TP + col * 2) = (uint16_t)f32_to_bf16_bits(v[d]);
+}
+__device__ __forceinline__ void put_col_t_bits(char* img, int col, const uint4 (&rowbits)[8]) {   // 64 bf16 already packed
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t w[4] = {rowbits[c].x, rowbits[c].y, rowbits[c].z, rowbits[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<uint16_t*>(img + (8 * c + 2 * e) * TP + col * 2) = (uint16_t)(w[e] & 0xffffu);
+            *reinterpret_cast<uint16_t*>(img + (8 * c + 2 * e + 1) * TP + col * 2) = (uint16_t)(w[e] >> 16);
+        }
+    }
+}
+
+
+constexpr int SMP_F = 10;
+
+// ===================================================================================================================
+// RVSA backward, 4 waves per (image, window, head): wave w owns query tile w in the query-major phase and key tile w in the
+// key-major phase, so the problem's critical path is 4x shorter and 12 waves share a CU (3 workgroups x 4) instead of 3.
+// LDS: Ks | Vs (K_sel / V_sel rows, later P^T / dS^T) | R2 = {K^T} then {Q^T | dO^T} | QR | dQR | tab | dtab | lses | delta | smp | vsum
+// ===================================================================================================================
+__global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ samp, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                            const float* __restrict__ lse, bf16_t* __restrict__ dqkv, float* __restrict__ dkv, float* __restrict__ dsamp,
+                                                            float* __restrict__ rel_part, float* __restrict__ tab_part,
+                                                            const float* __restrict__ rel_h, const float* __restrict__ rel_w, const float* __restrict__ bias_table,
+                                                            RvsaGeom g, float scale) {
+    __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
+    __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+    __shared__ __attribute__((aligned(16))) char R2[2 * 64 * TP];
+    __shared__ float QR[26 * 64];
+    __shared__ float dQR[26 * 64];
+    __shared__ float tab[176];
+    __shared__ float dtab[176];
+    __shared__ float lses[64];
+    __shared__ float delta[64];
+    __shared__ float smp[SMP_F * 64];
+    __shared__ float vsum[8];
+    char* Kt = R2;
+    char* Qt = R2;
+    char* dOt = R2 + 64 * TP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, gq = lane >> 4;
+    const int H = g.heads, nW = g.nh * g.nw;
+    const int h = blockIdx.x % H, bw = blockIdx.x / H, b = bw / nW, win = bw % nW, wi = win / g.nw, wj = win % g.nw;
+    const int C = H * HD, N = g.Hp * g.Wp;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
+    const bf16_t* dob = dout + (int64_t)b * N * C + h * HD;
+
+    if (tid < 176) {
+        tab[tid] = tid < 169 ? bias_table[tid * H + h] : 0.f;
+        dtab[tid] = 0.f;
+    }
+    if (tid < 8) vsum[tid] = 0.f;
+    for (int i = tid; i < 26 * 64; i += 256) dQR[i] = 0.f;
+    {   // ---- gather: thread = (key = lane, 16-channel quarter = wave)
+        const int d0 = 16 * wave;
+        float ks[16], vs[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { ks[d] = 0.f; vs[d] = 0.f; }
+        Sample s;
+        s.fx = 0.f; s.fy = 0.f; s.x0 = -100; s.y0 = -100; s.rx = 0.f; s.ry = 0.f; s.cs = 1.f; s.sn = 0.f; s.relx = 0.f; s.rely = 0.f;
+        if (lane < 49) {
+            s = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, lane / 7, lane % 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float w;
+                const int tok = neighbour(g, s.x0, s.y0, s.fx, s.fy, k, w);
+                const int tc = tok >= 0 ? tok : 0;
+                w = tok >= 0 ? w : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float t[8];
+                    load8(base + C + (int64_t)tc * ld + d0 + 8 * i, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ks[8 * i + e] += w * t[e];
+                    load8(base + 2 * C + (int64_t)tc * ld + d0 + 8 * i, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vs[8 * i + e] += w * t[e];
+                }
+            }
+        }
+        if (wave == 0) {
+            smp[0 * 64 + lane] = s.fx; smp[1 * 64 + lane] = s.fy; smp[2 * 64 + lane] = __int_as_float(s.x0); smp[3 * 64 + lane] = __int_as_float(s.y0);
+            smp[4 * 64 + lane] = s.rx; smp[5 * 64 + lane] = s.ry; smp[6 * 64 + lane] = s.cs; smp[7 * 64 + lane] = s.sn;
+            smp[8 * 64 + lane] = s.relx; smp[9 * 64 + lane] = s.rely;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4*>(Ks + swz(lane, 2 * wave + i)) = pack_bf16x8(ks[8 * i], ks[8 * i + 1], ks[8 * i + 2], ks[8 * i + 3], ks[8 * i + 4], ks[8 * i + 5], ks[8 * i + 6], ks[8 * i + 7]);
+            *reinterpret_cast<uint4*>(Vs + swz(lane, 2 * wave + i)) = pack_bf16x8(vs[8 * i], vs[8 * i + 1], vs[8 * i + 2], vs[8 * i + 3], vs[8 * i + 4], vs[8 * i + 5], vs[8 * i + 6], vs[8 * i + 7]);
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) *reinterpret_cast<uint16_t*>(Kt + (d0 + d) * TP + lane * 2) = (uint16_t)f32_to_bf16_bits(ks[d]);
+    }
+    if (wave == 0) {   // ---- lane = query: delta = dO . O, lse
+        float dl = 0.f, ls = 0.f;
+        const int tok = lane < 49 ? query_token(g, lane, wi, wj) : -1;
+        const int tc = tok >= 0 ? tok : 0;
+#pragma unroll
+        for (int i = 0; i < HD / 8; ++i) {
+            float a[8], c[8];
+            load8(dob + (int64_t)tc * C + 8 * i, a);
+            load8(o + ((int64_t)b * N + tc) * C + h * HD + 8 * i, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += a[e] * c[e];
+        }
+        dl = tok >= 0 ? dl : 0.f;
+        if (lane < 49) ls = lse[(int64_t)blockIdx.x * 49 + lane];
+        delta[lane] = dl;
+        lses[lane] = ls;
+    }
+    // ---- this wave's query tile: Q / dO fragments and QR = tables x Q^T
+    const int qt = wave;
+    const int nA = 16 * qt + fr;
+    const int qtokA = nA < 49 ? query_token(g, nA, wi, wj) : -1;
+    uint4 qf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = row_frag(base, ld, qtokA, ks * 32 + gq * 8);
+        dof[ks] = row_frag(dob, C, qtokA, ks * 32 + gq * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float* tb = t ? rel_w : rel_h;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma(table_frag(tb, fr, 13, gq * 8), qf[0], acc);
+        acc = mma(table_frag(tb, fr, 13, 32 + gq * 8), qf[1], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            if (4 * gq + rr < 13) QR[(t * 13 + 4 * gq + rr) * 64 + nA] = acc[rr];
+    }
+    __syncthreads();
+
+    // ================= phase A: wave = query tile; lane (query; 4 keys) -> dQ, dQR, dtab, P^T / dS^T images ===============
+    {
+        uint4 kf[4][2], vf[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[kt][ks] = ld16(Ks + swz(16 * kt + fr, ks * 4 + gq));
+                vf[kt][ks] = ld16(Vs + swz(16 * kt + fr, ks * 4 + gq));
+            }
+        __syncthreads();   // every wave holds its K_sel / V_sel fragments: Ks / Vs may now be overwritten with P^T / dS^T
+        const int n = nA, nq = n < 48 ? n : 48;
+        const int aq = (nq * 37) >> 8, bq = nq - 7 * aq;
+        const float ls = lses[n], dl = delta[n];
+        f32x4_t sT[4], dpT[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            sT[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dpT[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                sT[kt] = mma(kf[kt][ks], qf[ks], sT[kt]);
+                dpT[kt] = mma(vf[kt][ks], dof[ks], dpT[kt]);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kt + 4 * gq + r, kc = key < 48 ? key : 48;
+                const int ak = (kc * 37) >> 8, bk = kc - 7 * ak, dh = aq - ak + 6, dw = bq - bk + 6;
+                const float v = scale * sT[kt][r] + QR[dh * 64 + n] + QR[(13 + dw) * 64 + n] + tab[dh * 13 + dw];
+                float p = __expf(fminf(v - ls, 30.f));
+                p = (key < 49 && n < 49) ? p : 0.f;
+                const float ds = p * (dpT[kt][r] - dl);
+                atomicAdd(&dQR[dh * 64 + n], ds);
+                atomicAdd(&dQR[(13 + dw) * 64 + n], ds);
+                atomicAdd(&dtab[dh * 13 + dw], ds);
+                sT[kt][r] = ds * scale;
+                const int off = key * 128 + ((n * 2) ^ ((key & 7) << 4));
+                *reinterpret_cast<uint16_t*>(Ks + off) = (uint16_t)f32_to_bf16_bits(p);
+                *reinterpret_cast<uint16_t*>(Vs + off) = (uint16_t)f32_to_bf16_bits(ds * scale);
+            }
+        uint4 dsf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            dsf[kk] = pack_bf16x8(sT[2 * kk][0], sT[2 * kk][1], sT[2 * kk][2], sT[2 * kk][3], sT[2 * kk + 1][0], sT[2 * kk + 1][1], sT[2 * kk + 1][2], sT[2 * kk + 1][3]);
+        __syncthreads();   // dQR / dtab / P^T / dS^T complete
+        float e[8], f[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int r = 8 * gq + x;
+            e[x] = r < 13 ? dQR[r * 64 + n] : 0.f;
+            f[x] = r < 13 ? dQR[(13 + r) * 64 + n] : 0.f;
+        }
+        const uint4 eh = pack_bf16x8(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+        const uint4 ew = pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const char* row = Kt + (16 * dt + fr) * TP;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) acc = mma(ld8x2(row + (32 * kk + 4 * gq) * 2, row + (32 * kk + 16 + 4 * gq) * 2), dsf[kk], acc);
+            acc = mma(table_frag_t(rel_h, 16 * dt + fr, 13, 8 * gq), eh, acc);
+            acc = mma(table_frag_t(rel_w, 16 * dt + fr, 13, 8 * gq), ew, acc);
+            if (qtokA >= 0) store4(dqkv + ((int64_t)b * N + qtokA) * ld + h * HD + 16 * dt + 4 * gq, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        }
+    }
+    __syncthreads();   // K^T no longer needed: R2 becomes Q^T | dO^T
+    {   // ---- thread = (query = lane, 16-channel quarter = wave)
+        const int tok = lane < 49 ? query_token(g, lane, wi, wj) : -1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int d0 = 16 * wave + 8 * i;
+            const uint4 rq = row_frag(base, ld, tok, d0), rd = row_frag(dob, C, tok, d0);
+            const uint32_t wq[4] = {rq.x, rq.y, rq.z, rq.w}, wd[4] = {rd.x, rd.y, rd.z, rd.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                *reinterpret_cast<uint16_t*>(Qt + (d0 + 2 * e) * TP + lane * 2) = (uint16_t)(wq[e] & 0xffffu);
+                *reinterpret_cast<uint16_t*>(Qt + (d0 + 2 * e + 1) * TP + lane * 2) = (uint16_t)(wq[e] >> 16);
+                *reinterpret_cast<uint16_t*>(dOt + (d0 + 2 * e) * TP + lane * 2) = (uint16_t)(wd[e] & 0xffffu);
+                *reinterpret_cast<uint16_t*>(dOt + (d0 + 2 * e + 1) * TP + lane * 2) = (uint16_t)(wd[e] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    {   // ---- table gradients: wave = d tile
+        float* rp = rel_part + (int64_t)blockIdx.x * 26 * HD;
+        const int dt = wave;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const char* row = Qt + (16 * dt + fr) * TP;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) v[x] = fr < 13 ? dQR[(t * 13 + fr) * 64 + 32 * ks + 8 * gq + x] : 0.f;
+                acc = mma(pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]), ld8x2(row + (32 * ks + 8 * gq) * 2, row + (32 * ks + 8 * gq + 4) * 2), acc);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (4 * gq + rr < 13) rp[(t * 13 + 4 * gq + rr) * HD + 16 * dt + fr] = acc[rr];
+        }
+        if (tid < 169) tab_part[(int64_t)blockIdx.x * 169 + tid] = dtab[tid];
+    }
+    // ================= phase B: wave = key tile; lane (key; 4 queries) -> dK_sel^T, dV_sel^T, scatter, coordinate gradients ==
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+    {
+        const int kt = wave;
+        const int key = 16 * kt + fr, kc = key < 48 ? key : 48;
+        uint4 pfb[2], dsfb[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int o0 = key * 128 + (((32 * kk + 4 * gq) * 2) ^ ((key & 7) << 4));
+            const int o1 = key * 128 + (((32 * kk + 16 + 4 * gq) * 2) ^ ((key & 7) << 4));
+            pfb[kk] = ld8x2(Ks + o0, Ks + o1);
+            dsfb[kk] = ld8x2(Vs + o0, Vs + o1);
+        }
+        f32x4_t dks[4], dvs[4], dk2[4], dv2[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dks[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvs[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dk2[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv2[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const char* rq = Qt + (16 * dt + fr) * TP;
+            const char* rd = dOt + (16 * dt + fr) * TP;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const uint4 qtf = ld8x2(rq + (32 * kk + 4 * gq) * 2, rq + (32 * kk + 16 + 4 * gq) * 2);
+                const uint4 dotf = ld8x2(rd + (32 * kk + 4 * gq) * 2, rd + (32 * kk + 16 + 4 * gq) * 2);
+                dks[dt] = mma(qtf, dsfb[kk], dks[dt]);     // lane (key = fr; d = 16dt + 4gq + r)   -> coordinate gradients
+                dvs[dt] = mma(dotf, pfb[kk], dvs[dt]);
+                dk2[dt] = mma(dsfb[kk], qtf, dk2[dt]);     // lane (d = 16dt + fr; key = 4gq + r)   -> coalesced scatter
+                dv2[dt] = mma(pfb[kk], dotf, dv2[dt]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key2 = 16 * kt + 4 * gq + r, k2 = key2 < 48 ? key2 : 48;
+            const float fx2 = smp[0 * 64 + k2], fy2 = smp[1 * 64 + k2];
+            const int x02 = __float_as_int(smp[2 * 64 + k2]), y02 = __float_as_int(smp[3 * 64 + k2]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float w;
+                const int tok = key2 < 49 ? neighbour(g, x02, y02, fx2, fy2, k, w) : -1;
+                if (tok >= 0) {
+                    float* drow = dkv + ((int64_t)b * N + tok) * (2 * C) + h * HD + fr;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        atomicAdd(drow + 16 * dt, w * dk2[dt][r]);
+                        atomicAdd(drow + C + 16 * dt, w * dv2[dt][r]);
+                    }
+                }
+            }
+        }
+        const float fx = smp[0 * 64 + kc], fy = smp[1 * 64 + kc];
+        const int x0 = __float_as_int(smp[2 * 64 + kc]), y0 = __float_as_int(smp[3 * 64 + kc]);
+        float dix = 0.f, diy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float w;
+            const int tok = key < 49 ? neighbour(g, x0, y0, fx, fy, k, w) : -1;
+            const int tc = tok >= 0 ? tok : 0;
+            const bf16_t* krow = base + C + (int64_t)tc * ld + 4 * gq;
+            const bf16_t* vrow = base + 2 * C + (int64_t)tc * ld + 4 * gq;
+            float dot = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float4 kv = load4(krow + 16 * dt), vv = load4(vrow + 16 * dt);
+                dot += dks[dt][0] * kv.x + dks[dt][1] * kv.y + dks[dt][2] * kv.z + dks[dt][3] * kv.w
+                     + dvs[dt][0] * vv.x + dvs[dt][1] * vv.y + dvs[dt][2] * vv.z + dvs[dt][3] * vv.w;
+            }
+            dot = tok >= 0 ? dot : 0.f;
+            dot += __shfl_xor(dot, 16, 64);
+            dot += __shfl_xor(dot, 32, 64);
+            const int dx = k & 1, dy = k >> 1;
+            dix += dot * (dy ? fy : 1.0f - fy) * (dx ? 1.0f : -1.0f);
+            diy += dot * (dx ? fx : 1.0f - fx) * (dy ? 1.0f : -1.0f);
+        }
+        if (gq == 0 && key < 49) {
+            const float rx = smp[4 * 64 + kc], ry = smp[5 * 64 + kc], cs = smp[6 * 64 + kc], sn = smp[7 * 64 + kc];
+            const float dgx = dix * 0.5f * (float)(g.We - 1), dgy = diy * 0.5f * (float)(g.He - 1);
+            v0 = dgx * g.inv_div_x;
+            v1 = dgy * g.inv_div_y;
+            v2 = (dgx * cs + dgy * sn) * smp[8 * 64 + kc];
+            v3 = (-dgx * sn + dgy * cs) * smp[9 * 64 + kc];
+            v4 = dgx * (-rx * sn - ry * cs) + dgy * (-ry * sn + rx * cs);
+        }
+    }
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
+    if (lane == 0) {
+        atomicAdd(&vsum[0], v0); atomicAdd(&vsum[1], v1); atomicAdd(&vsum[2], v2); atomicAdd(&vsum[3], v3); atomicAdd(&vsum[4], v4);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float* dp = dsamp + (int64_t)bw * 5 * H;
+        dp[2 * h] = vsum[0]; dp[2 * h + 1] = vsum[1]; dp[2 * H + 2 * h] = vsum[2]; dp[2 * H + 2 * h + 1] = vsum[3]; dp[4 * H + h] = vsum[4];
+    }
+}
+
+RvsaGeom make_geom(int64_t Hp, int64_t Wp, int64_t heads) {
+    RvsaGeom g;
+    const int pad_h = (int)((7 - Hp % 7) % 7), pad_w = (int)((7 - Wp % 7) % 7);
+    g.Hp = (int)Hp; g.Wp = (int)Wp;
+    g.pad_t = pad_h / 2; g.pad_l = pad_w / 2;
+    g.He = (int)Hp + pad_h; g.We = (int)Wp + pad_w;
+    g.nh = g.He / 7; g.nw = g.We / 7;
+    g.heads = (int)heads;
+    g.inv_div_x = 1.0f / (float)(Hp / 7);
+    g.inv_div_y = 1.0f / (float)(Wp / 7);
+    return g;
+}
+
+}  // namespace
+
+int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse, void* dqkv, float* dkv, float* dsamp,
+                             float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
+                             int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
+    const RvsaGeom g = make_geom(Hp, Wp, heads);
+    hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
+                       (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale);
+    return mtp_launch_status();
+}

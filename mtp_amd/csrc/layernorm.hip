@@ -173,11 +173,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, i
     int64_t r1 = r0 + rows_per_block;
     r1 = r1 < M ? r1 : M;
     float4 s = make_float4(0, 0, 0, 0);
-    if (n < N)
-        for (int64_t r = r0 + ry; r < r1; r += 4) {
+    if (n < N) {
+        int64_t r = r0 + ry;
+        for (; r + 12 < r1; r += 16) {   // 4 independent row loads in flight per thread
+            const float4 v0 = load4(dY + r * ld + n), v1 = load4(dY + (r + 4) * ld + n), v2 = load4(dY + (r + 8) * ld + n), v3 = load4(dY + (r + 12) * ld + n);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; r < r1; r += 4) {
             const float4 v = load4(dY + r * ld + n);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    }
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && n < N) {
