@@ -184,8 +184,15 @@ def main():
             dom = max(fams, key=lambda k: fams[k]["seconds"])
             d = fams[dom]
             ach = d["flops"] / d["seconds"] / 1e12
+            traffic = None   # HBM bytes per launch of the dominant family, from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
+                traffic = pmc[dom + "_kernel"]["hbm_bytes_per_launch"] if args.model == "vit_l" and args.precision == "bf16" and B == 64 else None
+            except Exception:
+                traffic = None
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
-                        unit="TFLOP/s", frac=round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4), traffic=None,
+                        unit="TFLOP/s", frac=round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4), traffic=traffic,
+                        flops_per_launch=round(d["flops"] / d["launches"]),
                         avg_launch_us=round(d["seconds"] / d["launches"] * 1e6, 1), launches_per_step=d["launches"] // args.steps,
                         families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / args.steps * 1e3, 2))
                                   for k, v in fams.items()})
