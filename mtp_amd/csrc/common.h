@@ -92,9 +92,24 @@ __device__ __forceinline__ uint4 ldg16(const void* p) {
 }
 
 // exact-erf GELU (nn.GELU default) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf via Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. f32-roundoff class like erff itself) -- 1 rcp + 1 exp + 5 fma
+// instead of ocml's ~35-instruction erff: the GELU / GELU' GEMM epilogues were spending ~65 us per fc1-sized launch in erff.
+// `e` returns exp(-z^2) so GELU' can reuse it (exp(-x^2/2) with z = x/sqrt(2)).
+__device__ __forceinline__ float erf_as(float z, float& e) {
+    const float az = fabsf(z);
+    const float t = __frcp_rn(1.0f + 0.3275911f * az);
+    const float y = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    e = __expf(-az * az);
+    return copysignf(1.0f - y * e, z);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float e;
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    float e;
+    const float er = erf_as(x * 0.70710678118654752440f, e);
+    return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
 }
 
 // wave-wide reductions over 64 lanes

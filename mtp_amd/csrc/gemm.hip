@@ -74,6 +74,7 @@ struct KArgs {
     int k_tiles;          // total k tiles
     int k_tiles_per_split;
     int atomic_out;
+    int order;              // tile order experiment: bit0 = no XCD remap, bit1 = M-fastest instead of N-fastest
     int64_t split_stride;   // TN split-K with workspace: partial tile of split z lives at C + z*split_stride (f32 elements)
 };
 
@@ -239,8 +240,9 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_m_ = (int)gridDim.x / p.tiles_n;
+    const int m0 = ((p.order & 2) ? (tile % tiles_m_) : (tile / p.tiles_n)) * BM, n0 = ((p.order & 2) ? (tile / tiles_m_) : (tile % p.tiles_n)) * BN;
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -389,8 +391,9 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_m_ = (int)gridDim.x / p.tiles_n;
+    const int m0 = ((p.order & 2) ? (tile % tiles_m_) : (tile / p.tiles_n)) * BM, n0 = ((p.order & 2) ? (tile / tiles_m_) : (tile % p.tiles_n)) * BN;
     const int kt0 = blockIdx.y * p.k_tiles_per_split;
     int kt1 = kt0 + p.k_tiles_per_split;
     kt1 = kt1 < p.k_tiles ? kt1 : p.k_tiles;
@@ -440,6 +443,7 @@ int fill_common(const mtp_gemm_args* a, KArgs& k) {
     k.k_tiles = (int)((a->K + 8 * E - 1) / (8 * E));
     k.k_tiles_per_split = k.k_tiles;
     k.atomic_out = 0;
+    k.order = (a->variant >> 1) & 3;
     k.split_stride = 0;
     return 0;
 }
@@ -456,7 +460,7 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     if (a->bias && a->bias_mod > 0 && (a->bias_mod % 4)) return MTP_ERR_ARG;
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);
-    const bool glds = (a->variant == 0) && (a->K % (8 * E) == 0);
+    const bool glds = ((a->variant & 1) == 0) && (a->K % (8 * E) == 0);
     if (glds)
         hipLaunchKernelGGL((gemm_nt_kernel<T, Tout, EPI, true>), grid, block, LDS_BYTES, stream, k);
     else

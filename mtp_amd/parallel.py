@@ -116,13 +116,16 @@ class GradReducer:
         self.buckets = flat.buckets(bucket_bytes)
         self.by_gid = {g: (s, e) for g, s, e in self.buckets}
         self.cuda = flat.grad.is_cuda
-        self.stream = torch.cuda.Stream() if self.cuda and self.world > 1 else None
+        # MTP_FORCE_COMM=1: issue the collectives even at world size 1 (exercises the RCCL + side-stream path on a 1-GPU box)
+        import os
+        self.active = self.world > 1 or (os.environ.get("MTP_FORCE_COMM") == "1" and dist.is_available() and dist.is_initialized())
+        self.stream = torch.cuda.Stream() if self.cuda and self.active else None
         self.works = []
         self.bytes_reduced = 0
 
     def on_block_done(self, gid):
         """engine hook: gradients of group `gid` (and everything before it in completion order) are on the compute stream."""
-        if self.world == 1 or gid not in self.by_gid:
+        if not self.active or gid not in self.by_gid:
             return
         s, e = self.by_gid[gid]
         buf = self.flat.grad[s:e]
