@@ -84,6 +84,8 @@ int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
 int mtp_reduce_rows_f32(const float* part, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);
 /* bias gradient: out[n] = sum_m dY[m][n] */
 int mtp_colsum(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream);
+/* same, accumulating: out[n] += ... (no clearing pass; used with a gradient buffer that is zeroed once per step) */
+int mtp_colsum_acc(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream);
 
 /* ---- layout / elementwise ------------------------------------------------------------------------------- */
 /* PatchEmbed im2col (VIT:529,536-539): img f32 NCHW -> cols (B*Hp*Wp, Cin*P*P) ACT, K order (c, ky, kx). */

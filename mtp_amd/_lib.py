@@ -33,6 +33,7 @@ SIGNATURES = {
     "mtp_layernorm_bwd": (i32, [p, i32, p, i32, p, p, p, p, i32, p, p, p, i32, p, i32, p, i64, p, p, i64, i64, p]),
     "mtp_reduce_rows_f32": (i32, [p, p, i64, i64, i32, p]),
     "mtp_colsum": (i32, [p, i32, i64, p, i64, i64, p]),
+    "mtp_colsum_acc": (i32, [p, i32, i64, p, i64, i64, p]),
     "mtp_patchify": (i32, [p, p, i32, i64, i64, i64, i64, i64, p]),
     "mtp_unpatchify": (i32, [p, i32, p, i64, i64, i64, i64, i64, p]),
     "mtp_cast": (i32, [p, i32, p, i32, i64, p]),

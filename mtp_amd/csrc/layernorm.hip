@@ -278,13 +278,25 @@ extern "C" int mtp_reduce_rows_f32(const float* part, float* out, int64_t rows, 
     return mtp_launch_status();
 }
 
+static int colsum_impl(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, bool zero, mtp_stream_t stream);
+
 extern "C" int mtp_colsum(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream) {
+    return colsum_impl(dY, dtype, ld, out, M, N, true, stream);
+}
+// out[n] += sum_m dY[m][n]: no clearing pass (the training engine accumulates into a gradient buffer zeroed once per step)
+extern "C" int mtp_colsum_acc(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream) {
+    return colsum_impl(dY, dtype, ld, out, M, N, false, stream);
+}
+
+static int colsum_impl(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, bool zero, mtp_stream_t stream) {
     if (!dY || !out || M <= 0 || N <= 0 || (N % 4) || (ld % 4)) return MTP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
-    if (e != hipSuccess) return (int)e;
+    if (zero) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
+        if (e != hipSuccess) return (int)e;
+    }
     const int64_t col_blocks = (N / 4 + 63) / 64;
-    int64_t row_blocks = 2048 / col_blocks;
+    int64_t row_blocks = 1024 / col_blocks;   // >= 32 rows per thread: enough loads in flight to stream at HBM rate
     if (row_blocks < 1) row_blocks = 1;
     int64_t rpb = (M + row_blocks - 1) / row_blocks;
     rpb = (rpb + 3) / 4 * 4;

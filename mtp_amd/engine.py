@@ -102,6 +102,17 @@ class BackboneEngine:
     def _e(self, *shape, dtype=None):
         return torch.empty(*shape, device=self.dev, dtype=dtype or self.act)
 
+    # Bias / LayerNorm gradients ACCUMULATE into G (no per-call clearing pass: that was ~250 tiny memsets per step).
+    # Contract of backward(): the gradient buffers in G are zero on entry (zeros_like in the autograd path, one memset of
+    # the flat buffer per step in mtp_amd.parallel).
+    @staticmethod
+    def _colsum(dy, out):
+        return ops.colsum(dy, out, accumulate=True)
+
+    @staticmethod
+    def _ln_bwd(*args, **kw):
+        return ops.layernorm_bwd(*args, accumulate=True, **kw)
+
     def _drop_scales(self, B, training):
         """VIT:31-42, 619: per-sample factor floor(keep + U[0,1)) / keep for each residual branch; None when inactive."""
         out = []
@@ -159,18 +170,18 @@ class BackboneEngine:
         T = dx2.shape[0]
         # ---- MLP branch
         ops.gemm_tn(dx2_act, s["h"], G[pre + "mlp.fc2.weight"])
-        ops.colsum(dx2_act, G[pre + "mlp.fc2.bias"])
+        self._colsum(dx2_act, G[pre + "mlp.fc2.bias"])
         du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_DGELU, aux=s["u"])
         ops.gemm_tn(du, s["ln2"], G[pre + "mlp.fc1.weight"])
-        ops.colsum(du, G[pre + "mlp.fc1.bias"])
+        self._colsum(du, G[pre + "mlp.fc1.bias"])
         dln2 = ops.gemm_nt(du, b.w1T, self._e(T, C))
         del du
         dx1, dx1_act = self._e(T, C, dtype=F32), self._e(T, C)
-        ops.layernorm_bwd(dln2, s["x1"], s["mean2"], s["rstd2"], P[pre + "norm2.weight"], dx1, G[pre + "norm2.weight"], G[pre + "norm2.bias"],
+        self._ln_bwd(dln2, s["x1"], s["mean2"], s["rstd2"], P[pre + "norm2.weight"], dx1, G[pre + "norm2.weight"], G[pre + "norm2.bias"],
                           dres=dx2, dx_copy=dx1_act, copy_scale=dps[0], rows_per_sample=N)
         # ---- attention branch
         ops.gemm_tn(dx1_act, s["o"], G[pre + "attn.proj.weight"])
-        ops.colsum(dx1_act, G[pre + "attn.proj.bias"])
+        self._colsum(dx1_act, G[pre + "attn.proj.bias"])
         do = ops.gemm_nt(dx1_act, b.wprojT, self._e(T, C))
         dqkv = self._e(T, 3 * C)
         if b.window:
@@ -194,12 +205,12 @@ class BackboneEngine:
             ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, P[pre + "attn.full_attn_rel_pos_h"], P[pre + "attn.full_attn_rel_pos_w"],
                               G[pre + "attn.full_attn_rel_pos_h"], G[pre + "attn.full_attn_rel_pos_w"], B, Hp, Wp, self.heads, self.scale)
         ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"])
-        ops.colsum(dqkv, G[pre + "attn.qkv.bias"])
+        self._colsum(dqkv, G[pre + "attn.qkv.bias"])
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         if b.window:
             ops.rvsa_pool_bwd(dpooled, s["avg"], dln1, B, Hp, Wp, accumulate=True)
         dx0, dx0_act = self._e(T, C, dtype=F32), self._e(T, C)
-        ops.layernorm_bwd(dln1, s["x"], s["mean1"], s["rstd1"], P[pre + "norm1.weight"], dx0, G[pre + "norm1.weight"], G[pre + "norm1.bias"],
+        self._ln_bwd(dln1, s["x"], s["mean1"], s["rstd1"], P[pre + "norm1.weight"], dx0, G[pre + "norm1.weight"], G[pre + "norm1.bias"],
                           dres=dx1, extra=extra, dx_copy=dx0_act, copy_scale=prev_scale, rows_per_sample=N)
         return dx0, dx0_act
 
@@ -287,21 +298,21 @@ class BackboneEngine:
             dwg = self._e(4 * C, C, dtype=F32)
             ops.gemm_tn(dy2.view(4 * T, 4 * C), fctx["g1"], dwg)
             ops.convt_unpack_grad(dwg, G["fpn1.3.weight"])
-            ops.colsum(dy2, G["fpn1.3.bias"])
+            self._colsum(dy2, G["fpn1.3.bias"])
             dg1 = ops.gemm_nt(dy2.view(4 * T, 4 * C), self._fpn["fpn1.3"][1], self._e(4 * T, C))
             dy1 = self._e(4 * T, C)
-            ops.layernorm_bwd(dg1, fctx["y1"].view(4 * T, C), fctx["mean"], fctx["rstd"], P["fpn1.1.ln.weight"], dy1,
+            self._ln_bwd(dg1, fctx["y1"].view(4 * T, C), fctx["mean"], fctx["rstd"], P["fpn1.1.ln.weight"], dy1,
                               G["fpn1.1.ln.weight"], G["fpn1.1.ln.bias"], beta=P["fpn1.1.ln.bias"], gelu=True)
             ops.gemm_tn(dy1.view(T, 4 * C), fctx["t0"], dwg)
             ops.convt_unpack_grad(dwg, G["fpn1.0.weight"])
-            ops.colsum(dy1, G["fpn1.0.bias"])
+            self._colsum(dy1, G["fpn1.0.bias"])
             out[0] = ops.gemm_nt(dy1.view(T, 4 * C), self._fpn["fpn1.0"][1], self._e(T, C, dtype=F32))
         if dfeats[1] is not None:
             dz = ops.nchw_to_tokens(as_in(dfeats[1]), self._e(4 * T, C), B, Hp, Wp, 1)
             dwg = self._e(4 * C, C, dtype=F32)
             ops.gemm_tn(dz.view(T, 4 * C), fctx["t1"], dwg)
             ops.convt_unpack_grad(dwg, G["fpn2.0.weight"])
-            ops.colsum(dz, G["fpn2.0.bias"])
+            self._colsum(dz, G["fpn2.0.bias"])
             out[1] = ops.gemm_nt(dz.view(T, 4 * C), self._fpn["fpn2.0"][1], self._e(T, C, dtype=F32))
         if dfeats[2] is not None:
             out[2] = ops.nchw_to_tokens(as_in(dfeats[2]), self._e(T, C, dtype=F32), B, Hp, Wp, 0)
@@ -350,7 +361,7 @@ class BackboneEngine:
                 on_block_done(i)
         # ---- patch embed / pos embed
         ops.gemm_tn(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1))
-        ops.colsum(dx_act, G["patch_embed.proj.bias"])
+        self._colsum(dx_act, G["patch_embed.proj.bias"])
         if "pos_embed" in G:
             ops.reduce_rows(dx.view(B, N * C), G["pos_embed"])
         dimg = None

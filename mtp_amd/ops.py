@@ -100,16 +100,16 @@ def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-6, gelu=False)
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=False, dres=None, extra=None,
-                  dx_copy=None, copy_scale=None, rows_per_sample=0):
-    """dx = [dres] + [extra] + LN'(dy); dgamma/dbeta (C,) f32 are overwritten."""
+                  dx_copy=None, copy_scale=None, rows_per_sample=0, accumulate=False):
+    """dx = [dres] + [extra] + LN'(dy); dgamma/dbeta (C,) f32 are overwritten (or accumulated into)."""
     rows, Cc = x.shape
     nblk = lib().mtp_layernorm_bwd_partial_rows(rows)
     part = torch.empty(2, nblk, Cc, device=x.device, dtype=torch.float32)
     check(lib().mtp_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _f32(mean), _f32(rstd), _f32(gamma), _f32(beta), int(gelu),
                                   _f32(dres), _f32(extra), _p(dx), _dt(dx), _p(dx_copy), (_dt(dx_copy) if dx_copy is not None else 0),
                                   _f32(copy_scale), rows_per_sample, _p(part[0]), _p(part[1]), rows, Cc, _s()), "mtp_layernorm_bwd")
-    reduce_rows(part[0], dgamma)
-    reduce_rows(part[1], dbeta)
+    reduce_rows(part[0], dgamma, accumulate)
+    reduce_rows(part[1], dbeta, accumulate)
     return dx
 
 
@@ -121,9 +121,10 @@ def reduce_rows(part, out, accumulate=False):
     return out
 
 
-def colsum(dy, out):
+def colsum(dy, out, accumulate=False):
     M, N = dy.shape
-    check(lib().mtp_colsum(_p(dy), _dt(dy), N, _f32(out), M, N, _s()), "mtp_colsum")
+    fn = lib().mtp_colsum_acc if accumulate else lib().mtp_colsum
+    check(fn(_p(dy), _dt(dy), N, _f32(out), M, N, _s()), "mtp_colsum")
     return out
 
 

@@ -206,6 +206,7 @@ class DataParallelTrainer:
 
     def step(self, img, loss_and_grads):
         """loss_and_grads(feats) -> (loss, [dfeat or None] * 4).  Returns the (local) loss tensor."""
+        self.flat.grad.zero_()     # one memset per step: the engine accumulates bias / LayerNorm gradients (engine._colsum)
         feats, ctx = self.engine.forward(img, training=True, need_grad=True, feature_dtype=self.feature_dtype)
         loss, dfeats = loss_and_grads(feats)
         self.engine.backward(ctx, dfeats, self.flat.G, on_block_done=self.reducer.on_block_done)
