@@ -623,7 +623,8 @@ RvsaGeom make_geom(int64_t Hp, int64_t Wp, int64_t heads) {
 
 }  // namespace
 
-int mtp_rvsa_fwd_mfma_launch(const void* qkv, const float* samp, void* o, float* lse, const float* rel_h, const float* rel_w, const float* bias_table,
+// single-wave-per-problem forward (kept for A/B; the shipped launcher is the 4-wave kernel in attn_rvsa_fwd4.hip)
+int mtp_rvsa_fwd1_mfma_launch(const void* qkv, const float* samp, void* o, float* lse, const float* rel_h, const float* rel_w, const float* bias_table,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     const RvsaGeom g = make_geom(Hp, Wp, heads);
     hipLaunchKernelGGL(rvsa_fwd_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(64), 0, s, (const bf16_t*)qkv, samp, (bf16_t*)o, lse,

@@ -68,8 +68,11 @@ def gemm_nt(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0,
 
 def pick_split_k(M, N, K):
     """enough (tile, split) work items for >= 2 resident workgroups on each of the 256 CUs"""
+    # measured on MI355X (tools/ab_tn.py): ~512 work items (2 per CU) is the sweet spot; odd splits are consistently slower
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    split = max(1, min(16, -(-640 // tiles)))
+    split = max(1, min(16, round(512 / tiles)))
+    if split > 1 and split % 2:
+        split += 1
     return max(1, min(split, K // 1024))
 
 
