@@ -279,6 +279,30 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// Single-LDS-stage variant (32 KiB -> 4 workgroups / 16 waves per CU): thread-level parallelism across resident workgroups
+// covers each workgroup's load latency instead of a deeper software pipeline.
+template <typename T, typename Tout, int EPI>
+__global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_sb_kernel(KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < p.k_tiles; ++kt) {
+        stage_nt_glds<T>(p, smem, smem + OPER_BYTES, m0, n0, kt, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute_stage<T>(smem, smem + OPER_BYTES, acc, wm, wn, lane);
+        __syncthreads();
+    }
+    epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
 // ---- TN staging: ExE register transposes ------------------------------------------------------------------------------
 // Operand source is (Kc, X) row-major, X = M or N contiguous.  Item = one ExE block (E k-rows x E x-columns):
 // kb = blk & 7 (LDS chunk column), xb = blk >> 3 (E-wide column group); lanes with consecutive xb read consecutive
@@ -425,6 +449,41 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// Single-LDS-stage TN variant (32 KiB, 3 workgroups per CU): the prefetched tile waits in registers during the MFMAs and is
+// written to the one stage between two barriers; the other resident workgroups cover the bubbles.
+template <typename T, bool FULL>
+__global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_tn_sb_kernel(KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int kt0 = blockIdx.y * p.k_tiles_per_split;
+    int kt1 = kt0 + p.k_tiles_per_split;
+    kt1 = kt1 < p.k_tiles ? kt1 : p.k_tiles;
+    if (kt0 >= kt1) return;
+    p.C += (int64_t)blockIdx.y * p.split_stride * (int64_t)sizeof(float);
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    TnRegs<T> r;
+    load_tn_regs<T, FULL>(p, r, m0, n0, kt0, tid);
+    store_tn_regs<T>(r, smem, tid);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        __syncthreads();
+        const int ktn = kt + 1 < kt1 ? kt + 1 : kt;
+        load_tn_regs<T, FULL>(p, r, m0, n0, ktn, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_stage<T>(smem, smem + OPER_BYTES, acc, wm, wn, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        store_tn_regs<T>(r, smem, tid);
+    }
+    epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
+}
+
 template <typename T>
 int fill_common(const mtp_gemm_args* a, KArgs& k) {
     constexpr int E = Elem<T>::kPerChunk;
@@ -461,7 +520,11 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);
     const bool glds = ((a->variant & 1) == 0) && (a->K % (8 * E) == 0);
-    if (glds)
+    // default = single-stage / 4 workgroups per CU (measured +20 % over the double-buffered 2-per-CU kernel on every ViT-L
+    // shape: 827 / 707 / 825 / 910 vs 675 / 590 / 674 / 769 TF/s); variant bit 3 selects the double-buffered kernel
+    if (glds && !(a->variant & 8))
+        hipLaunchKernelGGL((gemm_nt_sb_kernel<T, Tout, EPI>), grid, block, STAGE_BYTES, stream, k);
+    else if (glds)
         hipLaunchKernelGGL((gemm_nt_kernel<T, Tout, EPI, true>), grid, block, LDS_BYTES, stream, k);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<T, Tout, EPI, false>), grid, block, LDS_BYTES, stream, k);
@@ -500,7 +563,9 @@ int launch_tn(const mtp_gemm_args* a, hipStream_t stream) {
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n, split), block(NT_THREADS);
     const bool full = (a->K % (8 * E) == 0) && (a->M % BM == 0) && (a->N % BN == 0);
-    if (full)
+    if (full && (a->variant & 8))
+        hipLaunchKernelGGL((gemm_tn_sb_kernel<T, true>), grid, block, STAGE_BYTES, stream, k);
+    else if (full)
         hipLaunchKernelGGL((gemm_tn_kernel<T, true>), grid, block, LDS_BYTES, stream, k);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<T, false>), grid, block, LDS_BYTES, stream, k);

@@ -76,7 +76,7 @@ def pick_split_k(M, N, K):
     return max(1, min(split, K // 1024))
 
 
-def gemm_tn(a, b, out, split_k=None, use_workspace=True):
+def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0):
     """out (M,N) f32 = a (K,M)^T @ b (K,N)   (weight gradient dW = dY^T X)."""
     K, M = a.shape
     N = b.shape[1]
@@ -87,6 +87,7 @@ def gemm_tn(a, b, out, split_k=None, use_workspace=True):
     g.lda, g.ldb, g.ldc = M, N, N
     g.in_dtype, g.out_dtype, g.epilogue = _dt(a), MTP_F32, EPI_BIAS
     g.split_k = pick_split_k(M, N, K) if split_k is None else split_k
+    g.variant = variant
     if g.split_k > 1 and use_workspace:
         ws = torch.empty(g.split_k * M * N, device=out.device, dtype=torch.float32)   # split-K partials (summed by the callee)
         g.aux = _p(ws)
