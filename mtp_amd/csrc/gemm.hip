@@ -484,6 +484,86 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- TN, bf16, complete tiles: LDS-DMA staging of the UNtransposed tiles + hardware transpose reads ----------------------
+// The register-transposing kernels above spend more LDS-pipe cycles on their 8 ds_write_b128 per thread and k-tile (13 cycles
+// each) plus the fragment reads than the SIMDs spend on MFMAs.  Here both operand tiles go HBM -> LDS as they lie in memory
+// ([64 t rows][128 x] bf16 = 256-B rows, global_load_lds x16B, no VGPR/ds_write traffic) and the MFMA fragments come out of
+// ds_read_b64_tr_b16: a 16-lane group hands in the addresses of a [4 t][16 x] block (lane i: row i>>2, columns 4(i&3)..+3)
+// and lane i gets column i, rows 0..3 -- measured on gfx950 with tools/_abl/tr_probe.  Two reads = the 8 consecutive k of
+// one MFMA operand.  Swizzle: 32-B slot pair ^= f(t), f = (t&3) | (t>>3 & 1)<<2, so that the 8 rows a 32-lane group touches
+// ({0..3, 8..11} + const) fall on 8 different bank octets; applied on the per-lane SOURCE address of the DMA.
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+constexpr int TR_ROW_BYTES = 256;
+
+__device__ __forceinline__ void stage_tn_glds(const KArgs& p, char* sA, char* sB, int m0, int n0, int kt, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = wave * 16 + i * 4;
+        const int row = rbase + (lane >> 4);
+        const int f = (row & 3) | ((row >> 1) & 4);
+        const int chunk = (lane & 15) ^ (f << 1);
+        const int64_t t = (int64_t)kt * 64 + row;
+        const char* ga = p.A + (t * p.lda + m0 + chunk * 8) * 2;
+        const char* gb = p.B + (t * p.ldb + n0 + chunk * 8) * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                         (__attribute__((address_space(3))) void*)(sA + rbase * TR_ROW_BYTES), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                         (__attribute__((address_space(3))) void*)(sB + rbase * TR_ROW_BYTES), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ uint4 tr_frag(const char* s, int off) {
+    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(s + off));
+    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(s + off + 4 * TR_ROW_BYTES));
+    const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, h.x, h.y);
+}
+
+__device__ __forceinline__ void compute_stage_tr(const char* sA, const char* sB, f32x4_t (&acc)[4][4], int wm, int wn, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int f = (i >> 2) | ((g & 1) << 2);
+    const int rowoff = (8 * g + (i >> 2)) * TR_ROW_BYTES + ((i >> 1) & 1) * 16 + (i & 1) * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = tr_frag(sA, rowoff + (((q | (wm << 2)) ^ f) << 5) + ks * 32 * TR_ROW_BYTES);
+            b[q] = tr_frag(sB, rowoff + (((q | (wn << 2)) ^ f) << 5) + ks * 32 * TR_ROW_BYTES);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) Mma<bf16_t>::run(acc[ni][mi], b[ni], a[mi]);
+    }
+}
+
+__global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_tn_tr_kernel(KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int kt0 = blockIdx.y * p.k_tiles_per_split;
+    int kt1 = kt0 + p.k_tiles_per_split;
+    kt1 = kt1 < p.k_tiles ? kt1 : p.k_tiles;
+    if (kt0 >= kt1) return;
+    p.C += (int64_t)blockIdx.y * p.split_stride * (int64_t)sizeof(float);
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = kt0; kt < kt1; ++kt) {
+        stage_tn_glds(p, smem, smem + OPER_BYTES, m0, n0, kt, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute_stage_tr(smem, smem + OPER_BYTES, acc, wm, wn, lane);
+        __syncthreads();
+    }
+    epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
+}
+
 template <typename T>
 int fill_common(const mtp_gemm_args* a, KArgs& k) {
     constexpr int E = Elem<T>::kPerChunk;
@@ -563,7 +643,10 @@ int launch_tn(const mtp_gemm_args* a, hipStream_t stream) {
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n, split), block(NT_THREADS);
     const bool full = (a->K % (8 * E) == 0) && (a->M % BM == 0) && (a->N % BN == 0);
-    if (full && (a->variant & 8))
+    // bf16 complete tiles: LDS-DMA + transpose-read kernel; variant bit 4 falls back to the register-transposing kernels
+    if (full && sizeof(T) == 2 && !(a->variant & 16))
+        hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, block, STAGE_BYTES, stream, k);
+    else if (full && (a->variant & 8))
         hipLaunchKernelGGL((gemm_tn_sb_kernel<T, true>), grid, block, STAGE_BYTES, stream, k);
     else if (full)
         hipLaunchKernelGGL((gemm_tn_kernel<T, true>), grid, block, LDS_BYTES, stream, k);
