@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const bf16_t* __rest
 
 // ===================================================================================================================
 // backward A: dQ and the rel-pos table gradients.
-// dynamic LDS: Ks | Vs (16NT x 128 each) | Kt[64*TPV] | QR[4][64][16] f32 | dQR[4][64][16] f32 | Qtt[4][64*40 B] | kpos[NP2]
+// dynamic LDS: Ks | Vs (16NT x 128 each) | Kt[64*TPV] | QR[4][64][16] f32 | dQR[4][64][16] f32 | Qtt[4][64*40 B] | kpos[NP2] | E[2][KK][64] x16 B
 // ===================================================================================================================
 constexpr int QTP = 40;   // byte pitch of the per-wave transposed 16-query tile [d][16 q] (32 + 8)
 
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
     float* dQRall = QRall + 4 * 64 * 16;
     char* Qttall = reinterpret_cast<char*>(dQRall + 4 * 64 * 16);
     uint32_t* kpos = reinterpret_cast<uint32_t*>(Qttall + 4 * 64 * QTP);
+    char* Eimg = reinterpret_cast<char*>(kpos + g.NP2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, gq = lane >> 4;
     const int bh = blockIdx.x, b = bh / g.heads, h = bh % g.heads;
     const int C = g.heads * HD, N = g.N;
@@ -212,6 +213,21 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
     float* QR = QRall + wave * 64 * 16;
     float* dQR = dQRall + wave * 64 * 16;
     char* Qtt = Qttall + wave * 64 * QTP;
+
+    // 0/1 indicator operands E_h[a][key] = (row(key) == a), E_w[a][key] = (col(key) == a) in the MFMA A layout with the key
+    // order of the dS^T fragments below: sum_k E[a][k] dS^T[k][q] is d(q.Rh)[q][hq - a] -- the segmented row / column sums
+    // of dS come out of the matrix cores instead of LDS float atomics (measured ~190 LDS cycles per ds_add_f32 instruction).
+    for (int idx = tid; idx < 2 * g.KK * 64; idx += 256) {
+        const int t = idx / (g.KK * 64), rem = idx % (g.KK * 64), kk = rem >> 6, l = rem & 63, a = l & 15, gl = l >> 4;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = 32 * kk + 4 * gl + (j & 3) + (j >> 2) * 16;
+            const bool hit = key < N && (t ? key % g.Wp : key / g.Wp) == a;
+            w[j >> 1] |= hit ? (0x3f80u << ((j & 1) * 16)) : 0u;
+        }
+        *reinterpret_cast<uint4*>(Eimg + (size_t)idx * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 
     stage_rows_swz(base + C, ld, N, g.NT * 16, Ks, tid);
     stage_rows_swz(base + 2 * C, ld, N, g.NT * 16, Vs, tid);
@@ -313,28 +329,14 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
                     const float v = scale * (sT[r] + QR[ih] + QR[iw]);
                     float ds = __expf(fminf(v - ls, 30.f)) * (dpT[r] - dl);
                     ds = (nv && key < N) ? ds : 0.f;
-                    atomicAdd(&dQR[ih], ds);
-                    atomicAdd(&dQR[iw], ds);
                     dsT[kt][r] = ds;
                 }
             }
         }
-        __syncthreads();
         // d(qs)^T = K^T.dS^T + Rh^T.dQRh + Rw^T.dQRw ; dq = scale * d(qs)
-        float e[8], f[8];
+        f32x4_t dq[4], dqh = {0.f, 0.f, 0.f, 0.f}, dqw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            e[x] = dQR[(8 * gq + x) * 16 + fr];
-            f[x] = dQR[(32 + 8 * gq + x) * 16 + fr];
-        }
-        const uint4 eh = pack_bf16x8(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
-        const uint4 ew = pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
-        f32x4_t dq[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dq[dt] = mma(rhT[dt], eh, f32x4_t{0.f, 0.f, 0.f, 0.f});
-            dq[dt] = mma(rwT[dt], ew, dq[dt]);
-        }
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             if (kk < g.KK) {
@@ -345,7 +347,29 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
                     const char* row = Kt + (16 * dt + fr) * g.TPV;
                     dq[dt] = mma(ld8x2(row + (32 * kk + 4 * gq) * 2, row + (32 * kk + 16 + 4 * gq) * 2), dsf, dq[dt]);
                 }
+                dqh = mma(ld16(Eimg + (kk * 64 + lane) * 16), dsf, dqh);             // lane: d(q.Rh) of query fr for key rows 4gq + r
+                dqw = mma(ld16(Eimg + ((g.KK + kk) * 64 + lane) * 16), dsf, dqw);
             }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * gq + r;
+            if (a < g.Hp) dQR[(hq - a) * 16 + fr] = dqh[r];
+            if (a < g.Wp) dQR[(32 + wq - a) * 16 + fr] = dqw[r];
+        }
+        __syncthreads();
+        float e[8], f[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            e[x] = dQR[(8 * gq + x) * 16 + fr];
+            f[x] = dQR[(32 + 8 * gq + x) * 16 + fr];
+        }
+        const uint4 eh = pack_bf16x8(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+        const uint4 ew = pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dq[dt] = mma(rhT[dt], eh, dq[dt]);
+            dq[dt] = mma(rwT[dt], ew, dq[dt]);
         }
         if (nv) {
             bf16_t* dp = dqkv + ((int64_t)b * N + n) * ld + h * HD + 4 * gq;
@@ -559,7 +583,7 @@ int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, c
     if (!make_fgeom(Hp, Wp, heads, g)) return MTP_ERR_UNSUPPORTED;
     hipError_t e = hipMemsetAsync(drel_part, 0, sizeof(float) * (size_t)(B * heads) * (size_t)(g.RH + g.RW) * HD, s);
     if (e != hipSuccess) return (int)e;
-    const size_t lds_a = 2 * (size_t)g.NT * 16 * 128 + (size_t)64 * g.TPV + 2 * 4 * 64 * 16 * 4 + 4 * 64 * QTP + (size_t)g.NP2 * 4;
+    const size_t lds_a = 2 * (size_t)g.NT * 16 * 128 + (size_t)64 * g.TPV + 2 * 4 * 64 * 16 * 4 + 4 * 64 * QTP + (size_t)g.NP2 * 4 + 2 * (size_t)g.KK * 64 * 16;
     const size_t lds_b = 2 * (size_t)64 * g.TPV + (size_t)64 * g.NP * 4 + 2 * (size_t)g.NP * 4 + (size_t)g.NP2 * 4;
     if (lds_a > 160 * 1024 || lds_b > 160 * 1024) return MTP_ERR_UNSUPPORTED;
     (void)hipFuncSetAttribute((const void*)full_bwd_a_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);

@@ -132,7 +132,7 @@ constexpr int SMP_F = 10;
 // ===================================================================================================================
 // RVSA backward, 4 waves per (image, window, head): wave w owns query tile w in the query-major phase and key tile w in the
 // key-major phase, so the problem's critical path is 4x shorter and 12 waves share a CU (3 workgroups x 4) instead of 3.
-// LDS: Ks | Vs (K_sel / V_sel rows, later P^T / dS^T) | R2 = {K^T} then {Q^T | dO^T} | QR | dQR | tab | dtab | lses | delta | smp | vsum
+// LDS: Ks | Vs (K_sel / V_sel rows, later P^T / dS^T) | R2 = {K^T} then {Q^T | dO^T} | QR | dQR | tab | lses | delta | smp | vsum
 // ===================================================================================================================
 __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ samp, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv, float* __restrict__ dkv, float* __restrict__ dsamp,
@@ -145,7 +145,6 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     __shared__ float QR[26 * 64];
     __shared__ float dQR[26 * 64];
     __shared__ float tab[176];
-    __shared__ float dtab[176];
     __shared__ float lses[64];
     __shared__ float delta[64];
     __shared__ float smp[SMP_F * 64];
@@ -163,7 +162,6 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
 
     if (tid < 176) {
         tab[tid] = tid < 169 ? bias_table[tid * H + h] : 0.f;
-        dtab[tid] = 0.f;
     }
     if (tid < 8) vsum[tid] = 0.f;
     for (int i = tid; i < 26 * 64; i += 256) dQR[i] = 0.f;
@@ -246,7 +244,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     }
     __syncthreads();
 
-    // ================= phase A: wave = query tile; lane (query; 4 keys) -> dQ, dQR, dtab, P^T / dS^T images ===============
+    // ================= phase A: wave = query tile; lane (query; 4 keys) -> dQ, dQR, P^T / dS^T images ===============
     {
         uint4 kf[4][2], vf[4][2];
 #pragma unroll
@@ -281,9 +279,6 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 float p = __expf(fminf(v - ls, 30.f));
                 p = (key < 49 && n < 49) ? p : 0.f;
                 const float ds = p * (dpT[kt][r] - dl);
-                atomicAdd(&dQR[dh * 64 + n], ds);
-                atomicAdd(&dQR[(13 + dw) * 64 + n], ds);
-                atomicAdd(&dtab[dh * 13 + dw], ds);
                 sT[kt][r] = ds * scale;
                 const int off = key * 128 + ((n * 2) ^ ((key & 7) << 4));
                 *reinterpret_cast<uint16_t*>(Ks + off) = (uint16_t)f32_to_bf16_bits(p);
@@ -293,7 +288,35 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
             dsf[kk] = pack_bf16x8(sT[2 * kk][0], sT[2 * kk][1], sT[2 * kk][2], sT[2 * kk][3], sT[2 * kk + 1][0], sT[2 * kk + 1][1], sT[2 * kk + 1][2], sT[2 * kk + 1][3]);
-        __syncthreads();   // dQR / dtab / P^T / dS^T complete
+        {   // d(q.Rh)[q][aq - ak + 6] = sum over the 7 keys of window row ak of dS (same for columns): segmented sums done as
+            // E[a][key] (0/1 indicator, MFMA A layout) x dS^T on the matrix cores -- LDS float atomics cost ~190 LDS cycles per
+            // instruction here and were 40 % of this kernel's wave time (SQ_WAIT_INST_LDS).
+            f32x4_t dqh = {0.f, 0.f, 0.f, 0.f}, dqw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint32_t wh[4] = {0u, 0u, 0u, 0u}, ww[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = 32 * kk + 4 * gq + (j & 3) + (j >> 2) * 16;
+                    const int ak = (key * 37) >> 8, bk = key - 7 * ak;
+                    const uint32_t one = 0x3f80u << ((j & 1) * 16);
+                    wh[j >> 1] |= (key < 49 && ak == fr) ? one : 0u;
+                    ww[j >> 1] |= (key < 49 && bk == fr) ? one : 0u;
+                }
+                dqh = mma(make_uint4(wh[0], wh[1], wh[2], wh[3]), dsf[kk], dqh);
+                dqw = mma(make_uint4(ww[0], ww[1], ww[2], ww[3]), dsf[kk], dqw);
+            }
+            const float inv_scale = 1.0f / scale;   // dsf carries dS * scale
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 4 * gq + r;
+                if (a < 7) {
+                    dQR[(aq - a + 6) * 64 + n] = dqh[r] * inv_scale;
+                    dQR[(13 + bq - a + 6) * 64 + n] = dqw[r] * inv_scale;
+                }
+            }
+        }
+        __syncthreads();   // dQR / P^T / dS^T complete
         float e[8], f[8];
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
@@ -350,7 +373,20 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
             for (int rr = 0; rr < 4; ++rr)
                 if (4 * gq + rr < 13) rp[(t * 13 + 4 * gq + rr) * HD + 16 * dt + fr] = acc[rr];
         }
-        if (tid < 169) tab_part[(int64_t)blockIdx.x * 169 + tid] = dtab[tid];
+        if (tid < 169) {   // bias-table gradient: thread = table bin (dh, dw), sum of dS over the (query, key) pairs at that offset,
+                           // read back from the dS^T image (query = key + 7(dh-6) + (dw-6)); no atomics
+            const int da = tid / 13 - 6, db = tid % 13 - 6, dn = 7 * da + db;
+            float acc = 0.f;
+#pragma unroll
+            for (int key = 0; key < 49; ++key) {
+                const int ak = key / 7, bk = key % 7;
+                const bool ok = (unsigned)(ak + da) < 7u && (unsigned)(bk + db) < 7u;
+                const int nn = ok ? key + dn : 0;
+                const float v = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(Vs + key * 128 + ((nn * 2) ^ ((key & 7) << 4))));
+                acc += ok ? v : 0.f;
+            }
+            tab_part[(int64_t)blockIdx.x * 169 + tid] = acc / scale;
+        }
     }
     // ================= phase B: wave = key tile; lane (key; 4 queries) -> dK_sel^T, dV_sel^T, scatter, coordinate gradients ==
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
