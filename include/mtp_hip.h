@@ -56,10 +56,15 @@ typedef struct {
     int64_t res_ld, res_mod;
     const float* rowscale; /* EPI_BIAS_RES: per-sample drop-path factor or NULL                           */
     int64_t rows_per_sample;
-    void* aux;          /* EPI_BIAS_GELU: u out;  EPI_DGELU: u in;  (M, N), ld aux_ld, dtype out_dtype     */
+    void* aux;          /* EPI_BIAS_GELU: u out;  EPI_DGELU: u in;  (M, N), ld aux_ld, dtype out_dtype.
+                         * TN with split_k > 1: optional f32 workspace (split_k * M * N) for the partial tiles,
+                         * summed into C by the callee (deterministic); NULL = f32 atomicAdd into zeroed C  */
     int64_t aux_ld;
-    int split_k;        /* TN only: >1 = split the contraction over gridDim.z, f32 atomicAdd into zeroed C */
-    int variant;        /* 0 = default; 1 = register-staged NT loads instead of direct-to-LDS (debug/A-B)  */
+    int split_k;        /* TN only: >1 = split the contraction over gridDim.y                               */
+    int variant;        /* 0 = default kernels; other values select A/B kernels (debug): NT bit0 = register-
+                         * staged loads, bit3 = double-buffered; TN bit3 / bit4 = register-transposing kernels */
+    float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
+                         * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
 } mtp_gemm_args;
 
 /* y = x W^T (+epilogue): nn.Linear fwd/dgrad (VIT:50,52,78,87,256,262), patch-embed conv as GEMM (VIT:529),

@@ -21,7 +21,7 @@ class GemmArgs(C.Structure):
                 ("in_dtype", i32), ("out_dtype", i32), ("epilogue", i32),
                 ("bias", p), ("bias_mod", i64), ("res", p), ("res_ld", i64), ("res_mod", i64),
                 ("rowscale", p), ("rows_per_sample", i64), ("aux", p), ("aux_ld", i64),
-                ("split_k", i32), ("variant", i32)]
+                ("split_k", i32), ("variant", i32), ("colsum", p)]
 
 
 # name -> (restype, argtypes); must list EVERY function declared in include/mtp_hip.h (tests/test_abi.py checks)

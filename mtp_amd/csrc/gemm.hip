@@ -76,6 +76,7 @@ struct KArgs {
     int atomic_out;
     int order;              // tile order experiment: bit0 = no XCD remap, bit1 = M-fastest instead of N-fastest
     int64_t split_stride;   // TN split-K with workspace: partial tile of split z lives at C + z*split_stride (f32 elements)
+    float* colsum;          // TN (transpose-read kernel): colsum[m] += sum_k A[k][m], or nullptr
 };
 
 // out[i] = sum_s part[s][i]   (float4 granules; deterministic split-K reduction)
@@ -554,12 +555,41 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // bias-gradient by-product: the workgroups of tile column 0 also add up the rows of their A (= dY) tiles out of LDS
+    // (thread = 16-B slot tid&15 of rows (tid>>4) + 16j; all four rows share one swizzle, i.e. one 8-column chunk)
+    const bool do_colsum = p.colsum != nullptr && n0 == 0;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int kt = kt0; kt < kt1; ++kt) {
         stage_tn_glds(p, smem, smem + OPER_BYTES, m0, n0, kt, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         compute_stage_tr(smem, smem + OPER_BYTES, acc, wm, wn, lane);
+        if (do_colsum) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + ((tid >> 4) + 16 * j) * TR_ROW_BYTES + (tid & 15) * 16);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cs[2 * e] += __uint_as_float(w[e] << 16);
+                    cs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                }
+            }
+        }
         __syncthreads();
+    }
+    if (do_colsum) {   // (after the loop's last barrier nobody reads the stage any more)
+        float* red = reinterpret_cast<float*>(smem);
+        const int rg = tid >> 4, f = (rg & 3) | ((rg >> 1) & 4), chunk = (tid & 15) ^ (f << 1);
+        *reinterpret_cast<float4*>(red + rg * BM + chunk * 8) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        *reinterpret_cast<float4*>(red + rg * BM + chunk * 8 + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+        __syncthreads();
+        if (tid < BM) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * BM + tid];
+            atomicAdd(p.colsum + m0 + tid, s);
+        }
     }
     epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -584,6 +614,7 @@ int fill_common(const mtp_gemm_args* a, KArgs& k) {
     k.atomic_out = 0;
     k.order = (a->variant >> 1) & 3;
     k.split_stride = 0;
+    k.colsum = nullptr;
     return 0;
 }
 
@@ -644,9 +675,15 @@ int launch_tn(const mtp_gemm_args* a, hipStream_t stream) {
     dim3 grid(tiles_m * k.tiles_n, split), block(NT_THREADS);
     const bool full = (a->K % (8 * E) == 0) && (a->M % BM == 0) && (a->N % BN == 0);
     // bf16 complete tiles: LDS-DMA + transpose-read kernel; variant bit 4 falls back to the register-transposing kernels
-    if (full && sizeof(T) == 2 && !(a->variant & 16))
+    const bool tr = full && sizeof(T) == 2 && !(a->variant & 16);
+    if (a->colsum && !tr) {   // the other kernels do not produce the column sums: separate streaming pass over A
+        rc = mtp_colsum_acc(a->A, a->in_dtype, a->lda, a->colsum, a->K, a->M, stream);
+        if (rc) return rc;
+    }
+    if (tr) {
+        k.colsum = a->colsum;
         hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, block, STAGE_BYTES, stream, k);
-    else if (full && (a->variant & 8))
+    } else if (full && (a->variant & 8))
         hipLaunchKernelGGL((gemm_tn_sb_kernel<T, true>), grid, block, STAGE_BYTES, stream, k);
     else if (full)
         hipLaunchKernelGGL((gemm_tn_kernel<T, true>), grid, block, LDS_BYTES, stream, k);

@@ -169,19 +169,17 @@ class BackboneEngine:
         pre = b.pre
         T = dx2.shape[0]
         # ---- MLP branch
-        ops.gemm_tn(dx2_act, s["h"], G[pre + "mlp.fc2.weight"])
-        self._colsum(dx2_act, G[pre + "mlp.fc2.bias"])
+        # (bias gradients = column sums of dY: by-product of the dW GEMM that streams dY anyway)
+        ops.gemm_tn(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], colsum=G[pre + "mlp.fc2.bias"])
         du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_DGELU, aux=s["u"])
-        ops.gemm_tn(du, s["ln2"], G[pre + "mlp.fc1.weight"])
-        self._colsum(du, G[pre + "mlp.fc1.bias"])
+        ops.gemm_tn(du, s["ln2"], G[pre + "mlp.fc1.weight"], colsum=G[pre + "mlp.fc1.bias"])
         dln2 = ops.gemm_nt(du, b.w1T, self._e(T, C))
         del du
         dx1, dx1_act = self._e(T, C, dtype=F32), self._e(T, C)
         self._ln_bwd(dln2, s["x1"], s["mean2"], s["rstd2"], P[pre + "norm2.weight"], dx1, G[pre + "norm2.weight"], G[pre + "norm2.bias"],
                           dres=dx2, dx_copy=dx1_act, copy_scale=dps[0], rows_per_sample=N)
         # ---- attention branch
-        ops.gemm_tn(dx1_act, s["o"], G[pre + "attn.proj.weight"])
-        self._colsum(dx1_act, G[pre + "attn.proj.bias"])
+        ops.gemm_tn(dx1_act, s["o"], G[pre + "attn.proj.weight"], colsum=G[pre + "attn.proj.bias"])
         do = ops.gemm_nt(dx1_act, b.wprojT, self._e(T, C))
         dqkv = self._e(T, 3 * C)
         if b.window:
@@ -204,8 +202,7 @@ class BackboneEngine:
         else:
             ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, P[pre + "attn.full_attn_rel_pos_h"], P[pre + "attn.full_attn_rel_pos_w"],
                               G[pre + "attn.full_attn_rel_pos_h"], G[pre + "attn.full_attn_rel_pos_w"], B, Hp, Wp, self.heads, self.scale)
-        ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"])
-        self._colsum(dqkv, G[pre + "attn.qkv.bias"])
+        ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], colsum=G[pre + "attn.qkv.bias"])
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         if b.window:
             ops.rvsa_pool_bwd(dpooled, s["avg"], dln1, B, Hp, Wp, accumulate=True)
@@ -360,8 +357,7 @@ class BackboneEngine:
             if on_block_done is not None:
                 on_block_done(i)
         # ---- patch embed / pos embed
-        ops.gemm_tn(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1))
-        self._colsum(dx_act, G["patch_embed.proj.bias"])
+        ops.gemm_tn(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1), colsum=G["patch_embed.proj.bias"])
         if "pos_embed" in G:
             ops.reduce_rows(dx.view(B, N * C), G["pos_embed"])
         dimg = None

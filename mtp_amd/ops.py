@@ -76,12 +76,16 @@ def pick_split_k(M, N, K):
     return max(1, min(split, K // 1024))
 
 
-def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0):
-    """out (M,N) f32 = a (K,M)^T @ b (K,N)   (weight gradient dW = dY^T X)."""
+def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None):
+    """out (M,N) f32 = a (K,M)^T @ b (K,N)   (weight gradient dW = dY^T X).
+    colsum (M,) f32, optional: colsum += a.sum(0) -- the bias gradient, produced by the same pass over dY."""
     K, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == K and out.dtype == torch.float32 and out.numel() == M * N and a.dtype == b.dtype
     g = GemmArgs()
+    if colsum is not None:
+        assert colsum.dtype == torch.float32 and colsum.numel() == M and colsum.is_contiguous()
+        g.colsum = _p(colsum)
     g.A, g.B, g.C = _p(a), _p(b), _p(out)
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb, g.ldc = M, N, N

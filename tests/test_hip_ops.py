@@ -89,6 +89,19 @@ def test_gemm_tn(ops, dtype, Kc, M, N, split):
     assert rel_err(out.cpu(), a.t() @ b) < 3e-4   # f32 accumulate/output in both modes; inputs are exact
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Kc,M,N,split", [(1024, 384, 256, 3), (12544, 256, 128, None), (392, 256, 128, 2), (128, 128, 384, 1)])
+def test_gemm_tn_bias_gradient_byproduct(ops, dtype, Kc, M, N, split):
+    """colsum += dY.sum(0) out of the dW GEMM: fused in the transpose-read kernel (bf16, complete tiles), a separate pass
+    otherwise; both ACCUMULATE (Linear bias gradient, VIT:50-52 backward)."""
+    a, b = rnd(Kc, M, dtype=dtype, scale=0.5), rnd(Kc, N, dtype=dtype, seed=1, scale=0.5)
+    cs0 = rnd(M, seed=2)
+    cs = dev(cs0)
+    out = ops.gemm_tn(dev(a, dtype), dev(b, dtype), e(M, N), split_k=split, colsum=cs)
+    assert rel_err(out.cpu(), a.t() @ b) < 3e-4
+    assert rel_err(cs.cpu(), cs0 + a.sum(0)) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm & reductions
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows,C", [(392, 128), (50, 768), (7, 1024)])
