@@ -85,8 +85,9 @@ int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
                       const float* dres, const float* extra, void* dx, int dx_dtype,
                       void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
                       float* dgamma_part, float* dbeta_part, int64_t rows, int64_t C, mtp_stream_t stream);
-/* out[c] (+)= sum_r part[r][c]   (also used for bias gradients) */
-int mtp_reduce_rows_f32(const float* part, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);
+/* out[c] (+)= sum_r part[r * ld + c], c < C   (per-workgroup partials -> parameter gradient; ld >= C lets one
+ * partial buffer feed several parameters) */
+int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);
 /* bias gradient: out[n] = sum_m dY[m][n] */
 int mtp_colsum(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream);
 /* same, accumulating: out[n] += ... (no clearing pass; used with a gradient buffer that is zeroed once per step) */
@@ -111,6 +112,10 @@ int mtp_nchw_to_tokens(const void* f, int f_dtype, void* out, int out_dtype, int
 int mtp_maxpool2_tokens_fwd(const float* x, void* y, int y_dtype, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream);
 int mtp_maxpool2_tokens_bwd(const float* x, const void* dy, int dy_dtype, float* dx, int accumulate, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream);
 int mtp_axpy_f32(float* y, const float* x, float alpha, int64_t n, mtp_stream_t stream);
+/* n <= MTP_MAX_SEGMENTS independent f32 copies dst[i][0..count[i]) = src[i][0..count[i]) in ONE launch (the stacked
+ * gradient of the three RVSA 1x1-conv heads, VIT:231-242, goes back to six separate parameters). Host arrays. */
+#define MTP_MAX_SEGMENTS 12
+int mtp_copy_segments_f32(const float* const* src, float* const* dst, const int64_t* count, int n, mtp_stream_t stream);
 /* dst (rows, C) ACT = scale[row / rows_per_sample] * src (rows, C) f32   (scale may be NULL = plain cast) */
 int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, const float* scale, int64_t rows_per_sample, int64_t rows, int64_t C, mtp_stream_t stream);
 
@@ -139,7 +144,7 @@ int mtp_rvsa_attn_fwd(const void* qkv, const float* samp, void* o, float* lse, i
 /* dqkv (T,3C) ACT: q part written directly; k/v parts are scattered through the bilinear weights with f32 atomics into
  * dkv_f32 (T, 2C) (zeroed by the callee) and then converted into dqkv by the callee.  dsamp (B*nh*nw, 5*heads) f32.
  * rel_part (B*nh*nw*heads, 26*hd) f32 = per-workgroup partials of [drel_h (13,hd) | drel_w (13,hd)];
- * tab_part (B*nh*nw, heads, 169) f32 = partials of the bias-table gradient (transposed: [head][idx]). */
+ * tab_part (B*nh*nw, 169, heads) f32 = per-window partials of the bias-table gradient, laid out like the parameter. */
 int mtp_rvsa_attn_bwd(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse,
                       void* dqkv, float* dkv_f32, float* dsamp, float* rel_part, float* tab_part, int dtype,
                       const float* rel_h, const float* rel_w, const float* bias_table,

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 const float v = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(Vs + key * 128 + ((nn * 2) ^ ((key & 7) << 4))));
                 acc += ok ? v : 0.f;
             }
-            tab_part[(int64_t)blockIdx.x * 169 + tid] = acc / scale;
+            tab_part[((int64_t)bw * 169 + tid) * H + h] = acc / scale;   // (169, heads) as the parameter
         }
     }
     // ================= phase B: wave = key tile; lane (key; 4 queries) -> dK_sel^T, dV_sel^T, scatter, coordinate gradients ==

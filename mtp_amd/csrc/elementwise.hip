@@ -471,6 +471,32 @@ extern "C" int mtp_axpy_f32(float* y, const float* x, float alpha, int64_t n, mt
     return mtp_launch_status();
 }
 
+// several small independent copies in one launch (blockIdx.y = segment); the table travels in the kernel arguments
+struct CopySegs {
+    const float* src[MTP_MAX_SEGMENTS];
+    float* dst[MTP_MAX_SEGMENTS];
+    int64_t count[MTP_MAX_SEGMENTS];
+};
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs t) {
+    const int sgm = blockIdx.y;
+    const float* __restrict__ s = t.src[sgm];
+    float* __restrict__ d = t.dst[sgm];
+    const int64_t n = t.count[sgm];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+extern "C" int mtp_copy_segments_f32(const float* const* src, float* const* dst, const int64_t* count, int n, mtp_stream_t stream) {
+    if (!src || !dst || !count || n <= 0 || n > MTP_MAX_SEGMENTS) return MTP_ERR_ARG;
+    CopySegs t;
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i] || count[i] <= 0) return MTP_ERR_ARG;
+        t.src[i] = src[i]; t.dst[i] = dst[i]; t.count[i] = count[i];
+        mx = count[i] > mx ? count[i] : mx;
+    }
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(blocks_for(mx, 256, 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    return mtp_launch_status();
+}
+
 static void rvsa_geom(int64_t Hp, int64_t Wp, int& pt, int& pl, int& nh, int& nw) {
     const int pad_h = (int)((7 - Hp % 7) % 7), pad_w = (int)((7 - Wp % 7) % 7);
     pt = pad_h / 2; pl = pad_w / 2;
@@ -510,8 +536,12 @@ extern "C" int mtp_small_linear_bwd(const float* x, const float* w, const float*
     hipStream_t s = (hipStream_t)stream;
     if (dx) hipLaunchKernelGGL(small_linear_dx_kernel, dim3(blocks_for(R * K / 4, 256, 4096)), dim3(256), 0, s, dy, w, dx, (int)R, (int)N, (int)K);
     if (dw) {
-        (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)(N * K), s);
-        if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s);
+        if (db == dw + N * K) {   // one buffer [dw | db]: one clearing pass
+            (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)(N * K + N), s);
+        } else {
+            (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)(N * K), s);
+            if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s);
+        }
         hipLaunchKernelGGL(small_linear_dw_kernel, dim3(blocks_for(N * K / 4, 256, 4096), (unsigned)((R + 15) / 16)), dim3(256), 0, s, dy, x, dw, db, (int)R, (int)N, (int)K);
     }
     return mtp_launch_status();

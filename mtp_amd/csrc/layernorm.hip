@@ -152,14 +152,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
 }
 
 // out[c] (+)= sum_r part[r][c]; thread per column, rows split over blockIdx.y, f32 atomics into (zeroed) out
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t rows, int64_t C, int64_t rows_per_block) {
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int64_t ld, float* __restrict__ out, int64_t rows, int64_t C, int64_t rows_per_block) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     r1 = r1 < rows ? r1 : rows;
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += part[r * C + c];
+    for (int64_t r = r0; r < r1; ++r) s += part[r * ld + c];
     atomicAdd(out + c, s);
 }
 
@@ -261,8 +261,8 @@ extern "C" int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
     return MTP_ERR_UNSUPPORTED;
 }
 
-extern "C" int mtp_reduce_rows_f32(const float* part, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream) {
-    if (!part || !out || rows <= 0 || C <= 0) return MTP_ERR_ARG;
+extern "C" int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream) {
+    if (!part || !out || rows <= 0 || C <= 0 || ld < C) return MTP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, s);
@@ -274,7 +274,7 @@ extern "C" int mtp_reduce_rows_f32(const float* part, float* out, int64_t rows, 
     if (splits > rows) splits = rows;
     const int64_t rpb = (rows + splits - 1) / splits;
     splits = (rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)col_blocks, (unsigned)splits), dim3(256), 0, s, part, out, rows, C, rpb);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)col_blocks, (unsigned)splits), dim3(256), 0, s, part, ld, out, rows, C, rpb);
     return mtp_launch_status();
 }
 

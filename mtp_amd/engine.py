@@ -190,18 +190,18 @@ class BackboneEngine:
             ops.rvsa_attn_bwd(s["qkv"], s["samp"], s["o"], do, s["lse"], dqkv, dsamp,
                               P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], P[pre + "attn.relative_position_bias_table"],
                               G[pre + "attn.rel_pos_h"], G[pre + "attn.rel_pos_w"], G[pre + "attn.relative_position_bias_table"],
-                              B, Hp, Wp, H, self.scale)
-            dpooled, dws, dbs = self._e(R, C, dtype=F32), self._e(5 * H, C, dtype=F32), self._e(5 * H, dtype=F32)
+                              B, Hp, Wp, H, self.scale, accumulate=True)
+            dpooled, dwb = self._e(R, C, dtype=F32), self._e(5 * H * C + 5 * H, dtype=F32)   # [dW stacked | db]: one clearing pass
+            dws, dbs = dwb[:5 * H * C].view(5 * H, C), dwb[5 * H * C:]
             ops.small_linear_bwd(s["pooled"], b.wsamp, dsamp, dpooled, dws, dbs)
-            G[pre + "attn.sampling_offsets.2.weight"].copy_(dws[:2 * H].view(2 * H, C, 1, 1))
-            G[pre + "attn.sampling_scales.2.weight"].copy_(dws[2 * H:4 * H].view(2 * H, C, 1, 1))
-            G[pre + "attn.sampling_angles.2.weight"].copy_(dws[4 * H:].view(H, C, 1, 1))
-            G[pre + "attn.sampling_offsets.2.bias"].copy_(dbs[:2 * H])
-            G[pre + "attn.sampling_scales.2.bias"].copy_(dbs[2 * H:4 * H])
-            G[pre + "attn.sampling_angles.2.bias"].copy_(dbs[4 * H:])
+            ops.copy_segments([dws[:2 * H], dws[2 * H:4 * H], dws[4 * H:], dbs[:2 * H], dbs[2 * H:4 * H], dbs[4 * H:]],
+                              [G[pre + "attn.sampling_offsets.2.weight"], G[pre + "attn.sampling_scales.2.weight"],
+                               G[pre + "attn.sampling_angles.2.weight"], G[pre + "attn.sampling_offsets.2.bias"],
+                               G[pre + "attn.sampling_scales.2.bias"], G[pre + "attn.sampling_angles.2.bias"]])
         else:
             ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, P[pre + "attn.full_attn_rel_pos_h"], P[pre + "attn.full_attn_rel_pos_w"],
-                              G[pre + "attn.full_attn_rel_pos_h"], G[pre + "attn.full_attn_rel_pos_w"], B, Hp, Wp, self.heads, self.scale)
+                              G[pre + "attn.full_attn_rel_pos_h"], G[pre + "attn.full_attn_rel_pos_w"], B, Hp, Wp, self.heads, self.scale,
+                              accumulate=True)
         ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], colsum=G[pre + "attn.qkv.bias"])
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         if b.window:

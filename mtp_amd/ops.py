@@ -122,11 +122,26 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=F
 
 
 def reduce_rows(part, out, accumulate=False):
-    rows = part.shape[0]
-    cols = part.numel() // rows
+    """out (+)= part.sum(0); part (rows, cols) f32, a column slice of a wider buffer is fine (row stride = part.stride(0))."""
+    if not part.is_cuda:
+        raise RuntimeError("mtp_amd ops run only on an MI355X device tensor (no CPU fallback)")
+    assert part.dim() == 2 and part.stride(1) == 1 and part.dtype == torch.float32
+    rows, cols = part.shape
     assert out.numel() == cols
-    check(lib().mtp_reduce_rows_f32(_f32(part), _f32(out), rows, cols, int(accumulate), _s()), "mtp_reduce_rows_f32")
+    check(lib().mtp_reduce_rows_f32(part.data_ptr(), part.stride(0), _f32(out), rows, cols, int(accumulate), _s()), "mtp_reduce_rows_f32")
     return out
+
+
+def copy_segments(srcs, dsts):
+    """dsts[i].copy_(srcs[i]) for up to 12 contiguous f32 tensors in one launch."""
+    n = len(srcs)
+    assert n == len(dsts) and 0 < n <= 12
+    for s, d in zip(srcs, dsts):
+        assert s.dtype == d.dtype == torch.float32 and s.is_contiguous() and d.is_contiguous() and s.numel() == d.numel()
+    P = C.c_void_p * n
+    sp, dp = P(*[s.data_ptr() for s in srcs]), P(*[d.data_ptr() for d in dsts])
+    cnt = (C.c_int64 * n)(*[s.numel() for s in srcs])
+    check(lib().mtp_copy_segments_f32(sp, dp, cnt, n, _s()), "mtp_copy_segments_f32")
 
 
 def colsum(dy, out, accumulate=False):
@@ -214,16 +229,15 @@ def full_attn_fwd(qkv, o, lse, rel_h, rel_w, B, Hp, Wp, heads, scale):
     return o, lse
 
 
-def full_attn_bwd(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, heads, scale):
+def full_attn_bwd(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, heads, scale, accumulate=False):
     hd = qkv.shape[1] // (3 * heads)
     rt = (2 * Hp - 1) + (2 * Wp - 1)
     part = torch.empty(B * heads, rt * hd, device=qkv.device, dtype=torch.float32)
     check(lib().mtp_full_attn_bwd(_p(qkv), _p(o), _p(dout), _f32(lse), _p(dqkv), _dt(qkv), _f32(rel_h), _f32(rel_w), _p(part),
                                   B, Hp, Wp, heads, hd, scale, _s()), "mtp_full_attn_bwd")
-    red = torch.empty(rt * hd, device=qkv.device, dtype=torch.float32)
-    reduce_rows(part, red)
-    drel_h.copy_(red[:(2 * Hp - 1) * hd].view_as(drel_h))
-    drel_w.copy_(red[(2 * Hp - 1) * hd:].view_as(drel_w))
+    nh_ = (2 * Hp - 1) * hd   # per-(image, head) partials -> the two parameters, no staging copy
+    reduce_rows(part[:, :nh_], drel_h, accumulate)
+    reduce_rows(part[:, nh_:], drel_w, accumulate)
     return dqkv
 
 
@@ -259,7 +273,7 @@ def rvsa_attn_fwd(qkv, samp, o, lse, rel_h, rel_w, table, B, Hp, Wp, heads, scal
     return o, lse
 
 
-def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, drel_h, drel_w, dtable, B, Hp, Wp, heads, scale):
+def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, drel_h, drel_w, dtable, B, Hp, Wp, heads, scale, accumulate=False):
     hd = qkv.shape[1] // (3 * heads)
     T, C3 = qkv.shape
     Cc = C3 // 3
@@ -271,13 +285,9 @@ def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, dre
     tab_part = torch.empty(B * nh * nw, heads * 169, device=dev, dtype=torch.float32)
     check(lib().mtp_rvsa_attn_bwd(_p(qkv), _f32(samp), _p(o), _p(dout), _f32(lse), _p(dqkv), _p(dkv), _f32(dsamp), _p(rel_part), _p(tab_part),
                                   _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table), B, Hp, Wp, heads, hd, scale, _s()), "mtp_rvsa_attn_bwd")
-    red = torch.empty(26 * hd, device=dev, dtype=torch.float32)
-    reduce_rows(rel_part, red)
-    drel_h.copy_(red[:13 * hd].view_as(drel_h))
-    drel_w.copy_(red[13 * hd:].view_as(drel_w))
-    tred = torch.empty(heads * 169, device=dev, dtype=torch.float32)
-    reduce_rows(tab_part, tred)
-    dtable.copy_(tred.view(heads, 169).t())
+    reduce_rows(rel_part[:, :13 * hd], drel_h, accumulate)   # per-workgroup partials -> the parameters, no staging copies
+    reduce_rows(rel_part[:, 13 * hd:], drel_w, accumulate)
+    reduce_rows(tab_part, dtable, accumulate)
     return dqkv
 
 

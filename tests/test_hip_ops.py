@@ -144,6 +144,14 @@ def test_colsum_reduce_rows_axpy_cast(ops, dtype):
     assert rel_err(ops.colsum(dev(dy, dtype), e(384)).cpu(), dy.sum(0)) < 2e-4
     part = rnd(5000, 260)
     assert rel_err(ops.reduce_rows(dev(part), e(260)).cpu(), part.sum(0)) < 2e-4
+    # column slice of a wider partial buffer, accumulating into a non-zero gradient (partials -> two parameters, no staging copy)
+    dpart, g0 = dev(part), rnd(160, seed=3)
+    acc = ops.reduce_rows(dpart[:, 100:], dev(g0), accumulate=True)
+    assert rel_err(acc.cpu(), g0 + part[:, 100:].sum(0)) < 2e-4
+    srcs = [rnd(n, seed=20 + i) for i, n in enumerate((32 * 128, 5, 16 * 128, 1, 700, 64))]
+    dsts = [e(n) for n in (32 * 128, 5, 16 * 128, 1, 700, 64)]
+    ops.copy_segments([dev(s) for s in srcs], dsts)
+    assert all(torch.equal(d.cpu(), s) for s, d in zip(srcs, dsts))
     y, x = rnd(1001), rnd(1001, seed=9)
     assert rel_err(ops.axpy(dev(y), dev(x), 0.5).cpu(), y + 0.5 * x) < 1e-6
     src = rnd(1027)
