@@ -100,6 +100,22 @@ int mtp_unpatchify(const void* cols, int dtype, float* dimg, int64_t B, int64_t 
 int mtp_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, mtp_stream_t stream);
 /* dst (C, R) = src (R, C)^T with dtype conversion (weight copies for dgrad) */
 int mtp_transpose_cast(const float* src, void* dst, int dst_dtype, int64_t R, int64_t C, mtp_stream_t stream);
+/* All GEMM-side images of the f32 master weights in ONE launch per optimizer step (nn.Linear weights of every block,
+ * VIT:50-52,78,87,256,262, and the patch-embed conv, VIT:529): for each matrix src (R, C) f32 -> w (R, C) and/or
+ * wt (C, R) in `act_dtype` (or f32 when f32_out: the three stacked RVSA head weights/biases, VIT:231-242).
+ * `descs` is a DEVICE array of n descriptors built once by the host; tile0 = exclusive prefix sum of
+ * ceil(R/64)*ceil(C/64) over the table, total_tiles = its total.  Matrices with C % 4 != 0 (or R % 4 != 0 with a
+ * transpose) take an element-wise path. */
+typedef struct {
+    const float* src;
+    void* w;        /* or NULL */
+    void* wt;       /* or NULL */
+    int64_t R, C;
+    int64_t tile0;
+    int32_t f32_out; /* images of this entry are f32 whatever act_dtype says */
+    int32_t pad_;
+} mtp_wimg_desc;
+int mtp_weight_images(const mtp_wimg_desc* descs_dev, int n, int64_t total_tiles, int act_dtype, mtp_stream_t stream);
 /* ConvTranspose2d weight (Cin, Cout, 2, 2) f32 -> GEMM weight wg (4*Cout, Cin) and its transpose wgT (Cin, 4*Cout) */
 int mtp_convt_pack(const float* w, void* wg, void* wgT, int dtype, int64_t Cin, int64_t Cout, mtp_stream_t stream);
 /* dwg (4*Cout, Cin) f32 -> dw (Cin, Cout, 2, 2) f32 */

@@ -24,8 +24,14 @@ class GemmArgs(C.Structure):
                 ("split_k", i32), ("variant", i32), ("colsum", p)]
 
 
+class WimgDesc(C.Structure):
+    """mtp_wimg_desc"""
+    _fields_ = [("src", p), ("w", p), ("wt", p), ("R", i64), ("C", i64), ("tile0", i64), ("f32_out", C.c_int32), ("pad_", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list EVERY function declared in include/mtp_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
+    "mtp_weight_images": (i32, [p, i32, i64, i32, p]),
     "mtp_gemm_nt": (i32, [C.POINTER(GemmArgs), p]),
     "mtp_gemm_tn": (i32, [C.POINTER(GemmArgs), p]),
     "mtp_layernorm_fwd": (i32, [p, i32, p, p, p, i32, p, p, i64, i64, f32, i32, p]),

@@ -421,6 +421,73 @@ extern "C" int mtp_transpose_cast(const float* src, void* dst, int dst_dtype, in
     return launch_transpose<true>(src, MTP_F32, dst, dst_dtype, 1, R, C, 1, 0, (hipStream_t)stream);
 }
 
+// ---- every weight image of the model in one launch: workgroup = one 64x64 tile of one matrix (descriptor table in HBM)
+template <typename T>
+__global__ __launch_bounds__(256) void weight_images_kernel(const mtp_wimg_desc* __restrict__ descs, int n) {
+    __shared__ float tile[64][65];
+    const int64_t tl = blockIdx.x;
+    int lo = 0, hi = n - 1;   // last descriptor with tile0 <= tl (uniform over the workgroup: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile0 <= tl) lo = mid; else hi = mid - 1;
+    }
+    const mtp_wimg_desc d = descs[lo];
+    const int64_t local = tl - d.tile0, tc = (d.C + 63) / 64;
+    const int64_t r0 = (local / tc) * 64, c0 = (local % tc) * 64;
+    const int t = threadIdx.x, a = t >> 2, g = (t & 3) * 16;
+    const int64_t r = r0 + a;
+    const bool f32o = d.f32_out != 0;
+    if ((d.C & 3) || (d.wt && (d.R & 3))) {   // odd-sized (tiny) matrices: element-wise
+        for (int e = 0; e < 16; ++e) {
+            const int64_t c = c0 + g + e;
+            if (r < d.R && c < d.C) {
+                const float v = d.src[r * d.C + c];
+                if (d.w) { if (f32o) reinterpret_cast<float*>(d.w)[r * d.C + c] = v; else Elem<T>::store(reinterpret_cast<T*>(d.w) + r * d.C + c, v); }
+                if (d.wt) { if (f32o) reinterpret_cast<float*>(d.wt)[c * d.R + r] = v; else Elem<T>::store(reinterpret_cast<T*>(d.wt) + c * d.R + r, v); }
+            }
+        }
+        return;
+    }
+    float4 x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t c = c0 + g + 4 * q;
+        const bool ok = r < d.R && c < d.C;
+        x[q] = ok ? load4(d.src + r * d.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && d.w) {
+            if (f32o) store4(reinterpret_cast<float*>(d.w) + r * d.C + c, x[q]);
+            else store4(reinterpret_cast<T*>(d.w) + r * d.C + c, x[q]);
+        }
+    }
+    if (d.wt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tile[g + 4 * q + 0][a] = x[q].x; tile[g + 4 * q + 1][a] = x[q].y; tile[g + 4 * q + 2][a] = x[q].z; tile[g + 4 * q + 3][a] = x[q].w;
+        }
+        __syncthreads();
+        const int64_t c = c0 + a;   // source column = image row
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t rr = r0 + g + 4 * q;
+            if (c < d.C && rr < d.R) {
+                const float4 v = make_float4(tile[a][g + 4 * q], tile[a][g + 4 * q + 1], tile[a][g + 4 * q + 2], tile[a][g + 4 * q + 3]);
+                if (f32o) store4(reinterpret_cast<float*>(d.wt) + c * d.R + rr, v);
+                else store4(reinterpret_cast<T*>(d.wt) + c * d.R + rr, v);
+            }
+        }
+    }
+}
+
+extern "C" int mtp_weight_images(const mtp_wimg_desc* descs_dev, int n, int64_t total_tiles, int act_dtype, mtp_stream_t stream) {
+    if (!descs_dev || n <= 0 || total_tiles <= 0 || total_tiles > INT32_MAX) return MTP_ERR_ARG;
+    if (act_dtype == MTP_BF16)
+        hipLaunchKernelGGL((weight_images_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    else if (act_dtype == MTP_F32)
+        hipLaunchKernelGGL((weight_images_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
 extern "C" int mtp_convt_pack(const float* w, void* wg, void* wgT, int dtype, int64_t Cin, int64_t Cout, mtp_stream_t stream) {
     if (!w || Cin <= 0 || Cout <= 0) return MTP_ERR_ARG;
     dim3 grid(blocks_for(Cin * Cout * 4, 256, 4096)), block(256);

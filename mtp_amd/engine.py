@@ -37,6 +37,8 @@ class BackboneEngine:
         self._blk = None
         self._fpn = None
         self._pe = None
+        self._wimg = None
+        self._wimg_ptrs = None
 
     # ------------------------------------------------------------------ parameters
     def params(self):
@@ -47,24 +49,34 @@ class BackboneEngine:
         return (self.act,) + tuple((p.data_ptr(), p._version) for p in P.values())
 
     def prepare_weights(self, force=False):
-        """(Re)build the GEMM-side weight images when a parameter changed: ACT-dtype copies (W) and transposes (W^T)
-        for the dgrad GEMMs; ConvTranspose2d weights as (4C, C) GEMM matrices; the three RVSA 1x1-conv heads stacked."""
+        """Refresh the GEMM-side weight images when a parameter changed: ACT-dtype copies (W) and transposes (W^T) for the
+        dgrad GEMMs, the three RVSA 1x1-conv heads stacked -- ONE launch over a descriptor table (ops.WeightImages) into
+        persistent buffers; ConvTranspose2d weights as (4C, C) GEMM matrices (3 small launches)."""
         P = self.params()
         key = self._weights_key(P)
         if not force and key == self._key:
             return
+        ptrs = (self.act,) + tuple(p.data_ptr() for p in P.values())
+        if self._wimg is None or ptrs != self._wimg_ptrs:
+            self._build_weight_images(P)
+            self._wimg_ptrs = ptrs
+        self._wimg.refresh()
+        for name, (wg, wgT) in self._fpn.items():
+            ops.convt_pack(P[name + ".weight"].detach().contiguous(), wg, wgT)
+        self._key = key
+
+    def _build_weight_images(self, P):
         dev = P["patch_embed.proj.weight"].device
-        act = self.act
+        act, H, C = self.act, self.heads, self.C
+        entries = []
 
         def both(w2d):
             w2d = w2d.detach()
+            assert w2d.is_contiguous()
             R, Cc = w2d.shape
             wt = torch.empty(Cc, R, device=dev, dtype=act)
-            ops.transpose_cast(w2d.contiguous(), wt)
-            if act == F32:
-                return w2d.contiguous(), wt
-            w = torch.empty(R, Cc, device=dev, dtype=act)
-            ops.cast(w2d.contiguous(), w)
+            w = w2d if act == F32 else torch.empty(R, Cc, device=dev, dtype=act)   # f32 mode multiplies by the parameter itself
+            entries.append((w2d, None if act == F32 else w, wt, False))
             return w, wt
 
         blks = []
@@ -77,26 +89,24 @@ class BackboneEngine:
             b.w1, b.w1T = both(P[pre + "mlp.fc1.weight"])
             b.w2, b.w2T = both(P[pre + "mlp.fc2.weight"])
             if b.window:
-                b.wsamp = torch.cat([P[pre + "attn.sampling_offsets.2.weight"].detach().reshape(2 * self.heads, self.C),
-                                     P[pre + "attn.sampling_scales.2.weight"].detach().reshape(2 * self.heads, self.C),
-                                     P[pre + "attn.sampling_angles.2.weight"].detach().reshape(self.heads, self.C)], 0).contiguous()
-                b.bsamp = torch.cat([P[pre + "attn.sampling_offsets.2.bias"].detach(), P[pre + "attn.sampling_scales.2.bias"].detach(),
-                                     P[pre + "attn.sampling_angles.2.bias"].detach()], 0).contiguous()
+                b.wsamp = torch.empty(5 * H, C, device=dev, dtype=F32)
+                b.bsamp = torch.empty(5 * H, device=dev, dtype=F32)
+                r0 = 0
+                for head, rows in (("sampling_offsets", 2 * H), ("sampling_scales", 2 * H), ("sampling_angles", H)):
+                    entries.append((P[pre + "attn.%s.2.weight" % head].detach().view(rows, C), b.wsamp[r0:r0 + rows], None, True))
+                    entries.append((P[pre + "attn.%s.2.bias" % head].detach().view(1, rows), b.bsamp[r0:r0 + rows], None, True))
+                    r0 += rows
             blks.append(b)
         self._blk = blks
         wpe = P["patch_embed.proj.weight"].detach()
-        self._pe = both(wpe.reshape(wpe.shape[0], -1))
+        self._pe = both(wpe.view(wpe.shape[0], -1))
         fpn = {}
         for name in ("fpn1.0", "fpn1.3", "fpn2.0"):
             if name + ".weight" in P:
-                w = P[name + ".weight"].detach().contiguous()
-                Cin, Cout = w.shape[:2]
-                wg = torch.empty(4 * Cout, Cin, device=dev, dtype=act)
-                wgT = torch.empty(Cin, 4 * Cout, device=dev, dtype=act)
-                ops.convt_pack(w, wg, wgT)
-                fpn[name] = (wg, wgT)
+                Cin, Cout = P[name + ".weight"].shape[:2]
+                fpn[name] = (torch.empty(4 * Cout, Cin, device=dev, dtype=act), torch.empty(Cin, 4 * Cout, device=dev, dtype=act))
         self._fpn = fpn
-        self._key = key
+        self._wimg = ops.WeightImages(entries, act)
 
     # ------------------------------------------------------------------ helpers
     def _e(self, *shape, dtype=None):

@@ -177,6 +177,34 @@ def transpose_cast(src, dst):
     return dst
 
 
+class WeightImages:
+    """Descriptor table (in device memory) for mtp_weight_images: every GEMM-side image of the f32 master weights is
+    refreshed by ONE launch per optimizer step.  entries: (src (R,C) f32, w or None, wt or None, f32_out)."""
+
+    def __init__(self, entries, act_dtype):
+        n = len(entries)
+        arr = (_lib.WimgDesc * n)()
+        tile0 = 0
+        self.keep = []
+        for i, (src, w, wt, f32_out) in enumerate(entries):
+            assert src.dim() == 2 and src.dtype == torch.float32
+            R, Cc = src.shape
+            want = torch.float32 if f32_out else act_dtype
+            for img in (w, wt):
+                assert img is None or (img.dtype == want and img.numel() == R * Cc)
+            d = arr[i]
+            d.src, d.w, d.wt = _f32(src), _p(w), _p(wt)
+            d.R, d.C, d.tile0, d.f32_out = R, Cc, tile0, int(bool(f32_out))
+            tile0 += ((R + 63) // 64) * ((Cc + 63) // 64)
+            self.keep.append((src, w, wt))
+        self.n, self.total_tiles, self.act = n, tile0, _DT[act_dtype]
+        dev = entries[0][0].device
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
+    def refresh(self):
+        check(lib().mtp_weight_images(self.table.data_ptr(), self.n, self.total_tiles, self.act, _s()), "mtp_weight_images")
+
+
 def convt_pack(w, wg, wgT):
     Cin, Cout = w.shape[:2]
     dt = _dt(wg if wg is not None else wgT)

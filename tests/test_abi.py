@@ -30,6 +30,13 @@ def test_gemm_args_struct_layout():
     assert GemmArgs.bias.offset == 88 and GemmArgs.split_k.offset == 160 and GemmArgs.colsum.offset == 168
 
 
+def test_weight_image_descriptor_layout():
+    import ctypes as C
+    from mtp_amd._lib import WimgDesc
+    # mtp_wimg_desc: 3 ptrs, 3 i64, 2 i32
+    assert C.sizeof(WimgDesc) == 56 and WimgDesc.R.offset == 24 and WimgDesc.tile0.offset == 40 and WimgDesc.f32_out.offset == 48
+
+
 def test_arg_checks_reject_without_gpu():
     """argument validation happens before any launch, so it is testable on CPU"""
     import ctypes as C

@@ -102,6 +102,30 @@ def test_gemm_tn_bias_gradient_byproduct(ops, dtype, Kc, M, N, split):
     assert rel_err(cs.cpu(), cs0 + a.sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_weight_images_one_launch(ops, dtype):
+    """every GEMM-side image (W, W^T in ACT; stacked f32 head weights / biases) out of one descriptor-table launch"""
+    ws = [rnd(192, 128, seed=1), rnd(64, 256, seed=2), rnd(100, 36, seed=3), rnd(32, 128, seed=4), rnd(16, 128, seed=5), rnd(1, 32, seed=6)]
+    dws = [dev(w) for w in ws]
+    stack, bias = e(48, 128), e(32)
+    imgs = [(e(192, 128, dtype=dtype), e(128, 192, dtype=dtype)), (None, e(256, 64, dtype=dtype)), (e(100, 36, dtype=dtype), e(36, 100, dtype=dtype))]
+    entries = [(dws[0], imgs[0][0], imgs[0][1], False), (dws[1], None, imgs[1][1], False), (dws[2], imgs[2][0], imgs[2][1], False),
+               (dws[3], stack[:32], None, True), (dws[4], stack[32:], None, True), (dws[5], bias, None, True)]
+    odd, odd_w, odd_t = rnd(6, 2, seed=7), e(6, 2), e(2, 6, dtype=dtype)          # tiny odd sizes: element-wise path
+    entries += [(dev(odd), odd_w, None, True), (dev(odd), None, odd_t, False)]
+    tab = ops.WeightImages(entries, dtype)
+    tab.refresh()
+    assert torch.equal(odd_w.cpu(), odd) and torch.equal(odd_t.cpu(), odd.t().contiguous().to(dtype))
+    for w, (a, at) in zip(ws[:3], imgs):
+        if a is not None:
+            assert torch.equal(a.cpu(), w.to(dtype))
+        assert torch.equal(at.cpu(), w.t().contiguous().to(dtype))
+    assert torch.equal(stack.cpu(), torch.cat([ws[3], ws[4]])) and torch.equal(bias.cpu(), ws[5].view(-1))
+    dws[1].mul_(2.0)   # parameters change in place (optimizer step): a refresh re-reads the same table
+    tab.refresh()
+    assert torch.equal(imgs[1][1].cpu(), (2 * ws[1]).t().contiguous().to(dtype))
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm & reductions
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows,C", [(392, 128), (50, 768), (7, 1024)])
