@@ -265,9 +265,12 @@ __global__ __launch_bounds__(256) void rvsa_pool_bwd_kernel(const float* __restr
     }
 }
 
-// y (R,N) = x (R,K) W(N,K)^T + b : one block per row, one wave per output column group
-__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int N, int K) {
+// ---- the three RVSA 1x1-conv heads as one small f32 linear layer (R = windows ~ 1e3, K = C, N = 5*heads = 80) -----------------
+// Far too small for the MFMA GEMMs (8 output tiles); the kernels below are shaped so that the 320 KB weight is not re-read
+// from L2 by every thread (the first versions moved ~335 MB of L2 traffic per call and took 35-39 us each).
+// y (R,N) = x (R,K) W(N,K)^T + b : generic fallback, one block per row, one wave per output column group
+__global__ __launch_bounds__(256) void small_linear_fwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                      float* __restrict__ y, int N, int K) {
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* xr = x + (int64_t)r * K;
     for (int n = wave; n < N; n += 4) {
@@ -281,39 +284,108 @@ __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __re
         if (lane == 0) y[(int64_t)r * N + n] = s + (bias ? bias[n] : 0.f);
     }
 }
-// dx (R,K) = dy (R,N) W (N,K)
-__global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int R, int N, int K) {
-    const int K4 = K / 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)R * K4; i += (int64_t)gridDim.x * 256) {
-        const int k4 = (int)(i % K4), r = (int)(i / K4);
-        float4 s = make_float4(0, 0, 0, 0);
-        for (int n = 0; n < N; ++n) {
-            const float d = dy[(int64_t)r * N + n];
-            const float4 ww = load4(w + (int64_t)n * K + 4 * k4);
-            s.x += d * ww.x; s.y += d * ww.y; s.z += d * ww.z; s.w += d * ww.w;
+// K <= 2048: one wave per row, the row slice stays in registers, 4 output columns in flight per pass
+constexpr int SL_MAXJ = 8;
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int R, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const int K4 = K >> 2;
+    const float* xr = x + (int64_t)r * K;
+    float4 xs[SL_MAXJ];
+#pragma unroll
+    for (int j = 0; j < SL_MAXJ; ++j) {
+        const int k4 = lane + 64 * j;
+        xs[j] = k4 < K4 ? load4(xr + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int n = 0; n < N; n += 4) {
+        float s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nn = n + q < N ? n + q : N - 1;
+            const float* wr = w + (int64_t)nn * K;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < SL_MAXJ; ++j) {
+                const int k4 = lane + 64 * j;
+                if (k4 < K4) {
+                    const float4 b = load4(wr + 4 * k4);
+                    acc += xs[j].x * b.x + xs[j].y * b.y + xs[j].z * b.z + xs[j].w * b.w;
+                }
+            }
+            s[q] = acc;
         }
-        store4(dx + (int64_t)r * K + 4 * k4, s);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = wave_sum(s[q]);
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n + q < N) y[(int64_t)r * N + n + q] = s[q] + (bias ? bias[n + q] : 0.f);
+        }
     }
 }
-// dw (N,K) = dy^T x ; db[n] = sum_r dy[r][n]
-// rows split over blockIdx.y (16 rows per block) with f32 atomics into the zeroed outputs: the op is tiny (80 x 1024 outputs)
-// and a single pass over all R rows per thread left the chip idle for 100 us
-__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K) {
-    const int K4 = K / 4;
-    const int r0 = blockIdx.y * 16, r1 = (r0 + 16) < R ? (r0 + 16) : R;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)N * K4; i += (int64_t)gridDim.x * 256) {
-        const int k4 = (int)(i % K4), n = (int)(i / K4);
-        float4 s = make_float4(0, 0, 0, 0);
-        float sb = 0.f;
-        for (int r = r0; r < r1; ++r) {
-            const float d = dy[(int64_t)r * N + n];
-            const float4 xv = load4(x + (int64_t)r * K + 4 * k4);
-            s.x += d * xv.x; s.y += d * xv.y; s.z += d * xv.z; s.w += d * xv.w;
-            sb += d;
+// dx (R,K) = dy (R,N) W (N,K): thread = 4 k-columns x 4 rows (the dy factors are workgroup-uniform: scalar loads), so each
+// weight vector is loaded once per 4 rows
+__global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int R, int N, int K) {
+    const int k = (blockIdx.x * 256 + threadIdx.x) * 4, r0 = blockIdx.y * 4;
+    if (k >= K) return;
+    const float* d[4];
+    float4 s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + i < R ? r0 + i : R - 1;
+        d[i] = dy + (int64_t)rr * N;
+        s[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll 4
+    for (int n = 0; n < N; ++n) {
+        const float4 ww = load4(w + (int64_t)n * K + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dv = d[i][n];
+            s[i].x += dv * ww.x; s[i].y += dv * ww.y; s[i].z += dv * ww.z; s[i].w += dv * ww.w;
         }
-        float* o = dw + (int64_t)n * K + 4 * k4;
-        atomicAdd(o, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
-        if (k4 == 0 && db) atomicAdd(db + n, sb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (r0 + i < R) store4(dx + (int64_t)(r0 + i) * K + k, s[i]);
+}
+// dw (N,K) = dy^T x ; db[n] = sum_r dy[r][n].  thread = 4 k-columns x 8 outputs n (dy factors workgroup-uniform), rows split
+// over blockIdx.z with f32 atomics into the zeroed outputs (each x vector is loaded once per 8 outputs)
+constexpr int SL_DW_ROWS = 64;
+__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K) {
+    const int k = (blockIdx.x * 256 + threadIdx.x) * 4, n0 = blockIdx.y * 8;
+    const int r0 = blockIdx.z * SL_DW_ROWS, r1 = (r0 + SL_DW_ROWS) < R ? (r0 + SL_DW_ROWS) : R;
+    const bool kok = k < K;
+    const int kc = kok ? k : 0;
+    int nn[8];
+    float4 s[8];
+    float sb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        nn[q] = n0 + q < N ? n0 + q : N - 1;
+        s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sb[q] = 0.f;
+    }
+#pragma unroll 2
+    for (int r = r0; r < r1; ++r) {
+        const float4 xv = load4(x + (int64_t)r * K + kc);
+        const float* dr = dy + (int64_t)r * N;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float dv = dr[nn[q]];
+            s[q].x += dv * xv.x; s[q].y += dv * xv.y; s[q].z += dv * xv.z; s[q].w += dv * xv.w;
+            sb[q] += dv;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (kok && n0 + q < N) {
+            float* o = dw + (int64_t)(n0 + q) * K + k;
+            atomicAdd(o, s[q].x); atomicAdd(o + 1, s[q].y); atomicAdd(o + 2, s[q].z); atomicAdd(o + 3, s[q].w);
+        }
+        if (db && blockIdx.x == 0 && threadIdx.x == 0 && n0 + q < N) atomicAdd(db + n0 + q, sb[q]);
     }
 }
 
@@ -595,13 +667,16 @@ extern "C" int mtp_rvsa_pool_bwd(const float* dpooled, const float* avg, void* d
 
 extern "C" int mtp_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t R, int64_t N, int64_t K, mtp_stream_t stream) {
     if (!x || !w || !y || R <= 0 || N <= 0 || (K % 4)) return MTP_ERR_ARG;
-    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (int)N, (int)K);
+    if (K <= 256 * SL_MAXJ)
+        hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (int)R, (int)N, (int)K);
+    else
+        hipLaunchKernelGGL(small_linear_fwd_generic_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (int)N, (int)K);
     return mtp_launch_status();
 }
 extern "C" int mtp_small_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t R, int64_t N, int64_t K, mtp_stream_t stream) {
     if (!x || !w || !dy || R <= 0 || N <= 0 || (K % 4)) return MTP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dx) hipLaunchKernelGGL(small_linear_dx_kernel, dim3(blocks_for(R * K / 4, 256, 4096)), dim3(256), 0, s, dy, w, dx, (int)R, (int)N, (int)K);
+    if (dx) hipLaunchKernelGGL(small_linear_dx_kernel, dim3((unsigned)((K + 1023) / 1024), (unsigned)((R + 3) / 4)), dim3(256), 0, s, dy, w, dx, (int)R, (int)N, (int)K);
     if (dw) {
         if (db == dw + N * K) {   // one buffer [dw | db]: one clearing pass
             (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)(N * K + N), s);
@@ -609,7 +684,8 @@ extern "C" int mtp_small_linear_bwd(const float* x, const float* w, const float*
             (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)(N * K), s);
             if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s);
         }
-        hipLaunchKernelGGL(small_linear_dw_kernel, dim3(blocks_for(N * K / 4, 256, 4096), (unsigned)((R + 15) / 16)), dim3(256), 0, s, dy, x, dw, db, (int)R, (int)N, (int)K);
+        hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((K + 1023) / 1024), (unsigned)((N + 7) / 8), (unsigned)((R + SL_DW_ROWS - 1) / SL_DW_ROWS)), dim3(256), 0, s,
+                           dy, x, dw, db, (int)R, (int)N, (int)K);
     }
     return mtp_launch_status();
 }

@@ -145,6 +145,10 @@ def test_layernorm_fwd_bwd(ops, dtype, rows, C):
     tot = dxr + dres + extra
     assert rel_err(dx.cpu(), tot) < 2e-4 and rel_err(dxc.float().cpu(), tot * cs.repeat_interleave(rps)[:, None]) < TOL[dtype]
     assert rel_err(dg.cpu(), dgr) < 2e-4 and rel_err(db.cpu(), dbr) < 2e-4
+    # accumulating entry point (training engine): dgamma / dbeta += ..., no partial buffer
+    dg2, db2, dx2 = dev(torch.ones(C)), dev(torch.full((C,), -2.0)), e(rows, C)
+    ops.layernorm_bwd(dev(dy, dtype), dev(x), mean, rstd, dev(g), dx2, dg2, db2, dres=dev(dres), extra=dev(extra), accumulate=True)
+    assert rel_err(dg2.cpu(), 1 + dgr) < 2e-4 and rel_err(db2.cpu(), dbr - 2) < 2e-4 and rel_err(dx2.cpu(), tot) < 2e-4
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -291,6 +295,17 @@ def test_rvsa_pool_and_small_linear(ops, dtype, Hp, Wp):
     acc = dev(base, dtype)
     ops.rvsa_pool_bwd(dx, avg, acc, B, Hp, Wp, accumulate=True)
     assert rel_err(acc.float().cpu(), base + O.rvsa_pool_bwd(dx.cpu(), ar, B, Hp, Wp)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("R,N,K", [(1024, 80, 1024), (37, 10, 128), (130, 5, 1100 * 4), (6, 83, 768)])
+def test_small_linear_shapes(ops, R, N, K):
+    """ragged rows / outputs, the ViT-L head shape, and K above the register path (generic forward kernel)"""
+    x, w, b, dy = rnd(R, K), rnd(N, K, seed=1, scale=0.1), rnd(N, seed=2), rnd(R, N, seed=3)
+    y = ops.small_linear_fwd(dev(x), dev(w), dev(b), e(R, N))
+    assert rel_err(y.cpu(), x @ w.t() + b) < 1e-5
+    dx, dw, db = e(R, K), e(N, K), e(N)
+    ops.small_linear_bwd(dev(x), dev(w), dev(dy), dx, dw, db)
+    assert rel_err(dx.cpu(), dy @ w) < 1e-5 and rel_err(dw.cpu(), dy.t() @ x) < 1e-5 and rel_err(db.cpu(), dy.sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", DT)
