@@ -85,13 +85,6 @@ int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
                       const float* dres, const float* extra, void* dx, int dx_dtype,
                       void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
                       float* dgamma_part, float* dbeta_part, int64_t rows, int64_t C, mtp_stream_t stream);
-/* same, but dgamma / dbeta are the (C,) f32 gradients themselves and are ACCUMULATED into (f32 atomics; no partial
- * buffer, no reduction launches): the training engine's path, whose gradient buffers are zeroed once per step */
-int mtp_layernorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
-                          const float* gamma, const float* beta, int fuse_gelu,
-                          const float* dres, const float* extra, void* dx, int dx_dtype,
-                          void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
-                          float* dgamma, float* dbeta, int64_t rows, int64_t C, mtp_stream_t stream);
 /* out[c] (+)= sum_r part[r * ld + c], c < C   (per-workgroup partials -> parameter gradient; ld >= C lets one
  * partial buffer feed several parameters) */
 int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);

@@ -284,44 +284,54 @@ __global__ __launch_bounds__(256) void small_linear_fwd_generic_kernel(const flo
         if (lane == 0) y[(int64_t)r * N + n] = s + (bias ? bias[n] : 0.f);
     }
 }
-// K <= 2048: one wave per row, the row slice stays in registers, 4 output columns in flight per pass
-constexpr int SL_MAXJ = 8;
+// K <= 256*MAXJ: one workgroup per ROWS rows, wave = a quarter of the output columns, the row slices stay in registers and every
+// weight vector loaded from L2 is used for ROWS rows (the one-row version re-read the whole 320 KB weight per row: 335 MB of L2
+// traffic per call, 39 us); 4 output columns (4*MAXJ weight loads) in flight per pass
+template <int ROWS, int MAXJ>
 __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                               float* __restrict__ y, int R, int N, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave;
-    if (r >= R) return;
+    const int r0 = blockIdx.x * ROWS;
     const int K4 = K >> 2;
-    const float* xr = x + (int64_t)r * K;
-    float4 xs[SL_MAXJ];
+    float4 xs[ROWS][MAXJ];
 #pragma unroll
-    for (int j = 0; j < SL_MAXJ; ++j) {
-        const int k4 = lane + 64 * j;
-        xs[j] = k4 < K4 ? load4(xr + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < ROWS; ++i) {
+        const float* xr = x + (int64_t)(r0 + i < R ? r0 + i : R - 1) * K;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int k4 = lane + 64 * j;
+            xs[i][j] = k4 < K4 ? load4(xr + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
-    for (int n = 0; n < N; n += 4) {
-        float s[4];
+    const int per = (N + 3) / 4, n_lo = wave * per, n_hi = (n_lo + per) < N ? (n_lo + per) : N;
+    for (int n = n_lo; n < n_hi; n += 4) {
+        float s[4][ROWS];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int nn = n + q < N ? n + q : N - 1;
+            const int nn = n + q < n_hi ? n + q : n_hi - 1;
             const float* wr = w + (int64_t)nn * K;
-            float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < SL_MAXJ; ++j) {
-                const int k4 = lane + 64 * j;
-                if (k4 < K4) {
-                    const float4 b = load4(wr + 4 * k4);
-                    acc += xs[j].x * b.x + xs[j].y * b.y + xs[j].z * b.z + xs[j].w * b.w;
-                }
+            for (int i = 0; i < ROWS; ++i) s[q][i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                // unconditional load from a clamped index (xs is zero beyond K): a branch around the load makes hipcc wait for
+                // each one separately -- 4*MAXJ serialised L2 latencies per pass, measured 10 us per pass
+                const int k4 = lane + 64 * j, k4c = k4 < K4 ? k4 : K4 - 1;
+                const float4 b = load4(wr + 4 * k4c);
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i) s[q][i] += xs[i][j].x * b.x + xs[i][j].y * b.y + xs[i][j].z * b.z + xs[i][j].w * b.w;
             }
-            s[q] = acc;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] = wave_sum(s[q]);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) s[q][i] = wave_sum(s[q][i]);
         if (lane == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (n + q < N) y[(int64_t)r * N + n + q] = s[q] + (bias ? bias[n + q] : 0.f);
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+                    if (n + q < n_hi && r0 + i < R) y[(int64_t)(r0 + i) * N + n + q] = s[q][i] + (bias ? bias[n + q] : 0.f);
         }
     }
 }
@@ -351,12 +361,16 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __res
     for (int i = 0; i < 4; ++i)
         if (r0 + i < R) store4(dx + (int64_t)(r0 + i) * K + k, s[i]);
 }
-// dw (N,K) = dy^T x ; db[n] = sum_r dy[r][n].  thread = 4 k-columns x 8 outputs n (dy factors workgroup-uniform), rows split
-// over blockIdx.z with f32 atomics into the zeroed outputs (each x vector is loaded once per 8 outputs)
-constexpr int SL_DW_ROWS = 64;
+// dw (N,K) = dy^T x ; db[n] = sum_r dy[r][n].  Workgroup = 256 k-columns x 8 outputs n x 4*SL_DW_ROWS rows: lane = 4 k-columns,
+// wave = a quarter of the rows (dy factors wave-uniform: scalar loads; each x vector feeds 8 outputs), waves combined through
+// LDS, then ONE set of f32 atomics per workgroup into the zeroed outputs (the atomics were the cost of the first versions).
+constexpr int SL_DW_ROWS = 32;
 __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K) {
-    const int k = (blockIdx.x * 256 + threadIdx.x) * 4, n0 = blockIdx.y * 8;
-    const int r0 = blockIdx.z * SL_DW_ROWS, r1 = (r0 + SL_DW_ROWS) < R ? (r0 + SL_DW_ROWS) : R;
+    __shared__ float4 red[3][8][64];
+    __shared__ float redb[3][8];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = (blockIdx.x * 64 + lane) * 4, n0 = blockIdx.y * 8;
+    const int r0 = (blockIdx.z * 4 + wave) * SL_DW_ROWS, r1 = (r0 + SL_DW_ROWS) < R ? (r0 + SL_DW_ROWS) : R;
     const bool kok = k < K;
     const int kc = kok ? k : 0;
     int nn[8];
@@ -379,13 +393,29 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __res
             sb[q] += dv;
         }
     }
+    if (wave > 0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        if (kok && n0 + q < N) {
-            float* o = dw + (int64_t)(n0 + q) * K + k;
-            atomicAdd(o, s[q].x); atomicAdd(o + 1, s[q].y); atomicAdd(o + 2, s[q].z); atomicAdd(o + 3, s[q].w);
+        for (int q = 0; q < 8; ++q) {
+            red[wave - 1][q][lane] = s[q];
+            if (lane == 0) redb[wave - 1][q] = sb[q];
         }
-        if (db && blockIdx.x == 0 && threadIdx.x == 0 && n0 + q < N) atomicAdd(db + n0 + q, sb[q]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const float4 o = red[v][q][lane];
+                s[q].x += o.x; s[q].y += o.y; s[q].z += o.z; s[q].w += o.w;
+                sb[q] += redb[v][q];
+            }
+            if (kok && n0 + q < N) {
+                float* o = dw + (int64_t)(n0 + q) * K + k;
+                atomicAdd(o, s[q].x); atomicAdd(o + 1, s[q].y); atomicAdd(o + 2, s[q].z); atomicAdd(o + 3, s[q].w);
+            }
+            if (db && blockIdx.x == 0 && lane == 0 && n0 + q < N) atomicAdd(db + n0 + q, sb[q]);
+        }
     }
 }
 
@@ -667,8 +697,10 @@ extern "C" int mtp_rvsa_pool_bwd(const float* dpooled, const float* avg, void* d
 
 extern "C" int mtp_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t R, int64_t N, int64_t K, mtp_stream_t stream) {
     if (!x || !w || !y || R <= 0 || N <= 0 || (K % 4)) return MTP_ERR_ARG;
-    if (K <= 256 * SL_MAXJ)
-        hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (int)R, (int)N, (int)K);
+    if (K <= 1024)
+        hipLaunchKernelGGL((small_linear_fwd_kernel<4, 4>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (int)R, (int)N, (int)K);
+    else if (K <= 2048)
+        hipLaunchKernelGGL((small_linear_fwd_kernel<2, 8>), dim3((unsigned)((R + 1) / 2)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (int)R, (int)N, (int)K);
     else
         hipLaunchKernelGGL(small_linear_fwd_generic_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, w, b, y, (int)N, (int)K);
     return mtp_launch_status();
@@ -684,7 +716,7 @@ extern "C" int mtp_small_linear_bwd(const float* x, const float* w, const float*
             (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)(N * K), s);
             if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s);
         }
-        hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((K + 1023) / 1024), (unsigned)((N + 7) / 8), (unsigned)((R + SL_DW_ROWS - 1) / SL_DW_ROWS)), dim3(256), 0, s,
+        hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)((N + 7) / 8), (unsigned)((R + 4 * SL_DW_ROWS - 1) / (4 * SL_DW_ROWS))), dim3(256), 0, s,
                            dy, x, dw, db, (int)R, (int)N, (int)K);
     }
     return mtp_launch_status();

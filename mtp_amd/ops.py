@@ -111,11 +111,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=F
                   dx_copy=None, copy_scale=None, rows_per_sample=0, accumulate=False):
     """dx = [dres] + [extra] + LN'(dy); dgamma/dbeta (C,) f32 are overwritten (or accumulated into)."""
     rows, Cc = x.shape
-    if accumulate:   # straight into the gradients (atomics): no partial buffer, no reduction launches
-        check(lib().mtp_layernorm_bwd_acc(_p(dy), _dt(dy), _p(x), _dt(x), _f32(mean), _f32(rstd), _f32(gamma), _f32(beta), int(gelu),
-                                          _f32(dres), _f32(extra), _p(dx), _dt(dx), _p(dx_copy), (_dt(dx_copy) if dx_copy is not None else 0),
-                                          _f32(copy_scale), rows_per_sample, _f32(dgamma), _f32(dbeta), rows, Cc, _s()), "mtp_layernorm_bwd_acc")
-        return dx
+    # (an in-kernel f32-atomic accumulation of dgamma / dbeta was measured: 512 workgroups hitting the same 2C addresses took
+    #  the kernel from 61 to 106 us; per-workgroup partials + two 8 us reductions are faster)
     nblk = lib().mtp_layernorm_bwd_partial_rows(rows)
     part = torch.empty(2, nblk, Cc, device=x.device, dtype=torch.float32)
     check(lib().mtp_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _f32(mean), _f32(rstd), _f32(gamma), _f32(beta), int(gelu),

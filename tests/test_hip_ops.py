@@ -297,7 +297,7 @@ def test_rvsa_pool_and_small_linear(ops, dtype, Hp, Wp):
     assert rel_err(acc.float().cpu(), base + O.rvsa_pool_bwd(dx.cpu(), ar, B, Hp, Wp)) < TOL[dtype]
 
 
-@pytest.mark.parametrize("R,N,K", [(1024, 80, 1024), (37, 10, 128), (130, 5, 1100 * 4), (6, 83, 768)])
+@pytest.mark.parametrize("R,N,K", [(1024, 80, 1024), (37, 10, 128), (130, 5, 1100 * 4), (6, 83, 768), (67, 12, 1536), (300, 80, 256)])
 def test_small_linear_shapes(ops, R, N, K):
     """ragged rows / outputs, the ViT-L head shape, and K above the register path (generic forward kernel)"""
     x, w, b, dy = rnd(R, K), rnd(N, K, seed=1, scale=0.1), rnd(N, seed=2), rnd(R, N, seed=3)
