@@ -11,33 +11,40 @@ namespace {
 constexpr int LN_THREADS = 256;   // 4 rows per block pass
 constexpr int MAXV = 4;           // float4 per lane kept in registers -> C <= 1024
 
+// All row loads are UNCONDITIONAL on a clamped column (lanes past the row end re-read the last group and are masked in the
+// arithmetic / at the store): with `if (c4 < nv)` around them hipcc emitted an exec-masked block + s_waitcnt vmcnt(0) per load,
+// i.e. one HBM latency after the other (the backward ran at 3.4 TB/s with 8-10 serialised waits per row).
 template <typename Tx, typename Ty, bool GELU>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const Tx* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            Ty* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                            int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;   // float4 groups per row
+    int col[MAXV];
+    bool ok[MAXV];
+    float4 g[MAXV], bb[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        ok[i] = c4 < nv;
+        col[i] = 4 * (ok[i] ? c4 : nv - 1);
+        g[i] = *reinterpret_cast<const float4*>(gamma + col[i]);
+        bb[i] = *reinterpret_cast<const float4*>(beta + col[i]);
+    }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const Tx* xr = x + row * C;
         float4 v[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) v[i] = load4(xr + col[i]);
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < nv) {
-                v[i] = load4(xr + 4 * c4);
-                s += v[i].x + v[i].y + v[i].z + v[i].w;
-            }
-        }
+        for (int i = 0; i < MAXV; ++i) s += ok[i] ? (v[i].x + v[i].y + v[i].z + v[i].w) : 0.f;
         const float mu = wave_sum(s) / (float)C;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < nv) {
-                const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
-                q += a * a + b * b + c * c + d * d;
-            }
+            const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+            q += ok[i] ? (a * a + b * b + c * c + d * d) : 0.f;
         }
         const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
         if (lane == 0) {
@@ -47,15 +54,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const Tx* __restrict
         Ty* yr = y + row * C;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < nv) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c4);
-                const float4 b = *reinterpret_cast<const float4*>(beta + 4 * c4);
-                float4 o = make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
-                                       (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w);
-                if (GELU) o = make_float4(gelu_f(o.x), gelu_f(o.y), gelu_f(o.z), gelu_f(o.w));
-                store4(yr + 4 * c4, o);
-            }
+            float4 o = make_float4((v[i].x - mu) * rs * g[i].x + bb[i].x, (v[i].y - mu) * rs * g[i].y + bb[i].y,
+                                   (v[i].z - mu) * rs * g[i].z + bb[i].z, (v[i].w - mu) * rs * g[i].w + bb[i].w);
+            if (GELU) o = make_float4(gelu_f(o.x), gelu_f(o.y), gelu_f(o.z), gelu_f(o.w));
+            if (ok[i]) store4(yr + col[i], o);
         }
     }
 }
@@ -70,56 +72,65 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
     float4 gacc[MAXV], bacc[MAXV], g[MAXV], bt[MAXV];
+    int col[MAXV];
+    bool ok[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         gacc[i] = make_float4(0, 0, 0, 0);
         bacc[i] = make_float4(0, 0, 0, 0);
         const int c4 = lane + 64 * i;
-        g[i] = c4 < nv ? *reinterpret_cast<const float4*>(gamma + 4 * c4) : make_float4(0, 0, 0, 0);
-        bt[i] = (GELU && c4 < nv) ? *reinterpret_cast<const float4*>(beta + 4 * c4) : make_float4(0, 0, 0, 0);
+        ok[i] = c4 < nv;
+        col[i] = 4 * (ok[i] ? c4 : nv - 1);
+        g[i] = *reinterpret_cast<const float4*>(gamma + col[i]);
+        bt[i] = GELU ? *reinterpret_cast<const float4*>(beta + col[i]) : make_float4(0, 0, 0, 0);
     }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        // ---- every load of the row first (the uniform `if (dres)` blocks contain loads only, no uses)
+        float4 xv[MAXV], dv[MAXV], rr[MAXV], ee[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            xv[i] = load4(x + row * C + col[i]);
+            dv[i] = load4(dy + row * C + col[i]);
+            rr[i] = zero4;
+            ee[i] = zero4;
+        }
+        if (dres) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) rr[i] = *reinterpret_cast<const float4*>(dres + row * C + col[i]);
+        }
+        if (extra) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) ee[i] = *reinterpret_cast<const float4*>(extra + row * C + col[i]);
+        }
         const float mu = mean[row], rs = rstd[row];
+        const float cs = (dx_copy && copy_scale) ? copy_scale[(uint32_t)row / (uint32_t)rows_per_sample] : 1.0f;   // (64-bit division is ~150 instructions)
         float4 xh[MAXV], d[MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < nv) {
-                const float4 xv = load4(x + row * C + 4 * c4);
-                float4 dv = load4(dy + row * C + 4 * c4);
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                if (GELU) {   // y = gelu(z), z = xhat*gamma+beta
-                    dv.x *= dgelu_f(xh[i].x * g[i].x + bt[i].x);
-                    dv.y *= dgelu_f(xh[i].y * g[i].y + bt[i].y);
-                    dv.z *= dgelu_f(xh[i].z * g[i].z + bt[i].z);
-                    dv.w *= dgelu_f(xh[i].w * g[i].w + bt[i].w);
-                }
-                gacc[i].x += dv.x * xh[i].x; gacc[i].y += dv.y * xh[i].y; gacc[i].z += dv.z * xh[i].z; gacc[i].w += dv.w * xh[i].w;
-                bacc[i].x += dv.x; bacc[i].y += dv.y; bacc[i].z += dv.z; bacc[i].w += dv.w;
-                d[i] = make_float4(dv.x * g[i].x, dv.y * g[i].y, dv.z * g[i].z, dv.w * g[i].w);
-                s1 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
-                s2 += d[i].x + d[i].y + d[i].z + d[i].w;
+            if (!ok[i]) dv[i] = zero4;   // select on the loaded VALUE: masked lanes add nothing below
+            xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
+            if (GELU) {   // y = gelu(z), z = xhat*gamma+beta
+                dv[i].x *= dgelu_f(xh[i].x * g[i].x + bt[i].x);
+                dv[i].y *= dgelu_f(xh[i].y * g[i].y + bt[i].y);
+                dv[i].z *= dgelu_f(xh[i].z * g[i].z + bt[i].z);
+                dv[i].w *= dgelu_f(xh[i].w * g[i].w + bt[i].w);
             }
+            gacc[i].x += dv[i].x * xh[i].x; gacc[i].y += dv[i].y * xh[i].y; gacc[i].z += dv[i].z * xh[i].z; gacc[i].w += dv[i].w * xh[i].w;
+            bacc[i].x += dv[i].x; bacc[i].y += dv[i].y; bacc[i].z += dv[i].z; bacc[i].w += dv[i].w;
+            d[i] = make_float4(dv[i].x * g[i].x, dv[i].y * g[i].y, dv[i].z * g[i].z, dv[i].w * g[i].w);
+            s1 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
+            s2 += d[i].x + d[i].y + d[i].z + d[i].w;
         }
         const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
-        const float cs = (dx_copy && copy_scale) ? copy_scale[row / rows_per_sample] : 1.0f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < nv) {
-                float4 o = make_float4((d[i].x - xh[i].x * c1 - c2) * rs, (d[i].y - xh[i].y * c1 - c2) * rs,
-                                       (d[i].z - xh[i].z * c1 - c2) * rs, (d[i].w - xh[i].w * c1 - c2) * rs);
-                if (dres) {
-                    const float4 r = *reinterpret_cast<const float4*>(dres + row * C + 4 * c4);
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                }
-                if (extra) {
-                    const float4 r = *reinterpret_cast<const float4*>(extra + row * C + 4 * c4);
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                }
-                store4(dx + row * C + 4 * c4, o);
-                if (dx_copy) store4(dx_copy + row * C + 4 * c4, make_float4(o.x * cs, o.y * cs, o.z * cs, o.w * cs));
+            const float4 o = make_float4((d[i].x - xh[i].x * c1 - c2) * rs + rr[i].x + ee[i].x, (d[i].y - xh[i].y * c1 - c2) * rs + rr[i].y + ee[i].y,
+                                         (d[i].z - xh[i].z * c1 - c2) * rs + rr[i].z + ee[i].z, (d[i].w - xh[i].w * c1 - c2) * rs + rr[i].w + ee[i].w);
+            if (ok[i]) {
+                store4(dx + row * C + col[i], o);
+                if (dx_copy) store4(dx_copy + row * C + col[i], make_float4(o.x * cs, o.y * cs, o.z * cs, o.w * cs));
             }
         }
     }
@@ -135,8 +146,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
     if (wave == 0) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < nv) {
+            if (ok[i]) {
                 float4 a = gacc[i], b = bacc[i];
 #pragma unroll
                 for (int w = 0; w < 3; ++w) {
@@ -144,8 +154,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
                     a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w;
                     b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
                 }
-                *reinterpret_cast<float4*>(dgamma_part + (int64_t)blockIdx.x * C + 4 * c4) = a;
-                *reinterpret_cast<float4*>(dbeta_part + (int64_t)blockIdx.x * C + 4 * c4) = b;
+                *reinterpret_cast<float4*>(dgamma_part + (int64_t)blockIdx.x * C + col[i]) = a;
+                *reinterpret_cast<float4*>(dbeta_part + (int64_t)blockIdx.x * C + col[i]) = b;
             }
         }
     }
@@ -248,7 +258,7 @@ extern "C" int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
                                  const float* gamma, const float* beta, int fuse_gelu, const float* dres, const float* extra, void* dx, int dx_dtype,
                                  void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
                                  float* dgamma_part, float* dbeta_part, int64_t rows, int64_t C, mtp_stream_t stream) {
-    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma_part || !dbeta_part || rows <= 0 || (C % 4) || C > 256 * MAXV) return MTP_ERR_ARG;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma_part || !dbeta_part || rows <= 0 || rows > INT32_MAX || (C % 4) || C > 256 * MAXV) return MTP_ERR_ARG;
     if (fuse_gelu && !beta) return MTP_ERR_ARG;
     if (dx_copy && copy_dtype != dy_dtype) return MTP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
