@@ -288,7 +288,18 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    int m0, n0;
+    if (p.order & 2) {   // grouped order: panels of 8 tile rows, rows fastest inside a panel (an XCD's ~128 resident tiles cover
+                         // 8 rows x 16 columns instead of 5 rows x all columns: the B tiles are shared by 8 instead of ~5 tiles)
+        const int tiles_m = (int)gridDim.x / p.tiles_n, per = 8 * p.tiles_n;
+        const int grp = tile / per, r = tile - grp * per;
+        const int gm = (tiles_m - grp * 8) < 8 ? (tiles_m - grp * 8) : 8;
+        m0 = (grp * 8 + r % gm) * BM;
+        n0 = (r / gm) * BN;
+    } else {
+        m0 = (tile / p.tiles_n) * BM;
+        n0 = (tile % p.tiles_n) * BN;
+    }
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -633,6 +644,11 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     const bool glds = ((a->variant & 1) == 0) && (a->K % (8 * E) == 0);
     // default = single-stage / 4 workgroups per CU (measured +20 % over the double-buffered 2-per-CU kernel on every ViT-L
     // shape: 827 / 707 / 825 / 910 vs 675 / 590 / 674 / 769 TF/s); variant bit 3 selects the double-buffered kernel
+    // tile order of the single-stage kernel: variant bits 1-2 = 0 auto, 1 plain blockIdx, 2 grouped, 3 row-major with XCD remap.
+    // Grouped (panels of 8 tile rows) measured +2..7 % at N = 3072 and +8..11 % at N = 4096, -2..3 % at N = 1024.
+    const int ord = (a->variant >> 1) & 3;
+    k.order = ord == 0 ? (k.tiles_n > 8 ? 2 : 0) : ord == 1 ? 1 : ord == 2 ? 2 : 0;
+    if (!(glds && !(a->variant & 8))) k.order = ord;   // the double-buffered kernels keep their own meaning of the bits
     if (glds && !(a->variant & 8))
         hipLaunchKernelGGL((gemm_nt_sb_kernel<T, Tout, EPI>), grid, block, STAGE_BYTES, stream, k);
     else if (glds)
