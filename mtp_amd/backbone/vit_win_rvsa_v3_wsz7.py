@@ -252,7 +252,9 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
         pretrained = pretrained or self.pretrained
         if isinstance(pretrained, str):
             self.apply(self._init_weights)
-            checkpoint = torch.load(pretrained, map_location="cpu")
+            # weights_only=False as the reference's torch.load (VIT:711) effectively was: its own checkpoints carry a numpy
+            # array ('loss_pretrain', MAIN:826) and optimizer / scheduler dicts next to 'state_dict'
+            checkpoint = torch.load(pretrained, map_location="cpu", weights_only=False)
             if "state_dict" in checkpoint:
                 state_dict = checkpoint["state_dict"]
             elif "model" in checkpoint:

@@ -107,6 +107,30 @@ class FlatParams:
         return torch.tensor(starts, dtype=torch.int64), torch.tensor(wds, dtype=torch.float32)
 
 
+def reference_param_groups(named_params, weight_decay, prefix="encoder."):
+    """Parameter groups as LayerDecayOptimizerConstructor_ViT.add_params builds them
+    (mmcv_custom/layer_decay_optimizer_constructor_vit.py:33-67): group = (layer id, decay / no_decay), created in
+    first-seen order of named_parameters(); no_decay = 1-D, `.bias`, or 'pos_embed' in the name (:43-48).
+    Faithful quirk: get_num_layer_for_vit (:7-16) tests for names starting with "backbone.", but in the pretrain model the
+    backbone's parameters are called "encoder.*" (MODELS:85-89), so EVERY parameter falls through to the last layer id
+    (num_layers - 1) and lr_scale = 0.9 ** 0 = 1: the layer decay is a no-op there, and there are exactly two groups.
+    Returns [(group_name, lr_scale, weight_decay, [names])], group_name = "layer_<depth+1>_<decay|no_decay>" as in :50."""
+    named_params = list(named_params)
+    depth = 1 + max([int(n.split(".")[1]) for n, _ in named_params if n.startswith("blocks.")] or [-1])
+    groups, order = {}, []
+    for n, p in named_params:
+        if not p.requires_grad:
+            continue
+        full = prefix + n
+        nd = p.dim() == 1 or full.endswith(".bias") or "pos_embed" in full
+        key = "layer_%d_%s" % (depth + 1, "no_decay" if nd else "decay")
+        if key not in groups:
+            groups[key] = (key, 1.0, 0.0 if nd else weight_decay, [])
+            order.append(key)
+        groups[key][3].append(n)
+    return [groups[k] for k in order]
+
+
 class GradReducer:
     """Bucketed gradient all-reduce overlapped with the backward (side stream on GPU; synchronous on CPU/gloo)."""
 
@@ -158,6 +182,7 @@ class FlatAdamW:
 
     def __init__(self, flat, lr=6e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_norm=5.0, total_steps=None, world_size=1):
         self.flat, self.lr0, self.betas, self.eps, self.max_norm = flat, lr, betas, eps, max_norm
+        self.weight_decay = weight_decay
         self.total_steps, self.world = total_steps, world_size
         dev = flat.data.device
         self.m = torch.zeros_like(flat.data)
@@ -176,6 +201,55 @@ class FlatAdamW:
     def hyper_values(self):
         b1, b2 = self.betas
         return [self.lr_at(self.t - 1), b1, b2, self.eps, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t]
+
+    # ---- checkpoint / resume in the reference's formats (MAIN:483-499, 823-829) --------------------------------------------
+    def state_dict(self, module):
+        """torch.optim.AdamW.state_dict() layout for the parameter groups the reference builds (reference_param_groups):
+        loadable by a torch AdamW constructed the same way and vice versa.  Parameters that never receive a gradient
+        (`norm.*`) carry no state, as in torch."""
+        f = self.flat
+        groups = reference_param_groups(module.named_parameters(), self.weight_decay)
+        state, pgs, idx = {}, [], 0
+        for name, scale, wd, names in groups:
+            ids = []
+            for n in names:
+                if self.t > 0 and f.groups[n] is not None:
+                    state[idx] = {"step": torch.tensor(float(self.t)), "exp_avg": f.view(self.m, n).detach().cpu().clone(),
+                                  "exp_avg_sq": f.view(self.v, n).detach().cpu().clone()}
+                ids.append(idx)
+                idx += 1
+            pgs.append({"lr": self.lr_at(self.t) * scale, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": wd, "amsgrad": False,
+                        "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                        "initial_lr": self.lr0 * scale, "param_names": list(names), "lr_scale": scale, "group_name": name, "params": ids})
+        return {"state": state, "param_groups": pgs}
+
+    def load_state_dict(self, sd, module):
+        f = self.flat
+        groups = reference_param_groups(module.named_parameters(), self.weight_decay)
+        names = [n for g in groups for n in g[3]]
+        ids = [i for pg in sd["param_groups"] for i in pg["params"]]
+        if len(ids) != len(names):
+            raise ValueError("optimizer state has %d parameters, the backbone has %d" % (len(ids), len(names)))
+        t = 0
+        self.m.zero_()
+        self.v.zero_()
+        for i, n in zip(ids, names):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            f.view(self.m, n).copy_(st["exp_avg"])
+            f.view(self.v, n).copy_(st["exp_avg_sq"])
+            t = max(t, int(float(st["step"])))
+        self.t = t
+
+    def scheduler_state_dict(self):
+        """the fields of torch.optim.lr_scheduler.CosineAnnealingLR.state_dict() (MAIN:457: T_max = end_iter, eta_min = 0)"""
+        return {"T_max": self.total_steps, "eta_min": 0, "base_lrs": [self.lr0, self.lr0], "last_epoch": self.t, "verbose": False,
+                "_step_count": self.t + 1, "_get_lr_called_within_step": False, "_last_lr": [self.lr_at(self.t)] * 2}
+
+    def load_scheduler_state_dict(self, sd):
+        self.total_steps = sd.get("T_max", self.total_steps)
+        self.t = int(sd.get("last_epoch", self.t))
 
     def step(self):
         from . import ops
@@ -203,6 +277,37 @@ class DataParallelTrainer:
         self.reducer = GradReducer(self.flat, bucket_bytes)
         self.opt = FlatAdamW(self.flat, lr=lr, weight_decay=weight_decay, max_norm=max_norm, total_steps=total_steps, world_size=self.world)
         self.feature_dtype = feature_dtype
+
+    # ---- encoder checkpoint in the reference's dict format (MAIN:823-829 save, MAIN:483-499 resume) -------------------------
+    def checkpoint(self, epoch=0, iteration=None, losses=()):
+        import numpy as np
+        return {"epoch": epoch, "iteration": self.opt.t if iteration is None else iteration,
+                "state_dict": {k: v.detach().cpu().clone() for k, v in self.module.state_dict().items()},
+                "optimizer": self.opt.state_dict(self.module), "scheduler": self.opt.scheduler_state_dict(),
+                "loss_pretrain": np.array(list(losses))}
+
+    def save_checkpoint(self, path, **kw):
+        """rank 0 writes (MAIN:823: main_process only); every rank holds identical state after the all-reduce"""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
+            torch.save(self.checkpoint(**kw), path)
+
+    def load_checkpoint(self, ckpt):
+        """ckpt: path or dict.  Same tolerance as MAIN:487-495: keys present in both are loaded, the rest keep their values.
+        Returns (epoch, iteration, losses)."""
+        if not isinstance(ckpt, dict):
+            ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+        own = self.module.state_dict()
+        with torch.no_grad():
+            for k, v in ckpt["state_dict"].items():
+                if k in own:
+                    own[k].copy_(v)        # in place: the parameters stay views of the flat buffer
+        if "optimizer" in ckpt:
+            self.opt.load_state_dict(ckpt["optimizer"], self.module)
+        if "scheduler" in ckpt:
+            self.opt.load_scheduler_state_dict(ckpt["scheduler"])
+        self.engine._key = None
+        losses = ckpt.get("loss_pretrain", [])
+        return ckpt.get("epoch", 0), ckpt.get("iteration", self.opt.t), (losses.tolist() if hasattr(losses, "tolist") else list(losses))
 
     def step(self, img, loss_and_grads):
         """loss_and_grads(feats) -> (loss, [dfeat or None] * 4).  Returns the (local) loss tensor."""

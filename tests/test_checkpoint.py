@@ -1,0 +1,108 @@
+"""CPU: checkpoint / resume in the reference's formats (main_pretrain.py:483-499 resume, :823-829 save) and the parameter
+groups of LayerDecayOptimizerConstructor_ViT (mmcv_custom/layer_decay_optimizer_constructor_vit.py:33-67)."""
+import numpy as np
+import pytest
+import torch
+
+import mtp_amd
+from mtp_amd.parallel import DataParallelTrainer, FlatAdamW, FlatParams, reference_param_groups
+
+
+def small():
+    torch.manual_seed(0)
+    return mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
+
+
+def torch_adamw_like_reference(net, lr=6e-5, wd=0.05):
+    """what build_optim_wrapper(model, LayerDecayOptimizerConstructor_ViT) hands to torch.optim.AdamW for the backbone"""
+    P = dict(net.named_parameters())
+    groups = [{"params": [P[n] for n in names], "weight_decay": gwd, "lr": lr * scale, "param_names": names, "lr_scale": scale, "group_name": g}
+              for g, scale, gwd, names in reference_param_groups(net.named_parameters(), wd)]
+    return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), weight_decay=wd)
+
+
+def test_param_groups_follow_the_reference_rule():
+    net = small()
+    groups = reference_param_groups(net.named_parameters(), 0.05)
+    # "encoder.*" never matches get_num_layer_for_vit's "backbone.*" tests: every parameter gets layer id num_layers - 1 = depth + 1,
+    # lr_scale 0.9 ** 0 = 1, so exactly two groups, in first-seen order (pos_embed comes first -> no_decay first)
+    assert [g[0] for g in groups] == ["layer_7_no_decay", "layer_7_decay"] and all(g[1] == 1.0 for g in groups)
+    nd, d = set(groups[0][3]), set(groups[1][3])
+    assert groups[0][2] == 0.0 and groups[1][2] == 0.05
+    assert "pos_embed" in nd and "blocks.0.norm1.weight" in nd and "blocks.0.attn.qkv.bias" in nd and "blocks.0.attn.sampling_offsets.2.bias" in nd
+    assert "blocks.0.attn.qkv.weight" in d and "blocks.0.attn.rel_pos_h" in d and "blocks.0.attn.relative_position_bias_table" in d
+    assert "patch_embed.proj.weight" in d and "fpn1.0.weight" in d
+    assert nd | d == {n for n, _ in net.named_parameters()} and not (nd & d)
+    # the flat optimizer's per-segment weight decay is the same rule
+    flat = FlatParams(net, unused=net._unused_params)
+    starts, wds = flat.weight_decay_segments(0.05)
+    for n, wd in zip(flat.names, wds.tolist()):
+        assert (wd == 0.0) == (n in nd), n
+
+
+def test_optimizer_state_round_trips_with_torch_adamw():
+    net = small()
+    flat = FlatParams(net, unused=net._unused_params)
+    opt = FlatAdamW(flat, total_steps=100)
+    g = torch.Generator().manual_seed(1)
+    opt.m.copy_(torch.randn(opt.m.shape, generator=g))
+    opt.v.copy_(torch.rand(opt.v.shape, generator=g))
+    opt.t = 7
+    sd = opt.state_dict(net)
+    ref = torch_adamw_like_reference(net)
+    ref.load_state_dict(sd)                                   # torch validates group sizes / ids
+    P = dict(net.named_parameters())
+    for n in ("blocks.2.attn.qkv.weight", "pos_embed", "fpn1.0.bias", "blocks.5.mlp.fc2.bias"):
+        st = ref.state[P[n]]
+        assert torch.equal(st["exp_avg"], flat.view(opt.m, n)) and torch.equal(st["exp_avg_sq"], flat.view(opt.v, n)) and float(st["step"]) == 7
+    assert P["norm.weight"] not in ref.state                  # never gets a gradient (VIT:638): no state, as in torch
+    assert sd["param_groups"][0]["lr"] == pytest.approx(opt.lr_at(7)) and sd["param_groups"][1]["weight_decay"] == 0.05
+    # and back: a state dict produced by torch's AdamW loads into the flat optimizer
+    opt2 = FlatAdamW(FlatParams(small(), unused=net._unused_params), total_steps=100)
+    opt2.load_state_dict(ref.state_dict(), net)
+    used = torch.zeros_like(opt.m, dtype=torch.bool)
+    for n in flat.names:
+        if flat.groups[n] is not None:
+            flat.view(used, n).fill_(True)
+    assert opt2.t == 7 and torch.equal(opt2.m[used], opt.m[used]) and torch.equal(opt2.v[used], opt.v[used])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(ref, 100, eta_min=0, last_epoch=-1)
+    ssd = opt.scheduler_state_dict()
+    assert set(ssd) >= {"T_max", "eta_min", "base_lrs", "last_epoch"}
+    sched.load_state_dict(ssd)
+    assert sched.last_epoch == 7 and sched.get_last_lr()[0] == pytest.approx(opt.lr_at(7))
+
+
+def test_trainer_checkpoint_in_reference_format(tmp_path):
+    net = small()
+    tr = DataParallelTrainer(net, total_steps=50)
+    tr.opt.t = 3
+    tr.opt.m.fill_(0.25)
+    tr.opt.v.fill_(0.5)
+    path = tmp_path / "Iter_3_vit_l_rvsa_pretrn_model_encoder.pth"
+    tr.save_checkpoint(str(path), epoch=1, losses=[1.0, 0.5])
+    ck = torch.load(str(path), map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "iteration", "state_dict", "optimizer", "scheduler", "loss_pretrain"}      # MAIN:826
+    assert list(ck["state_dict"]) == list(small().state_dict()) and isinstance(ck["loss_pretrain"], np.ndarray) and ck["iteration"] == 3
+    # resume into a fresh trainer (MAIN:483-499): weights, moments, step counter, schedule
+    net2 = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
+    with torch.no_grad():
+        for p in net2.parameters():
+            p.add_(1.0)
+    tr2 = DataParallelTrainer(net2, total_steps=10)
+    ck["state_dict"]["decoder.not_ours.weight"] = torch.zeros(3)       # foreign keys are skipped like MAIN:490-492
+    epoch, it, losses = tr2.load_checkpoint(ck)
+    assert (epoch, it, losses) == (1, 3, [1.0, 0.5]) and tr2.opt.t == 3 and tr2.opt.total_steps == 50
+    for (n, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), n
+    assert net2.pos_embed.data_ptr() == tr2.flat.view(tr2.flat.data, "pos_embed").data_ptr()     # still views of the flat buffer
+    n = "blocks.1.mlp.fc1.weight"
+    assert float(tr2.flat.view(tr2.opt.m, n).mean()) == 0.25 and float(tr2.flat.view(tr2.opt.v, n).mean()) == 0.5
+    # ckpt['state_dict'] is the encoder's own state dict: loads strictly into a fresh backbone.  (The pretrain-side
+    # init_weights(), VIT:744-768, always strips one cls token from pos_embed -- it is written for MAE checkpoints -- so, as in
+    # the reference, it is not the way to resume from these files.)
+    net3 = small()
+    with torch.no_grad():
+        net3.pos_embed.zero_()
+    assert not any(net3.load_state_dict(ck["state_dict"] if "decoder.not_ours.weight" not in ck["state_dict"] else
+                                        {k: v for k, v in ck["state_dict"].items() if k != "decoder.not_ours.weight"}, strict=True))
+    assert torch.equal(net3.pos_embed, net.pos_embed)
