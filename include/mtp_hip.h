@@ -97,6 +97,13 @@ int mtp_colsum_acc(const void* dY, int dtype, int64_t ld, float* out, int64_t M,
 /* PatchEmbed im2col (VIT:529,536-539): img f32 NCHW -> cols (B*Hp*Wp, Cin*P*P) ACT, K order (c, ky, kx). */
 int mtp_patchify(const float* img, void* cols, int dtype, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, mtp_stream_t stream);
 int mtp_unpatchify(const void* cols, int dtype, float* dimg, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, mtp_stream_t stream);
+/* Image side of MTP_DataPreprocessor (Multi-Task_Pretrain/preprocessing.py:145-148 -> mmengine ImgDataPreprocessor.forward:
+ * channel flip, .float(), (x - mean) / std, pad bottom/right with pad_value to a multiple of pad_size_divisor; configured at
+ * models.py:37-41) fused with the PatchEmbed im2col: img (B, H, W, 3) uint8 HWC -> cols (B*Hp*Wp, 3*P*P) ACT, K order
+ * (c, ky, kx), Hp = ceil(H / pad_divisor) * pad_divisor / P (likewise Wp).  mean / std: 3 HOST floats each, indexed by the
+ * OUTPUT channel (i.e. after the flip). */
+int mtp_preprocess_patchify(const uint8_t* img, void* cols, int dtype, int64_t B, int64_t H, int64_t W, int64_t P, int64_t pad_divisor,
+                            const float* mean, const float* std, int bgr_to_rgb, float pad_value, mtp_stream_t stream);
 int mtp_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, mtp_stream_t stream);
 /* dst (C, R) = src (R, C)^T with dtype conversion (weight copies for dgrad) */
 int mtp_transpose_cast(const float* src, void* dst, int dst_dtype, int64_t R, int64_t C, mtp_stream_t stream);

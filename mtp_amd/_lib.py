@@ -42,6 +42,7 @@ SIGNATURES = {
     "mtp_colsum": (i32, [p, i32, i64, p, i64, i64, p]),
     "mtp_colsum_acc": (i32, [p, i32, i64, p, i64, i64, p]),
     "mtp_patchify": (i32, [p, p, i32, i64, i64, i64, i64, i64, p]),
+    "mtp_preprocess_patchify": (i32, [p, p, i32, i64, i64, i64, i64, i64, C.POINTER(f32), C.POINTER(f32), i32, f32, p]),
     "mtp_unpatchify": (i32, [p, i32, p, i64, i64, i64, i64, i64, p]),
     "mtp_cast": (i32, [p, i32, p, i32, i64, p]),
     "mtp_transpose_cast": (i32, [p, p, i32, i64, i64, p]),

@@ -223,6 +223,7 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
         self.precision = precision
         self.feature_dtype = feature_dtype
         self._eng = None
+        self.data_preprocessor = None
         self._param_names = [n for n, _ in self.named_parameters()]
         self._unused_params = {"norm.weight", "norm.bias"}
         last = max(out_indices)
@@ -301,6 +302,16 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
         assert precision in ("bf16", "fp32")
         self.precision = precision
         self._eng = None
+        return self
+
+    def set_data_preprocessor(self, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), bgr_to_rgb=True,
+                              pad_size_divisor=32, pad_value=0.0):
+        """Optional input side: with this set, forward_features also accepts the raw (B, H, W, 3) uint8 batch
+        and applies MTP_DataPreprocessor's image path (defaults = its configuration at Multi-Task_Pretrain/models.py:37-41:
+        BGR->RGB, (x - mean) / std, pad bottom/right to a multiple of 32) inside the patch-embed im2col kernel."""
+        assert len(mean) == 3 and len(std) == 3 and all(float(s) != 0.0 for s in std)
+        self.data_preprocessor = dict(mean=tuple(float(v) for v in mean), std=tuple(float(v) for v in std), bgr_to_rgb=bool(bgr_to_rgb),
+                                      pad_size_divisor=int(pad_size_divisor), pad_value=float(pad_value))
         return self
 
     def _engine(self):

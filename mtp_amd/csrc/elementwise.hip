@@ -488,6 +488,69 @@ extern "C" int mtp_patchify(const float* img, void* cols, int dtype, int64_t B, 
     return mtp_launch_status();
 }
 
+// ---- uint8 HWC image -> normalised patch rows (data preprocessor + im2col in one pass over 1 byte per sample) ------------------
+// thread = 4 consecutive pixels of one patch row: 12 input bytes (three aligned dwords when W % 4 == 0), three 4-element
+// stores (one per output channel plane of the patch row).  IEEE division, so the f32 result is bit-equal to (x - mean) / std.
+struct PreNorm {
+    float mean[3], std[3];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_patchify_kernel(const uint8_t* __restrict__ img, T* __restrict__ cols, int B, int H, int W, int P, int Hp, int Wp,
+                                                                 PreNorm nm, int flip, float pad_value) {
+    const int P4 = P / 4, K = 3 * P * P;
+    const int64_t total = (int64_t)B * Hp * Wp * P * P4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x4 = (int)(i % P4), ky = (int)((i / P4) % P);
+        const int64_t t = i / ((int64_t)P4 * P);
+        const int px = (int)(t % Wp), py = (int)((t / Wp) % Hp), b = (int)(t / ((int64_t)Wp * Hp));
+        const int y = py * P + ky, x0 = px * P + 4 * x4;
+        float v[3][4];
+        if (y < H && x0 + 3 < W && (W & 3) == 0) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(img + (((int64_t)b * H + y) * W + x0) * 3);
+            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+            const uint32_t byte[12] = {w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 & 255u, (w1 >> 8) & 255u, (w1 >> 16) & 255u, w1 >> 24,
+                                       w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c][j] = ((float)byte[3 * j + (flip ? 2 - c : c)] - nm.mean[c]) / nm.std[c];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = y < H && x0 + j < W;
+                const uint8_t* p = img + (((int64_t)b * H + (in ? y : 0)) * W + (in ? x0 + j : 0)) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c][j] = in ? ((float)p[flip ? 2 - c : c] - nm.mean[c]) / nm.std[c] : pad_value;
+            }
+        }
+        T* cp = cols + t * K + ky * P + 4 * x4;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) store4(cp + c * P * P, make_float4(v[c][0], v[c][1], v[c][2], v[c][3]));
+    }
+}
+
+extern "C" int mtp_preprocess_patchify(const uint8_t* img, void* cols, int dtype, int64_t B, int64_t H, int64_t W, int64_t P, int64_t pad_divisor,
+                                       const float* mean, const float* std, int bgr_to_rgb, float pad_value, mtp_stream_t stream) {
+    if (!img || !cols || !mean || !std || B <= 0 || H <= 0 || W <= 0 || P <= 0 || (P % 4) || pad_divisor <= 0) return MTP_ERR_ARG;
+    const int64_t Hpad = (H + pad_divisor - 1) / pad_divisor * pad_divisor, Wpad = (W + pad_divisor - 1) / pad_divisor * pad_divisor;
+    if ((Hpad % P) || (Wpad % P)) return MTP_ERR_ARG;
+    PreNorm nm;
+    for (int c = 0; c < 3; ++c) {
+        if (std[c] == 0.f) return MTP_ERR_ARG;
+        nm.mean[c] = mean[c];
+        nm.std[c] = std[c];
+    }
+    const int Hp = (int)(Hpad / P), Wp = (int)(Wpad / P);
+    const int64_t total = B * Hp * Wp * P * (P / 4);
+    dim3 grid(blocks_for(total, 256, 8192)), block(256);
+    if (dtype == MTP_BF16)
+        hipLaunchKernelGGL((preprocess_patchify_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, img, (bf16_t*)cols, (int)B, (int)H, (int)W, (int)P, Hp, Wp, nm, bgr_to_rgb, pad_value);
+    else if (dtype == MTP_F32)
+        hipLaunchKernelGGL((preprocess_patchify_kernel<float>), grid, block, 0, (hipStream_t)stream, img, (float*)cols, (int)B, (int)H, (int)W, (int)P, Hp, Wp, nm, bgr_to_rgb, pad_value);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
 extern "C" int mtp_unpatchify(const void* cols, int dtype, float* dimg, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, mtp_stream_t stream) {
     if (!dimg || !cols || B <= 0 || (P % 4) || (W % 4) || H < P || W < P) return MTP_ERR_ARG;
     const int Hp = (int)(H / P), Wp = (int)(W / P);

@@ -229,16 +229,29 @@ class BackboneEngine:
         self.prepare_weights()
         self.P = P = {k: v.detach() for k, v in self.params().items()}
         C, act = self.C, self.act
-        B, Cin, H, W = img.shape
         ps = m.patch_size
-        Hp, Wp = H // ps, W // ps
-        N, T = Hp * Wp, B * Hp * Wp
         fdt = feature_dtype or act
-        img = img.contiguous()
-        if img.dtype != F32:
-            img = img.float()
-        # ---- patch embed (+ abs pos embed fused as the "residual" of the GEMM epilogue; VIT:536-539, 793-794)
-        cols = ops.patchify(img, self._e(T, Cin * ps * ps), ps)
+        if img.dtype == torch.uint8:
+            # raw (B,H,W,3) uint8 batch: MTP_DataPreprocessor's normalise / flip / pad (preprocessing.py:145-148, MODELS:37-41)
+            # fused with the im2col -- the f32 NCHW image is never materialised
+            pp = getattr(m, "data_preprocessor", None)
+            if pp is None:
+                raise ValueError("uint8 input needs ViT_Win_RVSA_V3_WSZ7.set_data_preprocessor(mean, std, ...)")
+            B, H, W, Cin = img.shape
+            Hp, Wp = ops.padded_grid(H, W, ps, pp["pad_size_divisor"])
+            N, T = Hp * Wp, B * Hp * Wp
+            cols = ops.preprocess_patchify(img.contiguous(), self._e(T, Cin * ps * ps), ps, pp["mean"], pp["std"], pp["bgr_to_rgb"],
+                                           pp["pad_size_divisor"], pp["pad_value"])
+            H, W = Hp * ps, Wp * ps
+        else:
+            B, Cin, H, W = img.shape
+            Hp, Wp = H // ps, W // ps
+            N, T = Hp * Wp, B * Hp * Wp
+            img = img.contiguous()
+            if img.dtype != F32:
+                img = img.float()
+            # ---- patch embed (+ abs pos embed fused as the "residual" of the GEMM epilogue; VIT:536-539, 793-794)
+            cols = ops.patchify(img, self._e(T, Cin * ps * ps), ps)
         pos = P.get("pos_embed")
         if pos is not None:
             assert pos.shape[1] == N, "pos_embed does not match the input size"

@@ -160,6 +160,28 @@ def patchify(img, cols, P=16):
     return cols
 
 
+def preprocess_patchify(img_u8, cols, P, mean, std, bgr_to_rgb=True, pad_divisor=32, pad_value=0.0):
+    """uint8 (B,H,W,3) HWC image batch -> normalised patch rows `cols` (B*Hp*Wp, 3*P*P): MTP_DataPreprocessor's image
+    path (channel flip, (x - mean) / std, pad to a multiple of pad_divisor) fused with the PatchEmbed im2col."""
+    if not img_u8.is_cuda:
+        raise RuntimeError("mtp_amd ops run only on an MI355X device tensor (no CPU fallback)")
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[-1] == 3 and img_u8.is_contiguous()
+    B, H, W, _ = img_u8.shape
+    Hp, Wp = padded_grid(H, W, P, pad_divisor)
+    assert tuple(cols.shape) == (B * Hp * Wp, 3 * P * P)
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    check(lib().mtp_preprocess_patchify(img_u8.data_ptr(), _p(cols), _dt(cols), B, H, W, P, pad_divisor, m3, s3, int(bool(bgr_to_rgb)),
+                                        float(pad_value), _s()), "mtp_preprocess_patchify")
+    return cols
+
+
+def padded_grid(H, W, P, pad_divisor):
+    """patch grid (Hp, Wp) of an H x W image padded bottom/right to a multiple of pad_divisor"""
+    Hpad, Wpad = -(-H // pad_divisor) * pad_divisor, -(-W // pad_divisor) * pad_divisor
+    assert Hpad % P == 0 and Wpad % P == 0
+    return Hpad // P, Wpad // P
+
+
 def unpatchify(cols, dimg, P=16):
     B, Cin, H, W = dimg.shape
     check(lib().mtp_unpatchify(_p(cols), _dt(cols), _f32(dimg), B, Cin, H, W, P, _s()), "mtp_unpatchify")

@@ -32,6 +32,25 @@ WS = 7                  # VIT:629
 
 
 # ----------------------------------------------------------------------------- patch embed
+def preprocess(img_u8, mean, std, bgr_to_rgb=True, pad_size_divisor=32, pad_value=0.0):
+    """Image path of MTP_DataPreprocessor.forward (Multi-Task_Pretrain/preprocessing.py:145-148 -> `super().forward`), as
+    configured at models.py:37-41 (mean [123.675, 116.28, 103.53], std [58.395, 57.12, 57.375], bgr_to_rgb, divisor 32).
+    PARITY UNPINNED: the arithmetic lives in mmengine's ImgDataPreprocessor (mmengine is not vendored in the reference and
+    not installed here), restated from its published algorithm: per image `x[[2, 1, 0]]` when bgr_to_rgb, `.float()`,
+    `(x - mean) / std` with mean/std viewed (3,1,1), then `stack_batch`: pad bottom/right with pad_value up to a multiple
+    of pad_size_divisor.  img_u8: (B, H, W, 3) uint8 HWC  ->  (B, 3, Hpad, Wpad) f32."""
+    x = img_u8.permute(0, 3, 1, 2)
+    if bgr_to_rgb:
+        x = x[:, [2, 1, 0]]
+    x = x.float()
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    x = (x - m) / s
+    H, W = x.shape[-2:]
+    Hpad, Wpad = -(-H // pad_size_divisor) * pad_size_divisor, -(-W // pad_size_divisor) * pad_size_divisor
+    return torch.nn.functional.pad(x, (0, Wpad - W, 0, Hpad - H), value=pad_value)
+
+
 def patchify(img, P=16):
     """VIT:529,536-539 -- (B,3,H,W) -> (B*Hp*Wp, 3*P*P), K order (c, ky, kx)."""
     B, Cin, H, W = img.shape

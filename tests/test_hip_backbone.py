@@ -183,3 +183,26 @@ def test_full_size_roundtrip_properties_vit_l_shapes():
     assert rel_err(ya[idx].cpu(), ref) < 1e-4
     f = ops.tokens_to_nchw(a, torch.empty(64, C, 14, 14, device="cuda", dtype=torch.bfloat16), 64, 14, 14, 0)
     assert torch.equal(ops.nchw_to_tokens(f, torch.empty_like(a), 64, 14, 14, 0), a)
+
+
+def test_uint8_input_through_fused_preprocessor_equals_preprocessed_f32_input():
+    """raw (B,H,W,3) uint8 batch -> same feature maps as feeding the oracle-preprocessed f32 NCHW batch (the
+    patch rows are bit-identical, so everything downstream is too); 200x150 is padded to 224x160 like MTP_DataPreprocessor does."""
+    net = build(128, 4, 2, 2, [0, 1, 2, 3], "fp32").eval()
+    net.set_data_preprocessor()          # models.py:37-41 defaults
+    for H, W in ((224, 224), (200, 150)):
+        Hp, Wp = -(-H // 32) * 2, -(-W // 32) * 2
+        g = torch.Generator().manual_seed(H)
+        raw = torch.randint(0, 256, (2, H, W, 3), generator=g, dtype=torch.uint8)
+        pp = net.data_preprocessor
+        x = O.preprocess(raw, pp["mean"], pp["std"], pp["bgr_to_rgb"], pp["pad_size_divisor"], pp["pad_value"])
+        with torch.no_grad():
+            net.pos_embed.data = torch.randn(1, Hp * Wp, 128, generator=torch.Generator().manual_seed(1)).cuda() * 0.02
+            a = net(raw.cuda())
+            b = net(x.cuda())
+        assert a[2].shape == (2, 128, Hp, Wp)
+        for fa, fb in zip(a, b):
+            assert torch.equal(fa, fb)
+    net.data_preprocessor = None
+    with pytest.raises(ValueError):
+        net(raw.cuda())

@@ -201,6 +201,24 @@ def test_patchify_roundtrip(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("H,W,flip", [(224, 224, True), (200, 150, True), (64, 96, False), (33, 31, True)])
+def test_preprocess_patchify_uint8(ops, dtype, H, W, flip):
+    """uint8 HWC batch -> normalised patch rows in one kernel == oracle.preprocess (MTP_DataPreprocessor's image path: flip,
+    (x - mean) / std, pad bottom/right to a multiple of 32) followed by oracle.patchify; exact in f32, exact after rounding in bf16"""
+    mean, std = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    img = torch.randint(0, 256, (3, H, W, 3), generator=g, dtype=torch.uint8)
+    ref_img = O.preprocess(img, mean, std, bgr_to_rgb=flip, pad_size_divisor=32, pad_value=0.0)
+    ref, (Hp, Wp) = O.patchify(ref_img)
+    assert (Hp, Wp) == ops.padded_grid(H, W, 16, 32)
+    cols = ops.preprocess_patchify(img.cuda(), e(3 * Hp * Wp, 768, dtype=dtype), 16, mean, std, bgr_to_rgb=flip, pad_divisor=32, pad_value=0.0)
+    assert torch.equal(cols.cpu(), ref.to(dtype))
+    cols = ops.preprocess_patchify(img.cuda(), e(3 * Hp * Wp, 768, dtype=dtype), 16, mean, std, bgr_to_rgb=flip, pad_divisor=32, pad_value=-1.5)
+    ref2, _ = O.patchify(O.preprocess(img, mean, std, bgr_to_rgb=flip, pad_size_divisor=32, pad_value=-1.5))
+    assert torch.equal(cols.cpu(), ref2.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("L", [0, 1, 2])
 def test_tokens_nchw_roundtrip(ops, dtype, L):
     B, Hp, Wp, C = 2, 14, 14, 128

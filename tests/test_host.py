@@ -123,6 +123,26 @@ def test_recipe_params_load_strictly():
     assert not msg.unexpected_keys and all(k.endswith("relative_position_index") for k in msg.missing_keys)
 
 
+def test_data_preprocessor_restatement_and_config():
+    """oracle.preprocess (the unpinned restatement of mmengine's ImgDataPreprocessor as MTP configures it, models.py:37-41):
+    channel flip, (x - mean) / std, zero padding bottom/right AFTER normalisation, to a multiple of 32."""
+    from mtp_amd import ops
+    from oracle import vit_rvsa_oracle as O
+    img = torch.zeros(1, 33, 40, 3, dtype=torch.uint8)
+    img[0, 0, 0] = torch.tensor([10, 20, 30], dtype=torch.uint8)        # B, G, R
+    mean, std = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+    x = O.preprocess(img, mean, std)
+    assert x.shape == (1, 3, 64, 64) and ops.padded_grid(33, 40, 16, 32) == (4, 4)
+    assert x[0, :, 0, 0].tolist() == pytest.approx([(30 - 123.675) / 58.395, (20 - 116.28) / 57.12, (10 - 103.53) / 57.375], rel=1e-6)
+    assert float(x[0, 0, 1, 1]) == pytest.approx(-123.675 / 58.395, rel=1e-6)      # a real black pixel is NOT zero after normalisation
+    assert torch.all(x[0, :, 33:, :] == 0) and torch.all(x[0, :, :, 40:] == 0)    # ... the padding is
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=3, num_heads=2, interval=3, out_indices=[0, 1, 2, 2])
+    assert net.data_preprocessor is None
+    net.set_data_preprocessor()
+    assert net.data_preprocessor == dict(mean=mean, std=std, bgr_to_rgb=True, pad_size_divisor=32, pad_value=0.0)
+    assert "data_preprocessor" not in net.state_dict()
+
+
 def test_no_cpu_fallback():
     net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=3, num_heads=2, interval=3, out_indices=[0, 1, 2, 2])
     with pytest.raises(RuntimeError, match="no CPU"):
