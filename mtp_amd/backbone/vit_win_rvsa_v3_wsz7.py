@@ -250,7 +250,14 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
         """VIT:693-778 (and the no-argument form of the fine-tune copies, vit_rvsa_mtp.py:684): load a checkpoint given
         as `state_dict` / `model` / raw mapping, strip `module.`, keep `encoder.*`, drop `patch_embed.proj` when
         in_chans != 3, bicubic-resize `pos_embed` assuming one extra (cls) token."""
-        pretrained = pretrained or self.pretrained
+        return self._load_pretrained(pretrained or self.pretrained, finetune=False)
+
+    def _load_pretrained(self, pretrained, finetune):
+        """finetune=True: the loader shared by all nine fine-tune copies (e.g. RS_Tasks_Finetune/Semantic_Segmentation/mmseg/
+        models/backbones/vit_rvsa_mtp.py:684-805), which differs from the pretrain-side one (VIT:693-778) in three places:
+        `patch_embed.proj` is kept whatever in_chans is (:727-733 commented out); the `full_attn_rel_pos_h/w` tables are
+        bicubically resized to this model's (2*Hp-1, head_dim) (:735-765); one extra token is stripped from `pos_embed`
+        only when the checkpoint has a `cls_token` key (:775-778)."""
         if isinstance(pretrained, str):
             self.apply(self._init_weights)
             # weights_only=False as the reference's torch.load (VIT:711) effectively was: its own checkpoints carry a numpy
@@ -266,15 +273,24 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
                 state_dict = {k[7:]: v for k, v in state_dict.items()}
             if sorted(list(state_dict.keys()))[0].startswith("encoder"):
                 state_dict = {k.replace("encoder.", ""): v for k, v in state_dict.items() if k.startswith("encoder.")}
-            if self.in_chans != 3:
+            if self.in_chans != 3 and not finetune:
                 for k in list(state_dict.keys()):
                     if "patch_embed.proj" in k:
                         del state_dict[k]
+            if finetune:
+                own = next((p for n, p in self.named_parameters() if "attn.full_attn_rel_pos_h" in n), None)
+                if own is not None:
+                    for k in list(state_dict.keys()):
+                        if "full_attn_rel_pos_h" in k or "full_attn_rel_pos_w" in k:
+                            old = state_dict[k]
+                            new = torch.nn.functional.interpolate(old.reshape(1, 1, old.shape[0], old.shape[1]), size=tuple(own.shape),
+                                                                  mode="bicubic", align_corners=False)
+                            state_dict[k] = new.squeeze()
             if "pos_embed" in state_dict:
                 pe = state_dict["pos_embed"]
                 emb = pe.shape[-1]
                 H, W = self.patch_embed.patch_shape
-                extra = 1
+                extra = (1 if "cls_token" in state_dict else 0) if finetune else 1
                 orig = int((pe.shape[-2] - extra) ** 0.5)
                 new = int(self.patch_embed.num_patches ** 0.5)
                 if orig != new:
@@ -361,6 +377,10 @@ class RVSA_MTP_branches(ViT_Win_RVSA_V3_WSZ7):
 
     def forward(self, x):
         return tuple(self.forward_features(x))
+
+    def init_weights(self, pretrained=None):
+        """no-argument form of the fine-tune copies (uses `self.pretrained`, vit_rvsa_mtp.py:684-691) with their loader rules"""
+        return self._load_pretrained(pretrained or self.pretrained, finetune=True)
 
 
 class RVSA_MTP(RVSA_MTP_branches):

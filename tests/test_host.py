@@ -117,6 +117,56 @@ def test_init_weights_checkpoint_contract(tmp_path):
         dst.init_weights(123)
 
 
+def test_finetune_loader_rules(tmp_path):
+    """`RVSA_MTP.init_weights()` = the loader of all nine fine-tune copies (…/mmseg/models/backbones/vit_rvsa_mtp.py:684-805):
+    no argument; a 224 MTP encoder checkpoint (no cls token, 27-row rel-pos tables) loads into a 448 model with bicubic
+    resizes of pos_embed AND full_attn_rel_pos_h/w; a cls token is stripped only when the checkpoint has a `cls_token` key;
+    patch_embed.proj is kept for in_chans != 3."""
+    import torch.nn.functional as F
+    kw = dict(embed_dim=128, depth=3, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[0, 1, 2, 2])
+    src = mtp_amd.RVSA_MTP(img_size=224, **kw)
+    with torch.no_grad():
+        for n, p in src.named_parameters():
+            if "rel_pos" in n or n == "pos_embed":
+                p.normal_(0, 0.02)
+    path = str(tmp_path / "enc.pth")
+    torch.save({"state_dict": {"encoder." + k: v.clone() for k, v in src.state_dict().items()}}, path)
+    big = mtp_amd.RVSA_MTP(img_size=448, pretrained=path, **kw)
+    msg = big.init_weights()
+    assert not msg.missing_keys and not msg.unexpected_keys
+    a, b = src.blocks[2].attn, big.blocks[2].attn                      # block 2 is the full-attention block (interval 3)
+    assert a.full_attn_rel_pos_h.shape == (27, 64) and b.full_attn_rel_pos_h.shape == (55, 64)
+    for name in ("full_attn_rel_pos_h", "full_attn_rel_pos_w"):
+        ref = F.interpolate(getattr(a, name).detach().reshape(1, 1, 27, 64), size=(55, 64), mode="bicubic", align_corners=False).squeeze()
+        assert torch.equal(getattr(b, name).detach(), ref)
+    ref = F.interpolate(src.pos_embed.detach().reshape(1, 14, 14, 128).permute(0, 3, 1, 2), size=(28, 28), mode="bicubic", align_corners=False)
+    assert torch.equal(big.pos_embed.detach(), ref.permute(0, 2, 3, 1).flatten(1, 2))
+    assert torch.equal(big.blocks[0].attn.rel_pos_h, src.blocks[0].attn.rel_pos_h)       # window tables (13 rows) are size-independent
+    # MAE-style checkpoint: cls_token present -> one extra pos_embed token is dropped
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    sd["cls_token"] = torch.zeros(1, 1, 128)
+    sd["pos_embed"] = torch.cat([torch.full((1, 1, 128), 9.0), src.pos_embed.detach()], 1)
+    path2 = str(tmp_path / "mae.pth")
+    torch.save({"model": sd}, path2)
+    same = mtp_amd.RVSA_MTP_branches(img_size=224, pretrained=path2, **kw)
+    msg = same.init_weights()
+    assert msg.unexpected_keys == ["cls_token"] and torch.equal(same.pos_embed, src.pos_embed)
+    # in_chans != 3: the fine-tune copies keep patch_embed.proj (the pretrain-side loader deletes it, VIT:731-734)
+    src4 = mtp_amd.RVSA_MTP(img_size=224, in_chans=4, **kw)
+    path3 = str(tmp_path / "c4.pth")
+    torch.save(src4.state_dict(), path3)
+    dst4 = mtp_amd.RVSA_MTP(img_size=224, in_chans=4, pretrained=path3, **kw)
+    dst4.init_weights()
+    assert torch.equal(dst4.patch_embed.proj.weight, src4.patch_embed.proj.weight)
+    pre4 = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=224, in_chans=4, **kw)
+    w0 = pre4.patch_embed.proj.weight.detach().clone()
+    sd4 = {k: v for k, v in src4.state_dict().items()}
+    sd4["pos_embed"] = torch.cat([torch.zeros(1, 1, 128), sd4["pos_embed"]], 1)
+    torch.save(sd4, path3)
+    msg = pre4.init_weights(path3)
+    assert "patch_embed.proj.weight" in msg.missing_keys and not torch.equal(pre4.patch_embed.proj.weight, src4.patch_embed.proj.weight)
+
+
 def test_recipe_params_load_strictly():
     net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
     msg = net.load_state_dict(recipe.make_params(recipe.state_shapes(128, 6, 2, 3)), strict=False)
