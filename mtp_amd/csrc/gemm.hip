@@ -555,7 +555,10 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    // an XCD owns a contiguous tile range and streams, per split, its share of one operand but ALL panels of the other one:
+    // walk the tiles so that the replicated operand is the smaller one (order bit 1: M fastest, for N > M, e.g. dW of fc2)
+    const int tiles_m = (int)gridDim.x / p.tiles_n;
+    const int m0 = ((p.order & 2) ? tile % tiles_m : tile / p.tiles_n) * BM, n0 = ((p.order & 2) ? tile / tiles_m : tile % p.tiles_n) * BN;
     const int kt0 = blockIdx.y * p.k_tiles_per_split;
     int kt1 = kt0 + p.k_tiles_per_split;
     kt1 = kt1 < p.k_tiles ? kt1 : p.k_tiles;
@@ -698,6 +701,8 @@ int launch_tn(const mtp_gemm_args* a, hipStream_t stream) {
     }
     if (tr) {
         k.colsum = a->colsum;
+        const int ord = (a->variant >> 1) & 3;   // 0 auto, 1 plain blockIdx, 2 M-fastest, 3 N-fastest
+        k.order = ord == 0 ? (a->N > a->M ? 2 : 0) : ord == 1 ? 1 : ord == 2 ? 2 : 0;
         hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, block, STAGE_BYTES, stream, k);
     } else if (full && (a->variant & 8))
         hipLaunchKernelGGL((gemm_tn_sb_kernel<T, true>), grid, block, STAGE_BYTES, stream, k);
