@@ -12,8 +12,11 @@
 //
 // NT  C[m][n] = sum_k A[m][k] B[n][k]   : both operands K-contiguous -> direct-to-LDS loads (global_load_lds x16B),
 //                                         swizzle applied on the per-lane SOURCE address (LDS image is lane-linear).
-// TN  C[m][n] = sum_k A[k][m] B[k][n]   : weight gradients; tiles are transposed in registers (ExE blocks) between the
-//                                         coalesced global loads and the ds_write_b128, split-K over gridDim.y.
+//                                         Default kernel: ONE 32 KiB stage, 4 workgroups per CU (gemm_nt_sb_kernel).
+// TN  C[m][n] = sum_k A[k][m] B[k][n]   : weight gradients, split-K over gridDim.y.  bf16 + complete tiles: both tiles go to
+//                                         LDS untransposed (LDS-DMA) and the fragments come out of ds_read_b64_tr_b16
+//                                         (gemm_tn_tr_kernel); f32 / ragged shapes: tiles are transposed in registers (ExE
+//                                         blocks) between the coalesced global loads and the ds_write_b128.
 #include "common.h"
 
 namespace {
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 // each) plus the fragment reads than the SIMDs spend on MFMAs.  Here both operand tiles go HBM -> LDS as they lie in memory
 // ([64 t rows][128 x] bf16 = 256-B rows, global_load_lds x16B, no VGPR/ds_write traffic) and the MFMA fragments come out of
 // ds_read_b64_tr_b16: a 16-lane group hands in the addresses of a [4 t][16 x] block (lane i: row i>>2, columns 4(i&3)..+3)
-// and lane i gets column i, rows 0..3 -- measured on gfx950 with tools/_abl/tr_probe.  Two reads = the 8 consecutive k of
+// and lane i gets column i, rows 0..3 -- measured on gfx950 with tools/tr_probe.hip.  Two reads = the 8 consecutive k of
 // one MFMA operand.  Swizzle: 32-B slot pair ^= f(t), f = (t&3) | (t>>3 & 1)<<2, so that the 8 rows a 32-lane group touches
 // ({0..3, 8..11} + const) fall on 8 different bank octets; applied on the per-lane SOURCE address of the DMA.
 typedef short tr_v4s __attribute__((ext_vector_type(4)));
