@@ -318,6 +318,63 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), one 48 KiB stage, 2 workgroups per CU: same occupancy and per-wave work as
+// the kernel above with 25 % fewer L2->LDS bytes per flop (A tile shared by 2 x more columns).  Selected for wide N only
+// (the tile count of N = 1024 problems would leave CUs idle).
+constexpr int NT8_THREADS = 512;
+constexpr int NT8_BM = 256;
+constexpr int NT8_STAGE_BYTES = NT8_BM * ROW_BYTES + OPER_BYTES;
+template <typename T, typename Tout, int EPI>
+__global__ __launch_bounds__(NT8_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_sb8_kernel(KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = Elem<T>::kPerChunk;
+    char* sA = smem;
+    char* sB = smem + NT8_BM * ROW_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    int m0, n0;
+    if (p.order & 2) {
+        const int tiles_m = (int)gridDim.x / p.tiles_n, per = 8 * p.tiles_n;
+        const int grp = tile / per, r = tile - grp * per;
+        const int gm = (tiles_m - grp * 8) < 8 ? (tiles_m - grp * 8) : 8;
+        m0 = (grp * 8 + r % gm) * NT8_BM;
+        n0 = (r / gm) * BN;
+    } else {
+        m0 = (tile / p.tiles_n) * NT8_BM;
+        n0 = (tile % p.tiles_n) * BN;
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < p.k_tiles; ++kt) {
+        const int k0 = kt * 8 * E;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // A: wave w fills rows [32w, 32w + 32)
+            const int rbase = wave * 32 + i * 8, row = rbase + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
+            int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+            const char* ga = p.A + ((int64_t)ra * p.lda + k0 + chunk * E) * (int64_t)sizeof(T);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                             (__attribute__((address_space(3))) void*)(sA + rbase * ROW_BYTES), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // B: wave w fills rows [16w, 16w + 16)
+            const int rbase = wave * 16 + i * 8, row = rbase + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
+            int rb = n0 + row; rb = rb < p.N ? rb : p.N - 1;
+            const char* gb = p.B + ((int64_t)rb * p.ldb + k0 + chunk * E) * (int64_t)sizeof(T);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                             (__attribute__((address_space(3))) void*)(sB + rbase * ROW_BYTES), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute_stage<T>(sA, sB, acc, wm, wn, lane);
+        __syncthreads();
+    }
+    epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
 // ---- TN staging: ExE register transposes ------------------------------------------------------------------------------
 // Operand source is (Kc, X) row-major, X = M or N contiguous.  Item = one ExE block (E k-rows x E x-columns):
 // kb = blk & 7 (LDS chunk column), xb = blk >> 3 (E-wide column group); lanes with consecutive xb read consecutive
@@ -655,6 +712,17 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     const int ord = (a->variant >> 1) & 3;
     k.order = ord == 0 ? (k.tiles_n > 8 ? 2 : 0) : ord == 1 ? 1 : ord == 2 ? 2 : 0;
     if (!(glds && !(a->variant & 8))) k.order = ord;   // the double-buffered kernels keep their own meaning of the bits
+    // 256 x 128 tile / 8 waves when the whole problem is ONE round of such workgroups on the 256 CUs (2 per CU) and every CU
+    // gets at least one: measured on M = 12544, N = 1024 (392 workgroups): +7.5 % (K = 1024), +17..18 % (K = 3072, 4096; up to
+    // 1095 TF/s); with several rounds (N = 3072: equal, N = 4096: -5 %) the coarser tiles lose to the tail.  Variant bit 5
+    // forces it, bit 6 forbids it.
+    const int tiles_m8 = (k.M + NT8_BM - 1) / NT8_BM;
+    const bool one_round = tiles_m8 * k.tiles_n >= 256 && tiles_m8 * k.tiles_n <= 512;
+    if (glds && !(a->variant & 8) && ((a->variant & 32) || (one_round && !(a->variant & 64)))) {
+        if (ord == 0) k.order = k.tiles_n > 8 ? 2 : 0;
+        hipLaunchKernelGGL((gemm_nt_sb8_kernel<T, Tout, EPI>), dim3(tiles_m8 * k.tiles_n), dim3(NT8_THREADS), NT8_STAGE_BYTES, stream, k);
+        return mtp_launch_status();
+    }
     if (glds && !(a->variant & 8))
         hipLaunchKernelGGL((gemm_nt_sb_kernel<T, Tout, EPI>), grid, block, STAGE_BYTES, stream, k);
     else if (glds)

@@ -10,6 +10,7 @@ from . import _lib
 from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, MTP_BF16, MTP_F32, GemmArgs, check  # noqa: F401
 
 _DT = {torch.float32: MTP_F32, torch.bfloat16: MTP_BF16}
+_NT_VARIANT = int(__import__("os").environ.get("MTP_NT_VARIANT", "0"))   # whole-model A/B of the NT GEMM kernel choices (mtp_hip.h: variant)
 
 
 def lib():
@@ -61,7 +62,7 @@ def gemm_nt(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0,
     g.aux, g.aux_ld = _p(aux), (aux.shape[-1] if aux is not None else 0)
     if aux is not None:
         assert aux.dtype == out.dtype and tuple(aux.shape) == (M, N)
-    g.split_k, g.variant = 1, variant
+    g.split_k, g.variant = 1, variant or _NT_VARIANT
     check(lib().mtp_gemm_nt(C.byref(g), _s()), "mtp_gemm_nt")
     return out
 

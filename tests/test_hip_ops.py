@@ -35,7 +35,7 @@ def e(*shape, dtype=torch.float32):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 8, 32, 36])   # default / register-staged / double-buffered / 256x128 8-wave tile (+ grouped order)
 @pytest.mark.parametrize("M,N,K", [(392, 384, 128), (300, 256, 192), (1024, 768, 768), (128, 128, 64)])
 def test_gemm_nt_bias(ops, dtype, variant, M, N, K):
     a, w, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1), rnd(N, seed=2)
@@ -79,6 +79,25 @@ def test_gemm_nt_epilogues(ops, dtype):
     b4 = rnd(N // 4, seed=6)
     out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N), bias=dev(b4), bias_mod=N // 4)
     assert rel_err(out.cpu(), a @ w.t() + b4.repeat(4)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nt_tile_variants_bit_identical(ops, dtype):
+    """the 256x128 / 8-wave kernel (variant 32; picked automatically for one-round problems such as M = 12544, N = 1024) and the
+    tile orders accumulate in the same k order as the default kernel: every epilogue must come out bit-identical"""
+    M, N, K, rps = 1000, 384, 256, 250
+    a, w, b = dev(rnd(M, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.2), dtype), dev(rnd(N, seed=2))
+    res, rs, uu = dev(rnd(M, N, seed=3)), dev(torch.tensor([0.0, 1.1, 0.9, 1.0])), dev(rnd(M, N, dtype=dtype, seed=5), dtype)
+    outs = {}
+    for v in (0, 32, 36, 4, 64):
+        u = e(M, N, dtype=dtype)
+        h = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU, bias=b, aux=u, variant=v)
+        r = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=v)
+        d = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_DGELU, aux=uu, variant=v)
+        outs[v] = (u, h, r, d)
+    for v in (32, 36, 4, 64):
+        for x, y in zip(outs[0], outs[v]):
+            assert torch.equal(x, y), v
 
 
 @pytest.mark.parametrize("dtype", DT)
