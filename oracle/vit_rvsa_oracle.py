@@ -17,7 +17,9 @@ Layout conventions shared with the HIP path:
   qkv         (T, 3C)  channel = [q|k|v][head][64]                       (VIT:97, VIT:390)
   samp        (B*nh*nw, 5*heads) = [off(head,2) | scale(head,2) | angle(head)]  per window (VIT:354-368)
 The *_bwd functions are the hand-derived backward formulas the HIP kernels implement; they are
-checked against torch.autograd of the forward in tests/test_oracle_manual_bwd.py.
+checked against torch.autograd of the forward in tests/test_oracle_golden.py (the "hand-derived backward == autograd"
+assertions), next to the comparison with the reference's own gradients.  `preprocess` (the MTP_DataPreprocessor image
+path) is the one function that is NOT pinned: its arithmetic lives in mmengine, see its docstring.
 """
 import math
 
