@@ -80,13 +80,14 @@ int mtp_gemm_tn(const mtp_gemm_args* args, mtp_stream_t stream);
 int mtp_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                       float* mean, float* rstd, int64_t rows, int64_t C, float eps, int fuse_gelu, mtp_stream_t stream);
 /* dx_out(f32 or ACT) = [dres] + [extra] + LN'(dy);  dx_copy (ACT, optional) = copy_scale[row / rows_per_sample] * dx_out;
- * dgamma/dbeta partials: (nblk, C) f32 each where nblk = mtp_layernorm_bwd_partial_rows(rows). */
+ * dgamma/dbeta partials: nblk rows of C f32 each, row stride part_ld (0 = C; 2C when both live in one (nblk, 2C) buffer so
+ * that one mtp_reduce_rows_f32 launch finishes both), nblk = mtp_layernorm_bwd_partial_rows(rows). */
 int64_t mtp_layernorm_bwd_partial_rows(int64_t rows);
 int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int fuse_gelu,
                       const float* dres, const float* extra, void* dx, int dx_dtype,
                       void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
-                      float* dgamma_part, float* dbeta_part, int64_t rows, int64_t C, mtp_stream_t stream);
+                      float* dgamma_part, float* dbeta_part, int64_t part_ld, int64_t rows, int64_t C, mtp_stream_t stream);
 /* out[c] (+)= sum_r part[r * ld + c], c < C   (per-workgroup partials -> parameter gradient; ld >= C lets one
  * partial buffer feed several parameters) */
 int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dres, const float* __restrict__ extra, Tdx* __restrict__ dx,
                                                            Tact* __restrict__ dx_copy, const float* __restrict__ copy_scale, int rows_per_sample,
-                                                           float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int64_t rows, int C) {
+                                                           float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int64_t part_ld, int64_t rows, int C) {
     __shared__ float4 red[2][3][64 * MAXV];   // waves 1..3 -> wave 0
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
                     a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w;
                     b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
                 }
-                *reinterpret_cast<float4*>(dgamma_part + (int64_t)blockIdx.x * C + col[i]) = a;
-                *reinterpret_cast<float4*>(dbeta_part + (int64_t)blockIdx.x * C + col[i]) = b;
+                *reinterpret_cast<float4*>(dgamma_part + (int64_t)blockIdx.x * part_ld + col[i]) = a;
+                *reinterpret_cast<float4*>(dbeta_part + (int64_t)blockIdx.x * part_ld + col[i]) = b;
             }
         }
     }
@@ -225,14 +225,14 @@ int launch_ln_fwd(const void* x, const float* g, const float* b, void* y, float*
 template <typename Tact, typename Tx, typename Tdx>
 int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int gelu,
                   const float* dres, const float* extra, void* dx, void* dx_copy, const float* copy_scale, int64_t rps,
-                  float* dgp, float* dbp, int64_t rows, int64_t C, hipStream_t s) {
+                  float* dgp, float* dbp, int64_t part_ld, int64_t rows, int64_t C, hipStream_t s) {
     dim3 grid((unsigned)mtp_layernorm_bwd_partial_rows(rows)), block(LN_THREADS);
     if (gelu)
         hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, rows, (int)C);
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
     else
         hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, rows, (int)C);
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
     return mtp_launch_status();
 }
 
@@ -257,17 +257,19 @@ extern "C" int64_t mtp_layernorm_bwd_partial_rows(int64_t rows) {
 extern "C" int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int fuse_gelu, const float* dres, const float* extra, void* dx, int dx_dtype,
                                  void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
-                                 float* dgamma_part, float* dbeta_part, int64_t rows, int64_t C, mtp_stream_t stream) {
+                                 float* dgamma_part, float* dbeta_part, int64_t part_ld, int64_t rows, int64_t C, mtp_stream_t stream) {
+    if (part_ld == 0) part_ld = C;
+    if (part_ld < C || (part_ld % 4)) return MTP_ERR_ARG;
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma_part || !dbeta_part || rows <= 0 || rows > INT32_MAX || (C % 4) || C > 256 * MAXV) return MTP_ERR_ARG;
     if (fuse_gelu && !beta) return MTP_ERR_ARG;
     if (dx_copy && copy_dtype != dy_dtype) return MTP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (dy_dtype == MTP_BF16 && x_dtype == MTP_F32 && dx_dtype == MTP_F32)
-        return launch_ln_bwd<bf16_t, float, float>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, rows, C, s);
+        return launch_ln_bwd<bf16_t, float, float>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s);
     if (dy_dtype == MTP_F32 && x_dtype == MTP_F32 && dx_dtype == MTP_F32)
-        return launch_ln_bwd<float, float, float>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, rows, C, s);
+        return launch_ln_bwd<float, float, float>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s);
     if (dy_dtype == MTP_BF16 && x_dtype == MTP_BF16 && dx_dtype == MTP_BF16)
-        return launch_ln_bwd<bf16_t, bf16_t, bf16_t>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, rows, C, s);
+        return launch_ln_bwd<bf16_t, bf16_t, bf16_t>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s);
     return MTP_ERR_UNSUPPORTED;
 }
 

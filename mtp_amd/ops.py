@@ -115,12 +115,18 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=F
     # (an in-kernel f32-atomic accumulation of dgamma / dbeta was measured: 512 workgroups hitting the same 2C addresses took
     #  the kernel from 61 to 106 us; per-workgroup partials + two 8 us reductions are faster)
     nblk = lib().mtp_layernorm_bwd_partial_rows(rows)
-    part = torch.empty(2, nblk, Cc, device=x.device, dtype=torch.float32)
+    part = torch.empty(nblk, 2 * Cc, device=x.device, dtype=torch.float32)     # [dgamma partials | dbeta partials] per workgroup
     check(lib().mtp_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _f32(mean), _f32(rstd), _f32(gamma), _f32(beta), int(gelu),
                                   _f32(dres), _f32(extra), _p(dx), _dt(dx), _p(dx_copy), (_dt(dx_copy) if dx_copy is not None else 0),
-                                  _f32(copy_scale), rows_per_sample, _p(part[0]), _p(part[1]), rows, Cc, _s()), "mtp_layernorm_bwd")
-    reduce_rows(part[0], dgamma, accumulate)
-    reduce_rows(part[1], dbeta, accumulate)
+                                  _f32(copy_scale), rows_per_sample, part.data_ptr(), part.data_ptr() + 4 * Cc, 2 * Cc, rows, Cc, _s()),
+          "mtp_layernorm_bwd")
+    if (dbeta.data_ptr() == dgamma.data_ptr() + 4 * Cc and dgamma.is_contiguous() and dbeta.is_contiguous()
+            and dgamma.untyped_storage().data_ptr() == dbeta.untyped_storage().data_ptr()):
+        # weight and bias gradient adjacent in one buffer (the flat gradient buffer of mtp_amd.parallel): ONE reduction launch
+        reduce_rows(part, dgamma.as_strided((2 * Cc,), (1,)), accumulate)
+    else:
+        reduce_rows(part[:, :Cc], dgamma, accumulate)
+        reduce_rows(part[:, Cc:], dbeta, accumulate)
     return dx
 
 
