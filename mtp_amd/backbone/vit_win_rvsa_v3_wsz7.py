@@ -65,15 +65,16 @@ class Mlp(_NoCall):
 class Attention(_NoCall):
     """VIT:65-88 parameter layout (full MHSA with decomposed rel-pos)."""
 
-    def __init__(self, dim, num_heads, qkv_bias, window_size):
+    def __init__(self, dim, num_heads, qkv_bias, window_size, rel_pos=True):
         super().__init__()
         self.num_heads = num_heads
         head_dim = dim // num_heads
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.window_size = window_size
         rel_sp_dim = 2 * window_size[0] - 1
-        self.full_attn_rel_pos_h = nn.Parameter(torch.zeros(rel_sp_dim, head_dim))
-        self.full_attn_rel_pos_w = nn.Parameter(torch.zeros(rel_sp_dim, head_dim))
+        if rel_pos:   # (the ViTDet-style fine-tune copies have these two lines commented out, mmdet vit_rvsa_mtp.py:73-74)
+            self.full_attn_rel_pos_h = nn.Parameter(torch.zeros(rel_sp_dim, head_dim))
+            self.full_attn_rel_pos_w = nn.Parameter(torch.zeros(rel_sp_dim, head_dim))
         self.proj = nn.Linear(dim, dim)
 
 
@@ -101,13 +102,13 @@ class RotatedVariedSizeWindowAttention(_NoCall):
 class Block(_NoCall):
     """VIT:479-504 parameter layout."""
 
-    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, norm_layer, window_size, window, drop_path=0.0):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, norm_layer, window_size, window, drop_path=0.0, full_rel_pos=True):
         super().__init__()
         self.norm1 = norm_layer(dim)
         if window:
             self.attn = RotatedVariedSizeWindowAttention(dim, num_heads, qkv_bias, window_size[0])
         else:
-            self.attn = Attention(dim, num_heads, qkv_bias, window_size)
+            self.attn = Attention(dim, num_heads, qkv_bias, window_size, rel_pos=full_rel_pos)
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
         self.drop_path_prob = drop_path
@@ -167,6 +168,8 @@ class _BackboneFn(torch.autograd.Function):
 class ViT_Win_RVSA_V3_WSZ7(nn.Module):
     """Vision Transformer with RVSA window attention (VIT:587-817), MI355X-native."""
 
+    _vitdet = False   # True in RVSA_MTP_det: the mmdet / mmrotate fine-tune copies' ViTDet-style forward
+
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=80, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
                  drop_path_rate=0., hybrid_backbone=None, norm_layer=None, init_values=None, use_checkpoint=False,
@@ -202,7 +205,7 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
         self.blocks = nn.ModuleList([
             Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer,
                   window_size=(7, 7) if self.window_blocks[i] else self.patch_embed.patch_shape,
-                  window=self.window_blocks[i], drop_path=dpr[i])
+                  window=self.window_blocks[i], drop_path=dpr[i], full_rel_pos=not self._vitdet)
             for i in range(depth)])
         self.interval = interval
         if self.pos_embed is not None:
@@ -225,9 +228,12 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
         self._eng = None
         self.data_preprocessor = None
         self._param_names = [n for n, _ in self.named_parameters()]
-        self._unused_params = {"norm.weight", "norm.bias"}
-        last = max(out_indices)
-        self._unused_params |= {n for n in self._param_names if n.startswith("blocks.") and int(n.split(".")[1]) > last}
+        if self._vitdet:      # last block -> norm -> fpn1-4: every parameter is on the path
+            self._unused_params = set()
+        else:
+            self._unused_params = {"norm.weight", "norm.bias"}
+            last = max(out_indices)
+            self._unused_params |= {n for n in self._param_names if n.startswith("blocks.") and int(n.split(".")[1]) > last}
 
     # ---- reference API -------------------------------------------------------------------------------------------
     def fix_init_weight(self):
@@ -383,11 +389,20 @@ class RVSA_MTP_branches(ViT_Win_RVSA_V3_WSZ7):
         return self._load_pretrained(pretrained or self.pretrained, finetune=True)
 
 
+class RVSA_MTP_det(RVSA_MTP_branches):
+    """`RVSA_MTP` as registered in mmdet / mmrotate (RS_Tasks_Finetune/Horizontal_Detection/mmdet/models/backbones/
+    vit_rvsa_mtp.py:577-844, Rotated_Detection/mmrotate*/...): ViTDet style -- full attention WITHOUT decomposed rel-pos
+    (:73-74, 93), no taps: the last block's output goes through the final `norm` (:835) and all four fpn ops are applied to
+    that one map (:841).  `out_indices` is accepted and ignored, as there.  Pinned by fixture f9 (generated from that file)."""
+
+    _vitdet = True
+
+
 class RVSA_MTP(RVSA_MTP_branches):
     """`RVSA_MTP` as registered in mmseg (RS_Tasks_Finetune/Semantic_Segmentation/mmseg/models/backbones/vit_rvsa_mtp.py:577):
     multi-level taps + fpn1-4, tuple output.  (The mmdet/mmrotate ViTDet-style last-layer variant is SURVEY 8f-4.)"""
 
 
-for _cls in (ViT_Win_RVSA_V3_WSZ7, RVSA_MTP, RVSA_MTP_branches):
+for _cls in (ViT_Win_RVSA_V3_WSZ7, RVSA_MTP, RVSA_MTP_branches, RVSA_MTP_det):
     MODELS.register_module(module=_cls, force=True)
     BACKBONES.register_module(module=_cls, force=True)

@@ -39,6 +39,7 @@ class BackboneEngine:
         self._pe = None
         self._wimg = None
         self._wimg_ptrs = None
+        self._zero_rel = {}
 
     # ------------------------------------------------------------------ parameters
     def params(self):
@@ -123,6 +124,18 @@ class BackboneEngine:
     def _ln_bwd(*args, **kw):
         return ops.layernorm_bwd(*args, accumulate=True, **kw)
 
+    def _full_rel(self, pre, Hp, Wp):
+        """decomposed rel-pos tables of a full-attention block; zero tables for the ViTDet-style fine-tune copies, whose full
+        attention has none (mmdet vit_rvsa_mtp.py:73-74, 93) -- adding q.0 is exact, so the same kernels serve both"""
+        h = self.P.get(pre + "attn.full_attn_rel_pos_h")
+        if h is not None:
+            return h, self.P[pre + "attn.full_attn_rel_pos_w"]
+        key = (Hp, Wp)
+        if self._zero_rel.get(key) is None:
+            self._zero_rel[key] = (torch.zeros(2 * Hp - 1, self.hd, device=self.dev, dtype=F32),
+                                   torch.zeros(2 * Wp - 1, self.hd, device=self.dev, dtype=F32))
+        return self._zero_rel[key]
+
     def _drop_scales(self, B, training):
         """VIT:31-42, 619: per-sample factor floor(keep + U[0,1)) / keep for each residual branch; None when inactive."""
         out = []
@@ -158,7 +171,8 @@ class BackboneEngine:
             s.update(avg=avg, pooled=pooled, samp=samp)
         else:
             lse = self._e(B * self.heads * N, dtype=F32)
-            ops.full_attn_fwd(qkv, o, lse, P[pre + "attn.full_attn_rel_pos_h"], P[pre + "attn.full_attn_rel_pos_w"], B, Hp, Wp, self.heads, self.scale)
+            rel_h, rel_w = self._full_rel(pre, Hp, Wp)
+            ops.full_attn_fwd(qkv, o, lse, rel_h, rel_w, B, Hp, Wp, self.heads, self.scale)
         x1 = ops.gemm_nt(o, b.wproj, self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=P[pre + "attn.proj.bias"], res=x,
                          rowscale=dps[0], rows_per_sample=N)
         mean2, rstd2 = self._e(T, dtype=F32), self._e(T, dtype=F32)
@@ -209,8 +223,12 @@ class BackboneEngine:
                                G[pre + "attn.sampling_angles.2.weight"], G[pre + "attn.sampling_offsets.2.bias"],
                                G[pre + "attn.sampling_scales.2.bias"], G[pre + "attn.sampling_angles.2.bias"]])
         else:
-            ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, P[pre + "attn.full_attn_rel_pos_h"], P[pre + "attn.full_attn_rel_pos_w"],
-                              G[pre + "attn.full_attn_rel_pos_h"], G[pre + "attn.full_attn_rel_pos_w"], B, Hp, Wp, self.heads, self.scale,
+            rel_h, rel_w = self._full_rel(pre, Hp, Wp)
+            if pre + "attn.full_attn_rel_pos_h" in G:
+                drel_h, drel_w = G[pre + "attn.full_attn_rel_pos_h"], G[pre + "attn.full_attn_rel_pos_w"]
+            else:   # ViTDet-style copies: no such parameters -- the table gradients go to a scratch buffer
+                drel_h, drel_w = self._e(*rel_h.shape, dtype=F32), self._e(*rel_w.shape, dtype=F32)
+            ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, self.heads, self.scale,
                               accumulate=True)
         ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], colsum=G[pre + "attn.qkv.bias"])
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
@@ -262,7 +280,8 @@ class BackboneEngine:
         dps = self._drop_scales(B, training)
         ckpt = bool(m.use_checkpoint) and need_grad
         saved, taps = [], {}
-        last = max(self.out_indices)
+        vitdet = bool(getattr(m, "_vitdet", False))
+        last = self.depth - 1 if vitdet else max(self.out_indices)
         for i in range(self.depth):
             if i > last:
                 break      # blocks after the last tap do not influence the outputs
@@ -271,10 +290,19 @@ class BackboneEngine:
             saved.append(s if (need_grad and not ckpt) else ({"x": xin} if need_grad else None))
             if i in self.out_indices:
                 taps[i] = x
-        feats, fctx = self._fpn_fwd([taps[i] for i in self.out_indices], B, Hp, Wp, fdt, need_grad)
+        final = None
+        if vitdet:
+            # mmdet / mmrotate `RVSA_MTP` (vit_rvsa_mtp.py:835-841): last block -> final norm -> the four fpn ops on that ONE map
+            fm, fr = self._e(T, dtype=F32), self._e(T, dtype=F32)
+            xn = ops.layernorm_fwd(x, P["norm.weight"], P["norm.bias"], self._e(T, C, dtype=F32), fm, fr)
+            final = (x, fm, fr)
+            tap_list = [xn, xn, xn, xn]
+        else:
+            tap_list = [taps[i] for i in self.out_indices]
+        feats, fctx = self._fpn_fwd(tap_list, B, Hp, Wp, fdt, need_grad)
         ctx = None
         if need_grad:
-            ctx = dict(saved=saved, dps=dps, fctx=fctx, cols=cols, geom=(B, Cin, H, W, Hp, Wp), ckpt=ckpt, last=last)
+            ctx = dict(saved=saved, dps=dps, fctx=fctx, cols=cols, geom=(B, Cin, H, W, Hp, Wp), ckpt=ckpt, last=last, final=final)
         return feats, ctx
 
     # ------------------------------------------------------------------ FPN tail (VIT:640-654, 807-811)
@@ -353,17 +381,32 @@ class BackboneEngine:
         P = self.P
         self.dev = ctx["cols"].device
         dtaps = self._fpn_bwd(dfeats, ctx["fctx"], B, Hp, Wp, G)
-        if on_block_done is not None:
-            on_block_done(self.depth)          # FPN parameters done
         tapgrad = {}
-        for idx, d in zip(self.out_indices, dtaps):
-            if d is None:
-                continue
-            if idx in tapgrad:
-                ops.axpy(tapgrad[idx], d)
-            else:
-                tapgrad[idx] = d
         last, dps, saved = ctx["last"], ctx["dps"], ctx["saved"]
+        if ctx.get("final") is not None:
+            # ViTDet-style copies: the four fpn gradients meet at the final norm's output; LN backward gives the last block's
+            # output gradient (and norm.weight / norm.bias, which DO get gradients in this variant)
+            dsum = None
+            for d in dtaps:
+                if d is None:
+                    continue
+                if dsum is None:
+                    dsum = d
+                else:
+                    ops.axpy(dsum, d)
+            if dsum is not None:
+                xl, fm, fr = ctx["final"]
+                tapgrad[last] = self._ln_bwd(dsum, xl, fm, fr, P["norm.weight"], self._e(T, C, dtype=F32), G["norm.weight"], G["norm.bias"])
+        else:
+            for idx, d in zip(self.out_indices, dtaps):
+                if d is None:
+                    continue
+                if idx in tapgrad:
+                    ops.axpy(tapgrad[idx], d)
+                else:
+                    tapgrad[idx] = d
+        if on_block_done is not None:
+            on_block_done(self.depth)          # FPN (and final-norm) parameter gradients are complete on the stream
         if last not in tapgrad:
             tapgrad[last] = torch.zeros(T, C, device=self.dev, dtype=F32)
         dx = tapgrad[last]

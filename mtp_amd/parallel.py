@@ -28,8 +28,8 @@ def execution_order(names, depth):
     """Reverse execution order of the parameter names; returns (ordered names, group id per name) with groups
     depth+0 = FPN tail, block i = i, -1 = patch/pos embed, None = never receives a gradient."""
     def group(n):
-        if n.startswith("fpn"):
-            return depth
+        if n.startswith("fpn") or n.startswith("norm."):   # norm.*: used only by the ViTDet-style copies (final norm before the
+            return depth                                    # fpn ops); FlatParams drops it through `unused` for the others
         if n.startswith("blocks."):
             return int(n.split(".")[1])
         if n.startswith("patch_embed") or n == "pos_embed":

@@ -472,7 +472,7 @@ def block_forward(x, p, pre, window, B, Hp, Wp, heads, dp_scale=None):
         a, _ = rvsa_attn_fwd(qkv, samp, B, Hp, Wp, heads, p[pre + "attn.rel_pos_h"], p[pre + "attn.rel_pos_w"],
                              p[pre + "attn.relative_position_bias_table"])
     else:
-        a, _ = full_attn_fwd(qkv, B, Hp, Wp, heads, p[pre + "attn.full_attn_rel_pos_h"], p[pre + "attn.full_attn_rel_pos_w"])
+        a, _ = full_attn_fwd(qkv, B, Hp, Wp, heads, *_full_rel_tables(p, pre, Hp, Wp, x.shape[1] // heads))
     a = a @ p[pre + "attn.proj.weight"].t() + p[pre + "attn.proj.bias"]
     if dp_scale is not None:
         a = a * dp_scale.repeat_interleave(N)[:, None]
@@ -484,9 +484,24 @@ def block_forward(x, p, pre, window, B, Hp, Wp, heads, dp_scale=None):
     return x + m
 
 
-def backbone_forward(img, p, depth, heads, interval, out_indices, dp_scales=None):
+def _full_rel_tables(p, pre, Hp, Wp, hd):
+    """decomposed rel-pos tables of a full-attention block; the ViTDet-style fine-tune copies (mmdet / mmrotate
+    vit_rvsa_mtp.py:73-74, 93: parameters and the calc_rel_pos_spatial call commented out) have none -> zero tables."""
+    h, w = p.get(pre + "attn.full_attn_rel_pos_h"), p.get(pre + "attn.full_attn_rel_pos_w")
+    ref = p[pre + "attn.qkv.weight"]
+    if h is None:
+        h = torch.zeros(2 * Hp - 1, hd, dtype=ref.dtype)
+    if w is None:
+        w = torch.zeros(2 * Wp - 1, hd, dtype=ref.dtype)
+    return h, w
+
+
+def backbone_forward(img, p, depth, heads, interval, out_indices, dp_scales=None, vitdet=False):
     """VIT:787-813 forward_features.  p: reference state-dict (name -> tensor).
-    dp_scales: optional list over blocks of (attn_scale, mlp_scale) per-sample factors."""
+    dp_scales: optional list over blocks of (attn_scale, mlp_scale) per-sample factors.
+    vitdet=True: forward_features of the mmdet / mmrotate `RVSA_MTP` copies
+    (RS_Tasks_Finetune/Horizontal_Detection/mmdet/models/backbones/vit_rvsa_mtp.py:822-844): no taps; the LAST block's
+    output goes through the final `norm` (:835) and all four fpn ops are applied to that one map (:841)."""
     B = img.shape[0]
     x, (Hp, Wp) = patch_embed(img, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], p.get("pos_embed"))
     taps = []
@@ -500,6 +515,9 @@ def backbone_forward(img, p, depth, heads, interval, out_indices, dp_scales=None
             x = block_forward(x, p, pre, window, B, Hp, Wp, heads)
         if i in out_indices:
             taps.append(x)
+    if vitdet:
+        xn = layernorm_fwd(x, p["norm.weight"], p["norm.bias"])[0]
+        taps = [xn, xn, xn, xn]
     return fpn(taps, B, Hp, Wp, p)
 
 
@@ -525,7 +543,7 @@ def block_forward_parts(x, p, pre, window, B, Hp, Wp, heads):
         a, _ = rvsa_attn_fwd(qkv, samp, B, Hp, Wp, heads, p[pre + "attn.rel_pos_h"], p[pre + "attn.rel_pos_w"],
                              p[pre + "attn.relative_position_bias_table"])
     else:
-        a, _ = full_attn_fwd(qkv, B, Hp, Wp, heads, p[pre + "attn.full_attn_rel_pos_h"], p[pre + "attn.full_attn_rel_pos_w"])
+        a, _ = full_attn_fwd(qkv, B, Hp, Wp, heads, *_full_rel_tables(p, pre, Hp, Wp, x.shape[1] // heads))
     a = a @ p[pre + "attn.proj.weight"].t() + p[pre + "attn.proj.bias"]
 
     def fn_mlp(xm):

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
 from ref_loader import load_reference  # noqa: E402
 import recipe  # noqa: E402
 
@@ -268,7 +269,42 @@ def f8():
     save("f8_small.npz", **out)
 
 
+# ------------------------------------------------------------------ f9: ViTDet-style fine-tune copy (mmdet RVSA_MTP), fwd + all grads
+def f9():
+    """RS_Tasks_Finetune/Horizontal_Detection/mmdet/models/backbones/vit_rvsa_mtp.py: full attention WITHOUT rel-pos, last block
+    -> final `norm` -> fpn1-4 all applied to that one map.  Same parameter recipe minus the full_attn_rel_pos_* keys."""
+    det = ref_loader.load_reference_det()
+    net = quiet(det.RVSA_MTP, img_size=224, patch_size=16, drop_path_rate=0.0, out_indices=[1, 2, 3, 3], embed_dim=128, depth=4,
+                num_heads=2, mlp_ratio=4, qkv_bias=True, use_abs_pos_emb=True, interval=2, use_rel_pos_bias=True)
+    shapes = {k: v for k, v in recipe.state_shapes(128, 4, 2, 2, 224).items() if "full_attn_rel_pos" not in k}
+    sd = net.state_dict()
+    float_keys = [k for k, v in sd.items() if v.dtype.is_floating_point]
+    assert float_keys == list(shapes.keys()), (set(float_keys) ^ set(shapes.keys()))
+    msg = net.load_state_dict(recipe.make_params(shapes, 2023), strict=False)
+    assert not msg.unexpected_keys and all("relative_position_index" in k for k in msg.missing_keys), msg
+    net.train()
+    img = recipe.make_input(2, 224, 224, seed=77).requires_grad_(True)
+    feats = net(img)
+    assert isinstance(feats, tuple) and len(feats) == 4
+    out = {"keys": np.array(float_keys)}
+    loss = 0
+    for i, f in enumerate(feats):
+        out["f%d_sum" % i], out["f%d_samples" % i] = recipe.summarize(f, 2048)
+        loss = loss + (f * recipe.loss_weights(f.shape, 300 + i)).sum()
+    out["f2"], out["f3"] = feats[2], feats[3]
+    loss.backward()
+    out["loss"] = loss.detach()
+    out["dimg_sum"], out["dimg_samples"] = recipe.summarize(img.grad, 2048)
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n          # every parameter (norm.* included) is used in this variant
+        if p.numel() <= 4096:
+            out["g_" + n] = p.grad
+        else:
+            out["gs_%s_sum" % n], out["gs_%s_samples" % n] = recipe.summarize(p.grad, 1024)
+    save("f9_vitdet.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8"]
+    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9"]
     for w in which:
         globals()[w]()

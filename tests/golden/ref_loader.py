@@ -56,3 +56,29 @@ def load_reference():
     sys.modules["ref_vit"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+REF_DET = "/root/reference/RS_Tasks_Finetune/Horizontal_Detection/mmdet/models/backbones/vit_rvsa_mtp.py"
+
+
+def load_reference_det():
+    """The mmdet fine-tune copy (`RVSA_MTP`, ViTDet style: final norm, one map through fpn1-4, full attention without
+    rel-pos).  One more stub: `mmdet.registry.MODELS.register_module()` (a decorator that returns the class)."""
+    if "ref_vit_det" in sys.modules:
+        return sys.modules["ref_vit_det"]
+    load_reference()     # installs the timm / mmengine stubs
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+    mmdet = types.ModuleType("mmdet")
+    mmdet_registry = types.ModuleType("mmdet.registry")
+    mmdet_registry.MODELS = _Reg()
+    mmdet.registry = mmdet_registry
+    sys.modules.setdefault("mmdet", mmdet)
+    sys.modules.setdefault("mmdet.registry", mmdet_registry)
+    spec = importlib.util.spec_from_file_location("ref_vit_det", REF_DET)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_vit_det"] = mod
+    spec.loader.exec_module(mod)
+    return mod

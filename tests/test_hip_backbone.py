@@ -206,3 +206,35 @@ def test_uint8_input_through_fused_preprocessor_equals_preprocessed_f32_input():
     net.data_preprocessor = None
     with pytest.raises(ValueError):
         net(raw.cuda())
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+def test_vitdet_style_finetune_variant_vs_reference(golden, precision, tol):
+    """fixture f9 = the reference's mmdet `RVSA_MTP`: full attention without rel-pos, last block -> final norm ->
+    fpn1-4 on that one map; every parameter (norm.* too) gets a gradient.  Here: mtp_amd.RVSA_MTP_det, tuple output."""
+    g = golden("f9_vitdet.npz")
+    net = mtp_amd.RVSA_MTP_det(img_size=224, embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True,
+                               out_indices=[1, 2, 3, 3], precision=precision, feature_dtype=torch.float32)
+    shapes = {k: v for k, v in recipe.state_shapes(128, 4, 2, 2).items() if "full_attn_rel_pos" not in k}
+    assert [k for k, v in net.state_dict().items() if v.dtype.is_floating_point] == [str(k) for k in g["keys"]]
+    msg = net.load_state_dict(recipe.make_params(shapes), strict=False)
+    assert not msg.unexpected_keys and all(k.endswith("relative_position_index") for k in msg.missing_keys)
+    net = net.cuda().train()
+    img = recipe.make_input(2, 224, 224, seed=77).cuda().requires_grad_(True)
+    feats = net(img)
+    assert isinstance(feats, tuple) and [tuple(f.shape) for f in feats] == [(2, 128, 56, 56), (2, 128, 28, 28), (2, 128, 14, 14), (2, 128, 7, 7)]
+    loss = 0
+    for i, f in enumerate(feats):
+        _check_summary(f, g["f%d_sum" % i], g["f%d_samples" % i], tol, 2048)
+        loss = loss + (f * recipe.loss_weights(f.shape, 300 + i).cuda()).sum()
+    assert rel_err(feats[2].cpu(), g["f2"]) < tol and rel_err(feats[3].cpu(), g["f3"]) < tol
+    loss.backward()
+    gt = 5 * tol if precision == "fp32" else 0.35
+    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], gt, 2048, "dimg")
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        if "g_" + n in g:
+            e = rel_err(p.grad.cpu(), g["g_" + n])
+        else:
+            e = _check_summary(p.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], gt, 1024, n)
+        assert e < (0.6 if (precision == "bf16" and "sampling" in n) else gt), (n, e)

@@ -167,6 +167,21 @@ def test_finetune_loader_rules(tmp_path):
     assert "patch_embed.proj.weight" in msg.missing_keys and not torch.equal(pre4.patch_embed.proj.weight, src4.patch_embed.proj.weight)
 
 
+def test_vitdet_style_class_matches_the_reference_copy(golden):
+    """`RVSA_MTP_det` = the mmdet / mmrotate `RVSA_MTP` (fixture f9 holds that class's own float state-dict keys, in order):
+    no full_attn_rel_pos_* parameters, `norm.*` is a USED parameter, tuple output class, registry-buildable."""
+    g = golden("f9_vitdet.npz")
+    kw = dict(img_size=224, embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 3])
+    net = mtp_amd.RVSA_MTP_det(**kw)
+    assert [k for k, v in net.state_dict().items() if v.dtype.is_floating_point] == [str(k) for k in g["keys"]]
+    assert not any("full_attn_rel_pos" in k for k in net.state_dict()) and net._unused_params == set()
+    assert "attn.full_attn_rel_pos_h" in " ".join(mtp_amd.RVSA_MTP(**kw).state_dict())         # the mmseg-style class keeps them
+    built = mtp_amd.MODELS.build(dict(type="RVSA_MTP_det", **kw))
+    assert type(built) is mtp_amd.RVSA_MTP_det and list(built.state_dict()) == list(net.state_dict())
+    with pytest.raises(RuntimeError, match="no CPU"):
+        net(torch.zeros(1, 3, 224, 224))
+
+
 def test_recipe_params_load_strictly():
     net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
     msg = net.load_state_dict(recipe.make_params(recipe.state_shapes(128, 6, 2, 3)), strict=False)

@@ -224,6 +224,30 @@ def test_f8_small_whole_model_fwd_and_grads(golden):
             _check_summary(v.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], 5 * TOL, 1024)
 
 
+def test_f9_vitdet_style_finetune_copy_fwd_and_grads(golden):
+    """fixture f9 = the reference's mmdet `RVSA_MTP` (RS_Tasks_Finetune/Horizontal_Detection/mmdet/models/backbones/
+    vit_rvsa_mtp.py): full attention without rel-pos, last block -> final norm -> fpn1-4 on that one map.  Every parameter
+    (norm.* included) has a gradient there."""
+    g = golden("f9_vitdet.npz")
+    shapes = {k: v for k, v in recipe.state_shapes(128, 4, 2, 2).items() if "full_attn_rel_pos" not in k}
+    assert list(shapes) == [str(k) for k in g["keys"]]
+    p = {k: v.requires_grad_(True) for k, v in recipe.make_params(shapes).items()}
+    img = recipe.make_input(2, 224, 224, seed=77).requires_grad_(True)
+    feats = O.backbone_forward(img, p, 4, 2, 2, [], vitdet=True)
+    loss = 0
+    for i, f in enumerate(feats):
+        _check_summary(f, g["f%d_sum" % i], g["f%d_samples" % i], TOL, 2048)
+        loss = loss + (f * recipe.loss_weights(f.shape, 300 + i)).sum()
+    assert rel_err(feats[2], g["f2"]) < TOL and rel_err(feats[3], g["f3"]) < TOL
+    loss.backward()
+    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], 5 * TOL, 2048)
+    for n, v in p.items():
+        if "g_" + n in g:
+            assert rel_err(v.grad, g["g_" + n]) < 5 * TOL, n
+        else:
+            _check_summary(v.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], 5 * TOL, 1024)
+
+
 def test_f7_vitb_whole_forward_config1(golden):
     """BASELINE config 1: ViT-B/16 forward, batch 2, 224x224 (+ input/param gradient samples)."""
     g = golden("f7_vitb.npz")

@@ -23,7 +23,12 @@ def test_execution_order_and_layout():
     ref = {n: p.detach().clone() for n, p in net.named_parameters()}
     flat = FlatParams(net, unused=net._unused_params)
     order, groups = execution_order([n for n, _ in net.named_parameters()], 6)
-    assert order[0].startswith("fpn") and order[-1].startswith("norm.")
+    assert groups["norm.weight"] == groups["fpn1.0.weight"] == 6      # tail group (the final norm is used by RVSA_MTP_det only)
+    assert flat.names[0].startswith("fpn") and flat.names[-1].startswith("norm.")   # ... and dropped here through `unused`
+    det = mtp_amd.RVSA_MTP_det(embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True, out_indices=[3])
+    fdet = FlatParams(det, unused=det._unused_params)
+    assert fdet.groups["norm.weight"] == 4 and "norm.weight" in fdet.G and fdet.offsets["norm.bias"] < fdet.reduced
+    assert not any("full_attn_rel_pos" in n for n in fdet.names)
     gids = [flat.groups[n] for n in flat.names if flat.groups[n] is not None]
     assert gids == sorted(gids, reverse=True)                      # FPN (6), blocks 5..0, embed (-1)
     assert all(flat.groups[n] is None for n in ("norm.weight", "norm.bias"))
