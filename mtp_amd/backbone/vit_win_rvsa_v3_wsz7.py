@@ -169,6 +169,7 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
     """Vision Transformer with RVSA window attention (VIT:587-817), MI355X-native."""
 
     _vitdet = False   # True in RVSA_MTP_det: the mmdet / mmrotate fine-tune copies' ViTDet-style forward
+    _taps_only = False   # True in RVSA_MTP_taps: the mmpretrain / opencd copies return the taps without the fpn ops
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=80, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
@@ -234,6 +235,8 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
             self._unused_params = {"norm.weight", "norm.bias"}
             last = max(out_indices)
             self._unused_params |= {n for n in self._param_names if n.startswith("blocks.") and int(n.split(".")[1]) > last}
+            if self._taps_only:   # the fpn modules exist (state-dict parity) but their ops are not applied
+                self._unused_params |= {n for n in self._param_names if n.startswith("fpn")}
 
     # ---- reference API -------------------------------------------------------------------------------------------
     def fix_init_weight(self):
@@ -398,11 +401,36 @@ class RVSA_MTP_det(RVSA_MTP_branches):
     _vitdet = True
 
 
+class RVSA_MTP_taps(RVSA_MTP_branches):
+    """`RVSA_MTP` as registered in mmpretrain / open-cd (RS_Tasks_Finetune/Scene_Classification/mmpretrain/models/backbones/
+    vit_rvsa_mtp.py:822-842, Change_Detection/opencd/...): the block outputs at `out_indices` (any number of them) are
+    returned as NCHW maps, the fpn ops are commented out there (:838-840); `norm.*` and `fpn*` stay in the state dict and get
+    no gradient.  open-cd's extra `frozen_stages` kwarg and `_freeze_stages()` (opencd copy :585, 820-835; never called there,
+    :669) are kept with the same meaning.  Pinned by fixture f10 (generated from the mmpretrain file)."""
+
+    _taps_only = True
+
+    def __init__(self, *args, frozen_stages=-1, **kw):
+        super().__init__(*args, **kw)
+        self.frozen_stages = frozen_stages
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.patch_embed.eval()
+            for p in self.patch_embed.parameters():
+                p.requires_grad = False
+            self.pos_embed.requires_grad = False
+            for i in range(self.frozen_stages):
+                self.blocks[i].eval()
+                for p in self.blocks[i].parameters():
+                    p.requires_grad = False
+
+
 class RVSA_MTP(RVSA_MTP_branches):
     """`RVSA_MTP` as registered in mmseg (RS_Tasks_Finetune/Semantic_Segmentation/mmseg/models/backbones/vit_rvsa_mtp.py:577):
     multi-level taps + fpn1-4, tuple output.  (The mmdet/mmrotate ViTDet-style last-layer variant is SURVEY 8f-4.)"""
 
 
-for _cls in (ViT_Win_RVSA_V3_WSZ7, RVSA_MTP, RVSA_MTP_branches, RVSA_MTP_det):
+for _cls in (ViT_Win_RVSA_V3_WSZ7, RVSA_MTP, RVSA_MTP_branches, RVSA_MTP_det, RVSA_MTP_taps):
     MODELS.register_module(module=_cls, force=True)
     BACKBONES.register_module(module=_cls, force=True)

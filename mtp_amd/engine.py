@@ -141,7 +141,7 @@ class BackboneEngine:
         out = []
         for i in range(self.depth):
             r = float(self.m.drop_path_rates[i])
-            if not training or r == 0.0:
+            if not training or r == 0.0 or not self.m.blocks[i].training:   # (a frozen stage is put in eval(): no drop-path there)
                 out.append((None, None))
             else:
                 keep = 1.0 - r
@@ -299,7 +299,12 @@ class BackboneEngine:
             tap_list = [xn, xn, xn, xn]
         else:
             tap_list = [taps[i] for i in self.out_indices]
-        feats, fctx = self._fpn_fwd(tap_list, B, Hp, Wp, fdt, need_grad)
+        if getattr(m, "_taps_only", False):
+            # mmpretrain / opencd `RVSA_MTP` (vit_rvsa_mtp.py:836-842): the taps as NCHW maps, no fpn ops
+            feats = [ops.tokens_to_nchw(t, self._e(B, C, Hp, Wp, dtype=fdt), B, Hp, Wp, 0) for t in tap_list]
+            fctx = {"taps_only": True}
+        else:
+            feats, fctx = self._fpn_fwd(tap_list, B, Hp, Wp, fdt, need_grad)
         ctx = None
         if need_grad:
             ctx = dict(saved=saved, dps=dps, fctx=fctx, cols=cols, geom=(B, Cin, H, W, Hp, Wp), ckpt=ckpt, last=last, final=final)
@@ -380,7 +385,11 @@ class BackboneEngine:
         C, N, T = self.C, Hp * Wp, B * Hp * Wp
         P = self.P
         self.dev = ctx["cols"].device
-        dtaps = self._fpn_bwd(dfeats, ctx["fctx"], B, Hp, Wp, G)
+        if ctx["fctx"].get("taps_only"):
+            dtaps = [None if d is None else ops.nchw_to_tokens((d.contiguous() if d.dtype in (F32, torch.bfloat16) else d.float().contiguous()),
+                                                               self._e(T, C, dtype=F32), B, Hp, Wp, 0) for d in dfeats]
+        else:
+            dtaps = self._fpn_bwd(dfeats, ctx["fctx"], B, Hp, Wp, G)
         tapgrad = {}
         last, dps, saved = ctx["last"], ctx["dps"], ctx["saved"]
         if ctx.get("final") is not None:

@@ -496,7 +496,7 @@ def _full_rel_tables(p, pre, Hp, Wp, hd):
     return h, w
 
 
-def backbone_forward(img, p, depth, heads, interval, out_indices, dp_scales=None, vitdet=False):
+def backbone_forward(img, p, depth, heads, interval, out_indices, dp_scales=None, vitdet=False, taps_only=False):
     """VIT:787-813 forward_features.  p: reference state-dict (name -> tensor).
     dp_scales: optional list over blocks of (attn_scale, mlp_scale) per-sample factors.
     vitdet=True: forward_features of the mmdet / mmrotate `RVSA_MTP` copies
@@ -518,6 +518,8 @@ def backbone_forward(img, p, depth, heads, interval, out_indices, dp_scales=None
     if vitdet:
         xn = layernorm_fwd(x, p["norm.weight"], p["norm.bias"])[0]
         taps = [xn, xn, xn, xn]
+    if taps_only:   # mmpretrain / opencd copies: the taps as NCHW maps, fpn ops commented out (vit_rvsa_mtp.py:836-842)
+        return [tokens_to_nchw(t, B, Hp, Wp, 0) for t in taps]
     return fpn(taps, B, Hp, Wp, p)
 
 

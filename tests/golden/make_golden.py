@@ -304,7 +304,40 @@ def f9():
     save("f9_vitdet.npz", **out)
 
 
+# ------------------------------------------------------------------ f10: tap-only fine-tune copy (mmpretrain RVSA_MTP), fwd + grads
+def f10():
+    """RS_Tasks_Finetune/Scene_Classification/mmpretrain/models/backbones/vit_rvsa_mtp.py: the taps are returned as NCHW maps
+    WITHOUT the fpn ops (:838-840 commented out); fpn*/norm parameters exist but are unused.  Two taps here (out_indices [1, 3])."""
+    cls = ref_loader.load_reference_cls()
+    net = quiet(cls.RVSA_MTP, img_size=224, patch_size=16, drop_path_rate=0.0, out_indices=[1, 3], embed_dim=128, depth=4,
+                num_heads=2, mlp_ratio=4, qkv_bias=True, use_abs_pos_emb=True, interval=2, use_rel_pos_bias=True)
+    shapes = recipe.state_shapes(128, 4, 2, 2, 224)
+    float_keys = [k for k, v in net.state_dict().items() if v.dtype.is_floating_point]
+    assert float_keys == list(shapes.keys())
+    msg = net.load_state_dict(recipe.make_params(shapes, 2023), strict=False)
+    assert not msg.unexpected_keys and all("relative_position_index" in k for k in msg.missing_keys), msg
+    net.train()
+    img = recipe.make_input(2, 224, 224, seed=55).requires_grad_(True)
+    feats = net(img)
+    assert isinstance(feats, tuple) and len(feats) == 2 and tuple(feats[0].shape) == (2, 128, 14, 14)
+    out = {"keys": np.array(float_keys), "f0": feats[0], "f1": feats[1]}
+    loss = 0
+    for i, f in enumerate(feats):
+        loss = loss + (f * recipe.loss_weights(f.shape, 400 + i)).sum()
+    loss.backward()
+    out["loss"] = loss.detach()
+    out["dimg_sum"], out["dimg_samples"] = recipe.summarize(img.grad, 2048)
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            out["nograd_" + n] = np.array([1])
+        elif p.numel() <= 4096:
+            out["g_" + n] = p.grad
+        else:
+            out["gs_%s_sum" % n], out["gs_%s_samples" % n] = recipe.summarize(p.grad, 1024)
+    save("f10_taps.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9"]
+    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10"]
     for w in which:
         globals()[w]()

@@ -82,3 +82,28 @@ def load_reference_det():
     sys.modules["ref_vit_det"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+REF_CLS = "/root/reference/RS_Tasks_Finetune/Scene_Classification/mmpretrain/models/backbones/vit_rvsa_mtp.py"
+
+
+def load_reference_cls():
+    """The mmpretrain fine-tune copy (`RVSA_MTP` returning the raw taps as NCHW, no fpn ops).  Stub: `mmpretrain.registry.MODELS`."""
+    if "ref_vit_cls" in sys.modules:
+        return sys.modules["ref_vit_cls"]
+    load_reference()
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+    pkg = types.ModuleType("mmpretrain")
+    reg = types.ModuleType("mmpretrain.registry")
+    reg.MODELS = _Reg()
+    pkg.registry = reg
+    sys.modules.setdefault("mmpretrain", pkg)
+    sys.modules.setdefault("mmpretrain.registry", reg)
+    spec = importlib.util.spec_from_file_location("ref_vit_cls", REF_CLS)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_vit_cls"] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -238,3 +238,38 @@ def test_vitdet_style_finetune_variant_vs_reference(golden, precision, tol):
         else:
             e = _check_summary(p.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], gt, 1024, n)
         assert e < (0.6 if (precision == "bf16" and "sampling" in n) else gt), (n, e)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+def test_tap_only_finetune_variant_vs_reference(golden, precision, tol):
+    """fixture f10 = the reference's mmpretrain `RVSA_MTP`: block outputs at out_indices (two here) as NCHW maps,
+    no fpn ops; fpn* / norm.* / blocks after the last tap get no gradient.  Here: mtp_amd.RVSA_MTP_taps."""
+    g = golden("f10_taps.npz")
+    net = mtp_amd.RVSA_MTP_taps(img_size=224, embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True,
+                                out_indices=[1, 3], precision=precision, feature_dtype=torch.float32, frozen_stages=-1)
+    assert [k for k, v in net.state_dict().items() if v.dtype.is_floating_point] == [str(k) for k in g["keys"]]
+    net.load_state_dict(recipe.make_params(recipe.state_shapes(128, 4, 2, 2)), strict=False)
+    net = net.cuda().train()
+    img = recipe.make_input(2, 224, 224, seed=55).cuda().requires_grad_(True)
+    feats = net(img)
+    assert isinstance(feats, tuple) and len(feats) == 2
+    assert rel_err(feats[0].cpu(), g["f0"]) < tol and rel_err(feats[1].cpu(), g["f1"]) < tol
+    loss = sum((f * recipe.loss_weights(f.shape, 400 + i).cuda()).sum() for i, f in enumerate(feats))
+    loss.backward()
+    gt = 5 * tol if precision == "fp32" else 0.35
+    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], gt, 2048, "dimg")
+    for n, p in net.named_parameters():
+        if "nograd_" + n in g:
+            assert p.grad is None, n
+        elif "g_" + n in g:
+            assert rel_err(p.grad.cpu(), g["g_" + n]) < (0.6 if (precision == "bf16" and "sampling" in n) else gt), n
+        else:
+            e = _check_summary(p.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], gt, 1024, n)
+            assert e < (0.6 if (precision == "bf16" and "sampling" in n) else gt), (n, e)
+    # open-cd's frozen stages: patch embed, pos_embed and the first block stop requiring gradients; the rest still trains
+    net.frozen_stages = 1
+    net._freeze_stages()
+    net.zero_grad()
+    sum(f.sum() for f in net(img.detach())).backward()
+    assert net.patch_embed.proj.weight.grad is None and net.pos_embed.grad is None and net.blocks[0].attn.qkv.weight.grad is None
+    assert net.blocks[1].attn.qkv.weight.grad is not None and not net.blocks[0].training and net.blocks[1].training

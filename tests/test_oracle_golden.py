@@ -248,6 +248,28 @@ def test_f9_vitdet_style_finetune_copy_fwd_and_grads(golden):
             _check_summary(v.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], 5 * TOL, 1024)
 
 
+def test_f10_tap_only_finetune_copy_fwd_and_grads(golden):
+    """fixture f10 = the reference's mmpretrain `RVSA_MTP`: the taps (here blocks 1 and 3) as NCHW maps, no fpn ops; fpn* and
+    norm.* exist in the state dict but receive no gradient."""
+    g = golden("f10_taps.npz")
+    shapes = recipe.state_shapes(128, 4, 2, 2)
+    assert list(shapes) == [str(k) for k in g["keys"]]
+    p = {k: v.requires_grad_(True) for k, v in recipe.make_params(shapes).items()}
+    img = recipe.make_input(2, 224, 224, seed=55).requires_grad_(True)
+    feats = O.backbone_forward(img, p, 4, 2, 2, [1, 3], taps_only=True)
+    assert len(feats) == 2 and rel_err(feats[0], g["f0"]) < TOL and rel_err(feats[1], g["f1"]) < TOL
+    loss = sum((f * recipe.loss_weights(f.shape, 400 + i)).sum() for i, f in enumerate(feats))
+    loss.backward()
+    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], 5 * TOL, 2048)
+    for n, v in p.items():
+        if "nograd_" + n in g:
+            assert v.grad is None and (n.startswith("fpn") or n.startswith("norm."))
+        elif "g_" + n in g:
+            assert rel_err(v.grad, g["g_" + n]) < 5 * TOL, n
+        else:
+            _check_summary(v.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], 5 * TOL, 1024)
+
+
 def test_f7_vitb_whole_forward_config1(golden):
     """BASELINE config 1: ViT-B/16 forward, batch 2, 224x224 (+ input/param gradient samples)."""
     g = golden("f7_vitb.npz")
