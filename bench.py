@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
+    ap.add_argument("--image-size", type=int, default=224, help="224 = the headline metric; 448 = what MTP actually pretrains at (use --batch 16)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,7 +134,7 @@ def main():
     ops.lib()
 
     class A:
-        image_size = 224
+        image_size = args.image_size
         use_ckpt = "False"
         precision = args.precision
     torch.manual_seed(2023)    # identical initial replicas (main_pretrain.py:107)
@@ -147,7 +148,7 @@ def main():
     trainer = DataParallelTrainer(net, lr=6e-5, weight_decay=0.05, max_norm=5.0, total_steps=1000, feature_dtype=fdt)
     torch.manual_seed(2023 + rank)   # per-rank data / drop-path streams (main_pretrain.py:517)
     B = args.batch
-    img = torch.randn(B, 3, 224, 224, device="cuda")
+    img = torch.randn(B, 3, args.image_size, args.image_size, device="cuda")
 
     def loss_and_grads(feats):
         # stand-in for the three task decoders: loss = sum_i mean(f_i), d loss / d f_i = 1 / numel(f_i), written out by hand
@@ -191,7 +192,8 @@ def main():
             traffic = None   # HBM bytes per launch of the dominant family, from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
-                traffic = pmc[dom + "_kernel"]["hbm_bytes_per_launch"] if args.model == "vit_l" and args.precision == "bf16" and B == 64 else None
+                traffic = (pmc[dom + "_kernel"]["hbm_bytes_per_launch"]
+                           if args.model == "vit_l" and args.precision == "bf16" and B == 64 and args.image_size == 224 else None)
             except Exception:
                 traffic = None
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
@@ -202,14 +204,15 @@ def main():
                                   for k, v in fams.items()})
         gf = FWD_GF_PER_IMAGE[args.model] * 3.0
         out = {
-            "metric": "images/sec pretrain step (ViT-L+RVSA, 224^2, bf16)" if args.model == "vit_l" else "images/sec pretrain step (ViT-B+RVSA, 224^2)",
+            "metric": ("images/sec pretrain step (ViT-L+RVSA, %d^2, bf16)" if args.model == "vit_l" else "images/sec pretrain step (ViT-B+RVSA, %d^2)") % args.image_size,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "%s + RVSA backbone fwd+bwd + grad all-reduce + clip + AdamW, 224x224, batch %d per GPU (BASELINE configs[2]/[3])"
-                                   % ("ViT-L" if args.model == "vit_l" else "ViT-B", B),
+            "config": {"workload": "%s + RVSA backbone fwd+bwd + grad all-reduce + clip + AdamW, %dx%d, batch %d per GPU%s"
+                                   % ("ViT-L" if args.model == "vit_l" else "ViT-B", args.image_size, args.image_size, B,
+                                      " (BASELINE configs[2]/[3])" if args.image_size == 224 else " (not the headline configuration)"),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss)},
-            "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if args.image_size == 224 else None,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

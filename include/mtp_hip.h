@@ -150,9 +150,12 @@ int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, const float*
  * o (T,C) ACT; lse (B, heads, N) f32.  logits = s*q.k + s*q.Rh[hq-hk+Hp-1] + s*q.Rw[wq-wk+Wp-1]. */
 int mtp_full_attn_fwd(const void* qkv, void* o, float* lse, int dtype, const float* rel_h, const float* rel_w,
                       int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream);
-/* drel partials: (B*heads, 2*Hp-1 + 2*Wp-1, hd) f32, reduced by mtp_reduce_rows_f32 */
+/* drel partials: (B*heads, 2*Hp-1 + 2*Wp-1, hd) f32, reduced by mtp_reduce_rows_f32.
+ * Token grids of more than 256 tokens (448^2 pretraining inputs: 28 x 28) run a three-pass f32-math backward that keeps
+ * per-query quantities in `workspace` (f32, mtp_full_attn_bwd_workspace_floats(...) elements; NULL / 0 for N <= 256). */
+int64_t mtp_full_attn_bwd_workspace_floats(int64_t B, int64_t Hp, int64_t Wp, int64_t heads);
 int mtp_full_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int dtype,
-                      const float* rel_h, const float* rel_w, float* drel_part,
+                      const float* rel_h, const float* rel_w, float* drel_part, float* workspace,
                       int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream);
 
 /* RVSA sampling heads, stage 1 (VIT:347 zero pad, AvgPool2d(7,7), LeakyReLU): x (T,C) ACT -> avg, pooled (B*nh*nw, C) f32 */

@@ -55,7 +55,8 @@ SIGNATURES = {
     "mtp_axpy_f32": (i32, [p, p, f32, i64, p]),
     "mtp_scale_rows_cast": (i32, [p, p, i32, p, i64, i64, i64, p]),
     "mtp_full_attn_fwd": (i32, [p, p, p, i32, p, p, i64, i64, i64, i64, i64, f32, p]),
-    "mtp_full_attn_bwd": (i32, [p, p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
+    "mtp_full_attn_bwd_workspace_floats": (i64, [i64, i64, i64, i64]),
+    "mtp_full_attn_bwd": (i32, [p, p, p, p, p, i32, p, p, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_rvsa_pool_fwd": (i32, [p, i32, p, p, i64, i64, i64, i64, p]),
     "mtp_rvsa_pool_bwd": (i32, [p, p, p, i32, i32, i64, i64, i64, i64, p]),
     "mtp_small_linear_fwd": (i32, [p, p, p, p, i64, i64, i64, p]),

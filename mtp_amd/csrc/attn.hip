@@ -292,6 +292,164 @@ __global__ __launch_bounds__(256) void full_attn_bwd_kernel(const T* __restrict_
 }
 
 // =====================================================================================================================
+// Full attention backward for token grids beyond one workgroup (N > 256: 448^2 pretraining inputs -> 28 x 28, 512^2 -> 32 x 32).
+// Same f32 math as the kernel above, split into three launches with the per-query quantities in a caller workspace:
+//   ws floats per (image, head): qr[Hp+Wp][N] | dqr[Hp+Wp][N] | delta[N]
+// Functional path (VALU); the MFMA kernels cover N <= 256, a flash-style MFMA version of this is the next step.
+// =====================================================================================================================
+// pass Q: thread = query (blockIdx.y * 256 + tid), streams all keys.  LDS: qr[(Hp+Wp)*256] | dqr[(Hp+Wp)*256] | cA | cB
+template <typename T>
+__global__ __launch_bounds__(256) void full_attn_bwdN_q_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ dout,
+                                                              const float* __restrict__ lse, T* __restrict__ dqkv,
+                                                              const float* __restrict__ rel_h, const float* __restrict__ rel_w, float* __restrict__ ws,
+                                                              int N, int Hp, int Wp, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = Hp + Wp;
+    float* qr = sm;
+    float* dqr = qr + HW * 256;
+    float* cA = dqr + HW * 256;
+    float* cB = cA + KT * HD;
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int C = heads * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)b * N * ld + h * HD;
+    const T* dob = dout + (int64_t)b * N * C + h * HD;
+    const int n = blockIdx.y * 256 + tid;
+    const bool valid = n < N;
+    const int nc = valid ? n : N - 1;
+    const int hq = nc / Wp, wq = nc % Wp;
+    float* wq_r = ws + (int64_t)bh * (2 * HW + 1) * N;   // qr rows, then dqr rows, then delta
+    float qs[HD], dO[HD], dq[HD];
+    load_row(base + (int64_t)nc * ld, qs, scale);
+    load_row(dob + (int64_t)nc * C, dO);
+    float dl = 0.f;
+    {
+        float ov[HD];
+        load_row(o + ((int64_t)b * N + nc) * C + h * HD, ov);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dl += dO[d] * ov[d];
+    }
+    const float ls = lse[(int64_t)bh * N + nc];
+    for (int kh = 0; kh < Hp; ++kh) {
+        qr[kh * 256 + tid] = dot_glb(qs, rel_h + (hq - kh + Hp - 1) * HD);
+        dqr[kh * 256 + tid] = 0.f;
+    }
+    for (int kw = 0; kw < Wp; ++kw) {
+        qr[(Hp + kw) * 256 + tid] = dot_glb(qs, rel_w + (wq - kw + Wp - 1) * HD);
+        dqr[(Hp + kw) * 256 + tid] = 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+    for (int c0 = 0; c0 < N; c0 += KT) {
+        const int cnt = (N - c0) < KT ? (N - c0) : KT;
+        __syncthreads();
+        stage_rows(base + C, ld, c0, cnt, cA, 1.0f, tid);
+        stage_rows(base + 2 * C, ld, c0, cnt, cB, 1.0f, tid);
+        __syncthreads();
+        int hj = c0 / Wp, wj = c0 % Wp;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float s = dot_lds(qs, cA + jj * HD) + qr[hj * 256 + tid] + qr[(Hp + wj) * 256 + tid];
+            const float p = valid ? __expf(s - ls) : 0.f;
+            const float ds = p * (dot_lds(dO, cB + jj * HD) - dl);
+            axpy_lds(dq, ds, cA + jj * HD);
+            dqr[hj * 256 + tid] += ds;
+            dqr[(Hp + wj) * 256 + tid] += ds;
+            if (++wj == Wp) { wj = 0; ++hj; }
+        }
+    }
+    if (valid) {
+        for (int kh = 0; kh < Hp; ++kh) axpy_glb(dq, dqr[kh * 256 + tid], rel_h + (hq - kh + Hp - 1) * HD);
+        for (int kw = 0; kw < Wp; ++kw) axpy_glb(dq, dqr[(Hp + kw) * 256 + tid], rel_w + (wq - kw + Wp - 1) * HD);
+        store_row(dqkv + ((int64_t)b * N + n) * ld + h * HD, dq, scale);
+        for (int r = 0; r < HW; ++r) {
+            wq_r[(int64_t)r * N + n] = qr[r * 256 + tid];
+            wq_r[(int64_t)(HW + r) * N + n] = dqr[r * 256 + tid];
+        }
+        wq_r[(int64_t)2 * HW * N + n] = dl;
+    }
+}
+
+// pass T: rel-pos table gradients.  grid (B*heads, ceil(RT/4)); thread = (table row blockIdx.y*4 + tid>>6, channel tid&63)
+template <typename T>
+__global__ __launch_bounds__(256) void full_attn_bwdN_t_kernel(const T* __restrict__ qkv, const float* __restrict__ ws, float* __restrict__ drel_part,
+                                                              int N, int Hp, int Wp, int heads, float scale) {
+    const int tid = threadIdx.x, d = tid & 63, r = blockIdx.y * 4 + (tid >> 6);
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int C = heads * HD, HW = Hp + Wp;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)b * N * ld + h * HD;
+    const float* dqr = ws + (int64_t)bh * (2 * HW + 1) * N + (int64_t)HW * N;
+    const int RH = 2 * Hp - 1, RT = RH + 2 * Wp - 1;
+    if (r >= RT) return;
+    float acc = 0.f;
+    int hn = 0, wn = 0;
+    for (int n = 0; n < N; ++n) {
+        const int kk = r < RH ? hn - r + Hp - 1 : wn - (r - RH) + Wp - 1;
+        const int lim = r < RH ? Hp : Wp;
+        if (kk >= 0 && kk < lim) acc += dqr[(int64_t)((r < RH ? 0 : Hp) + kk) * N + n] * (scale * Elem<T>::load(base + (int64_t)n * ld + d));
+        if (++wn == Wp) { wn = 0; ++hn; }
+    }
+    drel_part[((int64_t)bh * RT + r) * HD + d] = acc;
+}
+
+// pass K: thread = key (blockIdx.y * 256 + tid), streams all queries.  LDS: cA | cB | qrt[(Hp+Wp)][KT] | ls[KT] | dl[KT]
+template <typename T>
+__global__ __launch_bounds__(256) void full_attn_bwdN_k_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                              T* __restrict__ dqkv, const float* __restrict__ ws,
+                                                              int N, int Hp, int Wp, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = Hp + Wp;
+    float* cA = sm;
+    float* cB = cA + KT * HD;
+    float* qrt = cB + KT * HD;
+    float* lst = qrt + HW * KT;
+    float* dlt = lst + KT;
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int C = heads * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)b * N * ld + h * HD;
+    const T* dob = dout + (int64_t)b * N * C + h * HD;
+    const float* wq_r = ws + (int64_t)bh * (2 * HW + 1) * N;
+    const int key = blockIdx.y * 256 + tid;
+    const bool valid = key < N;
+    const int kc = valid ? key : N - 1;
+    const int hk = kc / Wp, wk = kc % Wp;
+    float kj[HD], vj[HD], dk[HD], dv[HD];
+    load_row(base + C + (int64_t)kc * ld, kj);
+    load_row(base + 2 * C + (int64_t)kc * ld, vj);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int c0 = 0; c0 < N; c0 += KT) {
+        const int cnt = (N - c0) < KT ? (N - c0) : KT;
+        __syncthreads();
+        stage_rows(base, ld, c0, cnt, cA, scale, tid);          // scaled queries
+        stage_rows(dob, (int64_t)C, c0, cnt, cB, 1.0f, tid);    // dO rows
+        for (int i = tid; i < HW * KT; i += 256) {
+            const int r = i / KT, nn = i % KT;
+            qrt[i] = nn < cnt ? wq_r[(int64_t)r * N + c0 + nn] : 0.f;
+        }
+        if (tid < KT) {
+            lst[tid] = tid < cnt ? lse[(int64_t)bh * N + c0 + tid] : 0.f;
+            dlt[tid] = tid < cnt ? wq_r[(int64_t)2 * HW * N + c0 + tid] : 0.f;
+        }
+        __syncthreads();
+        for (int nn = 0; nn < cnt; ++nn) {
+            const float s = dot_lds(kj, cA + nn * HD) + qrt[hk * KT + nn] + qrt[(Hp + wk) * KT + nn];
+            const float p = valid ? __expf(s - lst[nn]) : 0.f;
+            const float ds = p * (dot_lds(vj, cB + nn * HD) - dlt[nn]);
+            axpy_lds(dk, ds, cA + nn * HD);
+            axpy_lds(dv, p, cB + nn * HD);
+        }
+    }
+    if (valid) {
+        store_row(dqkv + ((int64_t)b * N + key) * ld + C + h * HD, dk);
+        store_row(dqkv + ((int64_t)b * N + key) * ld + 2 * C + h * HD, dv);
+    }
+}
+
+// =====================================================================================================================
 // RVSA geometry shared by forward and backward
 // =====================================================================================================================
 struct RvsaGeom {
@@ -693,8 +851,13 @@ extern "C" int mtp_full_attn_fwd(const void* qkv, void* o, float* lse, int dtype
     return mtp_launch_status();
 }
 
+extern "C" int64_t mtp_full_attn_bwd_workspace_floats(int64_t B, int64_t Hp, int64_t Wp, int64_t heads) {
+    const int64_t N = Hp * Wp;
+    return N > 256 ? B * heads * (2 * (Hp + Wp) + 1) * N : 0;
+}
+
 extern "C" int mtp_full_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int dtype,
-                                 const float* rel_h, const float* rel_w, float* drel_part,
+                                 const float* rel_h, const float* rel_w, float* drel_part, float* workspace,
                                  int64_t B, int64_t Hp, int64_t Wp, int64_t heads, int64_t hd, float scale, mtp_stream_t stream) {
     if (!qkv || !o || !dout || !lse || !dqkv || !rel_h || !rel_w || !drel_part || B <= 0 || heads <= 0) return MTP_ERR_ARG;
     if (hd != HD) return MTP_ERR_UNSUPPORTED;
@@ -703,7 +866,32 @@ extern "C" int mtp_full_attn_bwd(const void* qkv, const void* o, const void* dou
         if (rc != MTP_ERR_UNSUPPORTED) return rc;
     }
     const int N = (int)(Hp * Wp);
-    if (N > 256 || (2 * Hp - 1) + (2 * Wp - 1) > 4 * MAXR) return MTP_ERR_UNSUPPORTED;   // single-workgroup backward (224^2..256^2 inputs)
+    if (N > 256) {   // multi-workgroup three-pass backward (448^2 / 512^2 inputs); needs the caller's workspace
+        if (!workspace) return MTP_ERR_ARG;
+        const int HW = (int)(Hp + Wp), RT = (int)(2 * Hp - 1 + 2 * Wp - 1);
+        const size_t lds_q = sizeof(float) * (size_t)(2 * HW * 256 + 2 * KT * HD);
+        const size_t lds_k = sizeof(float) * (size_t)(2 * KT * HD + HW * KT + 2 * KT);
+        if (lds_q > 160 * 1024) return MTP_ERR_UNSUPPORTED;
+        hipStream_t s = (hipStream_t)stream;
+        dim3 gq((unsigned)(B * heads), (unsigned)((N + 255) / 256)), gt((unsigned)(B * heads), (unsigned)((RT + 3) / 4)), block(256);
+        if (dtype == MTP_BF16) {
+            (void)hipFuncSetAttribute((const void*)full_attn_bwdN_q_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+            hipLaunchKernelGGL((full_attn_bwdN_q_kernel<bf16_t>), gq, block, lds_q, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqkv,
+                               rel_h, rel_w, workspace, N, (int)Hp, (int)Wp, (int)heads, scale);
+            hipLaunchKernelGGL((full_attn_bwdN_t_kernel<bf16_t>), gt, block, 0, s, (const bf16_t*)qkv, (const float*)workspace, drel_part, N, (int)Hp, (int)Wp, (int)heads, scale);
+            hipLaunchKernelGGL((full_attn_bwdN_k_kernel<bf16_t>), gq, block, lds_k, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, (bf16_t*)dqkv,
+                               (const float*)workspace, N, (int)Hp, (int)Wp, (int)heads, scale);
+        } else {
+            (void)hipFuncSetAttribute((const void*)full_attn_bwdN_q_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+            hipLaunchKernelGGL((full_attn_bwdN_q_kernel<float>), gq, block, lds_q, s, (const float*)qkv, (const float*)o, (const float*)dout, lse, (float*)dqkv,
+                               rel_h, rel_w, workspace, N, (int)Hp, (int)Wp, (int)heads, scale);
+            hipLaunchKernelGGL((full_attn_bwdN_t_kernel<float>), gt, block, 0, s, (const float*)qkv, (const float*)workspace, drel_part, N, (int)Hp, (int)Wp, (int)heads, scale);
+            hipLaunchKernelGGL((full_attn_bwdN_k_kernel<float>), gq, block, lds_k, s, (const float*)qkv, (const float*)dout, lse, (float*)dqkv,
+                               (const float*)workspace, N, (int)Hp, (int)Wp, (int)heads, scale);
+        }
+        return mtp_launch_status();
+    }
+    if ((2 * Hp - 1) + (2 * Wp - 1) > 4 * MAXR) return MTP_ERR_UNSUPPORTED;   // single-workgroup backward (224^2..256^2 inputs)
     const size_t lds = sizeof(float) * (size_t)(2 * (Hp + Wp) * 256 + 512 + 2 * KT * HD);
     if (lds > 160 * 1024) return MTP_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(B * heads)), block(256);

@@ -292,7 +292,9 @@ def full_attn_bwd(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, 
     hd = qkv.shape[1] // (3 * heads)
     rt = (2 * Hp - 1) + (2 * Wp - 1)
     part = torch.empty(B * heads, rt * hd, device=qkv.device, dtype=torch.float32)
-    check(lib().mtp_full_attn_bwd(_p(qkv), _p(o), _p(dout), _f32(lse), _p(dqkv), _dt(qkv), _f32(rel_h), _f32(rel_w), _p(part),
+    nws = lib().mtp_full_attn_bwd_workspace_floats(B, Hp, Wp, heads)     # > 0 beyond 256 tokens (three-pass backward)
+    ws = torch.empty(nws, device=qkv.device, dtype=torch.float32) if nws else None
+    check(lib().mtp_full_attn_bwd(_p(qkv), _p(o), _p(dout), _f32(lse), _p(dqkv), _dt(qkv), _f32(rel_h), _f32(rel_w), _p(part), _p(ws),
                                   B, Hp, Wp, heads, hd, scale, _s()), "mtp_full_attn_bwd")
     nh_ = (2 * Hp - 1) * hd   # per-(image, head) partials -> the two parameters, no staging copy
     reduce_rows(part[:, :nh_], drel_h, accumulate)

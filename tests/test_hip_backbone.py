@@ -273,3 +273,31 @@ def test_tap_only_finetune_variant_vs_reference(golden, precision, tol):
     sum(f.sum() for f in net(img.detach())).backward()
     assert net.patch_embed.proj.weight.grad is None and net.pos_embed.grad is None and net.blocks[0].attn.qkv.weight.grad is None
     assert net.blocks[1].attn.qkv.weight.grad is not None and not net.blocks[0].training and net.blocks[1].training
+
+
+def test_448_pretraining_resolution_forward_and_gradients_vs_oracle():
+    """448x448 (the resolution MTP really pretrains at): 28x28 = 784 tokens per image -> RVSA with 16 windows and
+    full attention beyond one workgroup (generic forward + three-pass backward kernels); fp32 mode vs the oracle's autograd."""
+    kw = dict(img_size=448, embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True, out_indices=[0, 1, 2, 3])
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(precision="fp32", feature_dtype=torch.float32, **kw)
+    sd = recipe.make_params({k: v.shape for k, v in net.state_dict().items() if v.dtype.is_floating_point}, seed=21)
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().train()
+    img = recipe.make_input(1, 448, 448, seed=8)
+    x = img.cuda().requires_grad_(True)
+    feats = net(x)
+    assert [tuple(f.shape) for f in feats] == [(1, 128, 112, 112), (1, 128, 56, 56), (1, 128, 28, 28), (1, 128, 14, 14)]
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in net.state_dict().items()}
+    xr = img.clone().requires_grad_(True)
+    ref = O.backbone_forward(xr, p, 4, 2, 2, [0, 1, 2, 3])
+    ws = [recipe.loss_weights(f.shape, 500 + i) for i, f in enumerate(ref)]
+    for a, b in zip(feats, ref):
+        assert rel_err(a.cpu(), b) < 1e-3
+    sum((f * w.cuda()).sum() for f, w in zip(feats, ws)).backward()
+    sum((f * w).sum() for f, w in zip(ref, ws)).backward()
+    assert rel_err(x.grad.cpu(), xr.grad) < 5e-3
+    for n, q in net.named_parameters():
+        if p[n].grad is None:
+            assert q.grad is None, n
+        else:
+            assert rel_err(q.grad.cpu(), p[n].grad) < 5e-3, n

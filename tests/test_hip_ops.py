@@ -288,8 +288,8 @@ def _attn_inputs(T, C, dtype, seed=0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("Hp,Wp", [(14, 14), (9, 12)])
-def test_full_attention_fwd_bwd(ops, dtype, Hp, Wp):
+@pytest.mark.parametrize("Hp,Wp", [(14, 14), (9, 12), (28, 28), (17, 19), (32, 32)])   # 28x28 = 448^2 pretraining inputs, 32x32 = 512^2:
+def test_full_attention_fwd_bwd(ops, dtype, Hp, Wp):                                    # beyond 256 tokens -> multi-workgroup kernels
     B, heads, hd = 2, 2, 64
     C, N = heads * hd, Hp * Wp
     T = B * N
