@@ -120,13 +120,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=F
                                   _f32(dres), _f32(extra), _p(dx), _dt(dx), _p(dx_copy), (_dt(dx_copy) if dx_copy is not None else 0),
                                   _f32(copy_scale), rows_per_sample, part.data_ptr(), part.data_ptr() + 4 * Cc, 2 * Cc, rows, Cc, _s()),
           "mtp_layernorm_bwd")
-    if (dbeta.data_ptr() == dgamma.data_ptr() + 4 * Cc and dgamma.is_contiguous() and dbeta.is_contiguous()
-            and dgamma.untyped_storage().data_ptr() == dbeta.untyped_storage().data_ptr()):
-        # weight and bias gradient adjacent in one buffer (the flat gradient buffer of mtp_amd.parallel): ONE reduction launch
-        reduce_rows(part, dgamma.as_strided((2 * Cc,), (1,)), accumulate)
-    else:
-        reduce_rows(part[:, :Cc], dgamma, accumulate)
-        reduce_rows(part[:, Cc:], dbeta, accumulate)
+    # weight and bias gradient adjacent in one buffer (the flat gradient buffer of mtp_amd.parallel) -> ONE reduction launch
+    _reduce_pair(part, Cc, dgamma, dbeta, accumulate)
     return dx
 
 
@@ -139,6 +134,21 @@ def reduce_rows(part, out, accumulate=False):
     assert out.numel() == cols
     check(lib().mtp_reduce_rows_f32(part.data_ptr(), part.stride(0), _f32(out), rows, cols, int(accumulate), _s()), "mtp_reduce_rows_f32")
     return out
+
+
+def _adjacent(a, b):
+    """b starts right where a ends, in the same storage (true for consecutive parameters' gradients in the flat buffer)"""
+    return (a.is_contiguous() and b.is_contiguous() and b.data_ptr() == a.data_ptr() + 4 * a.numel()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())
+
+
+def _reduce_pair(part, n0, out0, out1, accumulate):
+    """part (rows, n0 + n1) f32: column sums of [:, :n0] -> out0 and of [:, n0:] -> out1; one launch when out1 follows out0 in memory"""
+    if _adjacent(out0, out1) and out0.numel() == n0:
+        reduce_rows(part, out0.as_strided((part.shape[1],), (1,)), accumulate)
+    else:
+        reduce_rows(part[:, :n0], out0, accumulate)
+        reduce_rows(part[:, n0:], out1, accumulate)
 
 
 def copy_segments(srcs, dsts):
@@ -296,9 +306,7 @@ def full_attn_bwd(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, 
     ws = torch.empty(nws, device=qkv.device, dtype=torch.float32) if nws else None
     check(lib().mtp_full_attn_bwd(_p(qkv), _p(o), _p(dout), _f32(lse), _p(dqkv), _dt(qkv), _f32(rel_h), _f32(rel_w), _p(part), _p(ws),
                                   B, Hp, Wp, heads, hd, scale, _s()), "mtp_full_attn_bwd")
-    nh_ = (2 * Hp - 1) * hd   # per-(image, head) partials -> the two parameters, no staging copy
-    reduce_rows(part[:, :nh_], drel_h, accumulate)
-    reduce_rows(part[:, nh_:], drel_w, accumulate)
+    _reduce_pair(part, (2 * Hp - 1) * hd, drel_h, drel_w, accumulate)   # per-(image, head) partials -> the two parameters
     return dqkv
 
 
@@ -346,8 +354,7 @@ def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, dre
     tab_part = torch.empty(B * nh * nw, heads * 169, device=dev, dtype=torch.float32)
     check(lib().mtp_rvsa_attn_bwd(_p(qkv), _f32(samp), _p(o), _p(dout), _f32(lse), _p(dqkv), _p(dkv), _f32(dsamp), _p(rel_part), _p(tab_part),
                                   _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table), B, Hp, Wp, heads, hd, scale, _s()), "mtp_rvsa_attn_bwd")
-    reduce_rows(rel_part[:, :13 * hd], drel_h, accumulate)   # per-workgroup partials -> the parameters, no staging copies
-    reduce_rows(rel_part[:, 13 * hd:], drel_w, accumulate)
+    _reduce_pair(rel_part, 13 * hd, drel_h, drel_w, accumulate)   # per-workgroup partials -> the parameters, no staging copies
     reduce_rows(tab_part, dtable, accumulate)
     return dqkv
 
