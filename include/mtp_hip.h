@@ -64,7 +64,8 @@ typedef struct {
     int variant;        /* 0 = default kernels and heuristics; other values force A/B choices (debug): bit0 NT register-
                          * staged loads; bits1-2 tile order (1 plain, 2 grouped / M-fastest, 3 row-major); bit3 NT
                          * double-buffered / TN single-stage; bit4 TN register-transposing; bit5 / bit6 force / forbid
-                         * the 256x128 8-wave NT tile.  All variants of one problem give bit-identical results. */
+                         * the 256x128 8-wave NT tile; bit7 NT at 5 workgroups per CU (complete tiles only).
+                         * All variants of one problem give bit-identical results. */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
 } mtp_gemm_args;

@@ -318,6 +318,55 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// Same single-stage structure at FIVE workgroups per CU (5 x 32 KiB = the whole LDS, <= 96 VGPRs): the tile loads are issued as
+// `global_load_lds_dwordx4 voffset, s[base]` from inline asm -- one 32-bit per-lane offset per operand plus scalar bases,
+// instead of the eight 64-bit per-lane pointers hipcc keeps live for the builtin (which spill at 96 VGPRs).  Complete tiles,
+// operands below 4 GiB.  (A/B: variant bit 7.)
+template <typename T, typename Tout, int EPI>
+__global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void gemm_nt_sb5_kernel(KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = Elem<T>::kPerChunk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    int m0, n0;
+    if (p.order & 2) {
+        const int tiles_m = (int)gridDim.x / p.tiles_n, per = 8 * p.tiles_n;
+        const int grp = tile / per, r = tile - grp * per;
+        const int gm = (tiles_m - grp * 8) < 8 ? (tiles_m - grp * 8) : 8;
+        m0 = (grp * 8 + r % gm) * BM;
+        n0 = (r / gm) * BN;
+    } else {
+        m0 = (tile / p.tiles_n) * BM;
+        n0 = (tile % p.tiles_n) * BN;
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int row0 = wave * 32 + (lane >> 3), chunk = (lane & 7) ^ (row0 & 7);   // rows row0 + 8i share the swizzle
+    const uint32_t offA = (uint32_t)(((int64_t)(m0 + row0) * p.lda + chunk * E) * (int64_t)sizeof(T));
+    const uint32_t offB = (uint32_t)(((int64_t)(n0 + row0) * p.ldb + chunk * E) * (int64_t)sizeof(T));
+    const int64_t strA = 8 * p.lda * (int64_t)sizeof(T), strB = 8 * p.ldb * (int64_t)sizeof(T);
+    const uint32_t ldsA = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + wave * 32 * ROW_BYTES;
+    const uint32_t ldsB = ldsA + OPER_BYTES;
+    for (int kt = 0; kt < p.k_tiles; ++kt) {
+        const char* ka = p.A + (int64_t)kt * 8 * E * (int64_t)sizeof(T);
+        const char* kb = p.B + (int64_t)kt * 8 * E * (int64_t)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(offA), "s"(ka + i * strA), "s"(ldsA + i * 8 * ROW_BYTES) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(offB), "s"(kb + i * strB), "s"(ldsB + i * 8 * ROW_BYTES) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute_stage<T>(smem, smem + OPER_BYTES, acc, wm, wn, lane);
+        __syncthreads();
+    }
+    epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
 // 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), one 48 KiB stage, 2 workgroups per CU: same occupancy and per-wave work as
 // the kernel above with 25 % fewer L2->LDS bytes per flop (A tile shared by 2 x more columns).  Selected for wide N only
 // (the tile count of N = 1024 problems would leave CUs idle).
@@ -716,6 +765,13 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     // gets at least one: measured on M = 12544, N = 1024 (392 workgroups): +7.5 % (K = 1024), +17..18 % (K = 3072, 4096; up to
     // 1095 TF/s); with several rounds (N = 3072: equal, N = 4096: -5 %) the coarser tiles lose to the tail.  Variant bit 5
     // forces it, bit 6 forbids it.
+    const bool fits32 = (uint64_t)a->M * (uint64_t)a->lda * sizeof(T) < (1ull << 32) && (uint64_t)a->N * (uint64_t)a->ldb * sizeof(T) < (1ull << 32);
+    const bool full_tiles = (a->M % BM == 0) && (a->N % BN == 0);
+    if (glds && (a->variant & 128) && full_tiles && fits32) {   // 5 workgroups per CU (A/B)
+        if (ord == 0) k.order = k.tiles_n > 8 ? 2 : 0;
+        hipLaunchKernelGGL((gemm_nt_sb5_kernel<T, Tout, EPI>), grid, block, STAGE_BYTES, stream, k);
+        return mtp_launch_status();
+    }
     const int tiles_m8 = (k.M + NT8_BM - 1) / NT8_BM;
     const bool one_round = tiles_m8 * k.tiles_n >= 256 && tiles_m8 * k.tiles_n <= 512;
     if (glds && !(a->variant & 8) && ((a->variant & 32) || (one_round && !(a->variant & 64)))) {

@@ -85,17 +85,17 @@ def test_gemm_nt_epilogues(ops, dtype):
 def test_gemm_nt_tile_variants_bit_identical(ops, dtype):
     """the 256x128 / 8-wave kernel (variant 32; picked automatically for one-round problems such as M = 12544, N = 1024) and the
     tile orders accumulate in the same k order as the default kernel: every epilogue must come out bit-identical"""
-    M, N, K, rps = 1000, 384, 256, 250
+    M, N, K, rps = 1024, 384, 256, 256   # complete 128-row tiles, so that variant 128 (5 workgroups per CU, asm LDS-DMA loads) applies
     a, w, b = dev(rnd(M, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.2), dtype), dev(rnd(N, seed=2))
     res, rs, uu = dev(rnd(M, N, seed=3)), dev(torch.tensor([0.0, 1.1, 0.9, 1.0])), dev(rnd(M, N, dtype=dtype, seed=5), dtype)
     outs = {}
-    for v in (0, 32, 36, 4, 64):
+    for v in (0, 32, 36, 4, 64, 128, 132):
         u = e(M, N, dtype=dtype)
         h = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU, bias=b, aux=u, variant=v)
         r = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=v)
         d = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_DGELU, aux=uu, variant=v)
         outs[v] = (u, h, r, d)
-    for v in (32, 36, 4, 64):
+    for v in (32, 36, 4, 64, 128, 132):
         for x, y in zip(outs[0], outs[v]):
             assert torch.equal(x, y), v
 
