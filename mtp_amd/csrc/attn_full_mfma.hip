@@ -185,6 +185,127 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const bf16_t* __rest
 }
 
 // ===================================================================================================================
+// forward beyond 256 tokens (448^2 pretraining inputs: 784): flash-style.  Workgroup = 64 queries of one (image, head)
+// (wave = one 16-query tile), loop over blocks of 256 keys with an online softmax; per block the same S^T = K.Q^T /
+// in-lane softmax / O^T = V^T.P^T scheme as above.  Table rows up to 64 per axis (Hp, Wp <= 32).
+// dynamic LDS: Ks[256*128] | Vt[64*FTPV] | QR[4 waves][128][16] f32 | kpos[256] u32
+// ===================================================================================================================
+constexpr int FKB = 256;
+constexpr int FTPV = FKB * 2 + 8;
+
+__global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+                                                                 const float* __restrict__ rel_h, const float* __restrict__ rel_w,
+                                                                 int N, int Hp, int Wp, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    char* Ks = sm;
+    char* Vt = Ks + FKB * 128;
+    float* QRall = reinterpret_cast<float*>(Vt + 64 * FTPV);
+    uint32_t* kpos = reinterpret_cast<uint32_t*>(QRall + 4 * 128 * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, gq = lane >> 4;
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int C = heads * HD, RH = 2 * Hp - 1, RW = 2 * Wp - 1;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
+    float* QR = QRall + wave * 128 * 16;
+    const int n = 16 * (blockIdx.y * 4 + wave) + fr;
+    const bool nv = n < N;
+    const int nc = nv ? n : N - 1;
+    uint4 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = row_frag(base, ld, nc, nv, ks * 32 + gq * 8);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {   // q.Rh / q.Rw for every table row: one MFMA tile row each, exchanged through LDS
+        f32x4_t ah = {0.f, 0.f, 0.f, 0.f}, aw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            ah = mma(table_frag(rel_h, 16 * rt + fr, RH, ks * 32 + gq * 8), qf[ks], ah);
+            aw = mma(table_frag(rel_w, 16 * rt + fr, RW, ks * 32 + gq * 8), qf[ks], aw);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            QR[(16 * rt + 4 * gq + rr) * 16 + fr] = ah[rr];
+            QR[(64 + 16 * rt + 4 * gq + rr) * 16 + fr] = aw[rr];
+        }
+    }
+    const int hq = nc / Wp + Hp - 1, wq = nc % Wp + Wp - 1;
+    float m = -INFINITY, l = 0.f;
+    f32x4_t oa[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nblk = (N + FKB - 1) / FKB;
+    for (int jb = 0; jb < nblk; ++jb) {
+        const int kb0 = jb * FKB, rem = N - kb0;
+        __syncthreads();   // the previous block's K / V^T reads are done (first pass: the QR tiles are visible)
+        stage_rows_swz(base + C + (int64_t)kb0 * ld, ld, rem, FKB, Ks, tid);
+        stage_rows_t(base + 2 * C + (int64_t)kb0 * ld, ld, rem, FKB, FTPV, Vt, tid);
+        {
+            const int key = kb0 + tid < N ? kb0 + tid : N - 1;
+            kpos[tid] = (uint32_t)(key / Wp) | ((uint32_t)(key % Wp) << 8);
+        }
+        __syncthreads();
+        const int keys = rem < FKB ? rem : FKB, tiles = (keys + 15) / 16, kkb = (keys + 31) / 32;
+        f32x4_t s[16];
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+            s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (kt < tiles) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) s[kt] = mma(ld16(Ks + swz(16 * kt + fr, ks * 4 + gq)), qf[ks], s[kt]);
+            }
+        }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kl = 16 * kt + 4 * gq + r;
+                const uint32_t kp = kpos[kl];
+                float v = scale * (s[kt][r] + QR[(hq - (int)(kp & 0xffu)) * 16 + fr] + QR[(64 + wq - (int)(kp >> 8)) * 16 + fr]);
+                v = kb0 + kl < N ? v : -INFINITY;
+                s[kt][r] = v;
+                bm = fmaxf(bm, v);
+            }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mnew = fmaxf(m, bm);
+        const float alpha = __expf(m - mnew);   // first block: exp(-inf) = 0
+        float lb = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[kt][r] - mnew);
+                s[kt][r] = p;
+                lb += p;
+            }
+        lb += __shfl_xor(lb, 16, 64);
+        lb += __shfl_xor(lb, 32, 64);
+        l = l * alpha + lb;
+        m = mnew;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oa[dt] = f32x4_t{oa[dt][0] * alpha, oa[dt][1] * alpha, oa[dt][2] * alpha, oa[dt][3] * alpha};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (kk < kkb) {
+                const uint4 pf = pack_bf16x8(s[2 * kk][0], s[2 * kk][1], s[2 * kk][2], s[2 * kk][3], s[2 * kk + 1][0], s[2 * kk + 1][1], s[2 * kk + 1][2], s[2 * kk + 1][3]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const char* row = Vt + (16 * dt + fr) * FTPV;
+                    oa[dt] = mma(ld8x2(row + (32 * kk + 4 * gq) * 2, row + (32 * kk + 16 + 4 * gq) * 2), pf, oa[dt]);
+                }
+            }
+        }
+    }
+    if (nv) {
+        const float inv = 1.0f / l;
+        bf16_t* op = o + ((int64_t)b * N + n) * C + h * HD + 4 * gq;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4(op + 16 * dt, make_float4(oa[dt][0] * inv, oa[dt][1] * inv, oa[dt][2] * inv, oa[dt][3] * inv));
+        if (gq == 0) lse[(int64_t)bh * N + n] = m + __logf(l);
+    }
+}
+
+// ===================================================================================================================
 // backward A: dQ and the rel-pos table gradients.
 // dynamic LDS: Ks | Vs (16NT x 128 each) | Kt[64*TPV] | QR[4][64][16] f32 | dQR[4][64][16] f32 | Qtt[4][64*40 B] | kpos[NP2] | E[2][KK][64] x16 B
 // ===================================================================================================================
@@ -570,7 +691,15 @@ bool make_fgeom(int64_t Hp, int64_t Wp, int64_t heads, FGeom& g) {
 int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* rel_h, const float* rel_w,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     FGeom g;
-    if (!make_fgeom(Hp, Wp, heads, g)) return MTP_ERR_UNSUPPORTED;
+    if (!make_fgeom(Hp, Wp, heads, g)) {
+        const int64_t N = Hp * Wp;
+        if (N <= 256 || Hp > 32 || Wp > 32 || getenv("MTP_NO_FLASH_ATTN")) return MTP_ERR_UNSUPPORTED;
+        const size_t lds = (size_t)FKB * 128 + (size_t)64 * FTPV + 4 * 128 * 16 * 4 + FKB * 4;   // flash-style forward, 64 queries per workgroup
+        (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(full_fwd_flash_mfma_kernel, dim3((unsigned)(B * heads), (unsigned)((N + 63) / 64)), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse,
+                           rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
+        return mtp_launch_status();
+    }
     const size_t lds = (size_t)g.NT * 16 * 128 + (size_t)64 * g.TPV + 4 * 64 * 16 * 4 + (size_t)g.NP2 * 4;
     (void)hipFuncSetAttribute((const void*)full_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(full_fwd_mfma_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, g, scale);
