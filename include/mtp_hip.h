@@ -68,6 +68,9 @@ typedef struct {
                          * All variants of one problem give bit-identical results. */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
+    int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them
+                         * later with mtp_sum_partials_batch (one launch for the weight gradients of a whole block) */
+    int pad_;
 } mtp_gemm_args;
 
 /* y = x W^T (+epilogue): nn.Linear fwd/dgrad (VIT:50,52,78,87,256,262), patch-embed conv as GEMM (VIT:529),
@@ -75,6 +78,10 @@ typedef struct {
 int mtp_gemm_nt(const mtp_gemm_args* args, mtp_stream_t stream);
 /* weight gradient: C[m][n] = sum_k A[k][m] * B[k][n]  (dW = dY^T X), f32 output. */
 int mtp_gemm_tn(const mtp_gemm_args* args, mtp_stream_t stream);
+/* out[i] = sum over `splits[i]` partial tiles of numel[i] f32 each, stored back to back at parts[i] -- the deferred split-K
+ * reductions of up to MTP_MAX_SEGMENTS weight-gradient GEMMs (args.defer_sum) in one launch.  Host arrays. */
+int mtp_sum_partials_batch(const float* const* parts, float* const* outs, const int64_t* numel, const int* splits, int count,
+                           mtp_stream_t stream);
 
 /* nn.LayerNorm(C, eps) over the last dim (VIT:484,496,579,596); optional fused exact GELU (fpn1: Norm2d -> GELU,
  * VIT:643-644).  x: (rows, C) in x_dtype; y in y_dtype; mean/rstd f32 (rows). */

@@ -21,7 +21,7 @@ class GemmArgs(C.Structure):
                 ("in_dtype", i32), ("out_dtype", i32), ("epilogue", i32),
                 ("bias", p), ("bias_mod", i64), ("res", p), ("res_ld", i64), ("res_mod", i64),
                 ("rowscale", p), ("rows_per_sample", i64), ("aux", p), ("aux_ld", i64),
-                ("split_k", i32), ("variant", i32), ("colsum", p)]
+                ("split_k", i32), ("variant", i32), ("colsum", p), ("defer_sum", i32), ("pad_", i32)]
 
 
 class WimgDesc(C.Structure):
@@ -34,6 +34,7 @@ SIGNATURES = {
     "mtp_weight_images": (i32, [p, i32, i64, i32, p]),
     "mtp_gemm_nt": (i32, [C.POINTER(GemmArgs), p]),
     "mtp_gemm_tn": (i32, [C.POINTER(GemmArgs), p]),
+    "mtp_sum_partials_batch": (i32, [p, p, p, p, i32, p]),
     "mtp_layernorm_fwd": (i32, [p, i32, p, p, p, i32, p, p, i64, i64, f32, i32, p]),
     "mtp_layernorm_bwd_partial_rows": (i64, [i64]),
     "mtp_layernorm_bwd": (i32, [p, i32, p, i32, p, p, p, p, i32, p, p, p, i32, p, i32, p, i64, p, p, i64, i64, i64, p]),

@@ -837,12 +837,35 @@ int launch_tn(const mtp_gemm_args* a, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_tn_kernel<T, true>), grid, block, LDS_BYTES, stream, k);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<T, false>), grid, block, LDS_BYTES, stream, k);
-    if (use_ws) {
+    if (use_ws && !a->defer_sum) {   // defer_sum: the caller sums the partial tiles later (mtp_sum_partials_batch, several GEMMs per launch)
         const int64_t n4 = (int64_t)a->M * a->N / 4;
         int64_t nb = (n4 + 255) / 256;
         hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, stream, (const float*)a->aux, (float*)a->C, n4, split);
     }
     return mtp_launch_status();
+}
+
+// several split-K reductions in one launch (blockIdx.y = job); the table travels in the kernel arguments
+struct SumJobs {
+    const float* part[MTP_MAX_SEGMENTS];
+    float* out[MTP_MAX_SEGMENTS];
+    int64_t n4[MTP_MAX_SEGMENTS];
+    int split[MTP_MAX_SEGMENTS];
+};
+__global__ __launch_bounds__(256) void sum_partials_batch_kernel(SumJobs t) {
+    const int j = blockIdx.y;
+    const float* __restrict__ part = t.part[j];
+    float* __restrict__ out = t.out[j];
+    const int64_t n4 = t.n4[j];
+    const int split = t.split[j];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
+        for (int z = 1; z < split; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(part + 4 * (i + (int64_t)z * n4));
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + 4 * i) = s;
+    }
 }
 
 template <typename T, typename Tout>
@@ -869,6 +892,20 @@ extern "C" int mtp_gemm_nt(const mtp_gemm_args* a, mtp_stream_t stream) {
     if (a->in_dtype == MTP_F32 && a->out_dtype == MTP_F32) return dispatch_epi<float, float>(a, s);
     if (a->in_dtype == MTP_BF16 && a->out_dtype == MTP_F32 && a->epilogue == MTP_EPI_BIAS) return launch_nt<bf16_t, float, MTP_EPI_BIAS>(a, s);
     return MTP_ERR_UNSUPPORTED;
+}
+
+extern "C" int mtp_sum_partials_batch(const float* const* parts, float* const* outs, const int64_t* numel, const int* splits, int count, mtp_stream_t stream) {
+    if (!parts || !outs || !numel || !splits || count <= 0 || count > MTP_MAX_SEGMENTS) return MTP_ERR_ARG;
+    SumJobs t;
+    int64_t mx = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!parts[i] || !outs[i] || numel[i] <= 0 || (numel[i] % 4) || splits[i] < 1) return MTP_ERR_ARG;
+        t.part[i] = parts[i]; t.out[i] = outs[i]; t.n4[i] = numel[i] / 4; t.split[i] = splits[i];
+        mx = t.n4[i] > mx ? t.n4[i] : mx;
+    }
+    int64_t nb = (mx + 255) / 256;
+    hipLaunchKernelGGL(sum_partials_batch_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb), (unsigned)count), dim3(256), 0, (hipStream_t)stream, t);
+    return mtp_launch_status();
 }
 
 extern "C" int mtp_gemm_tn(const mtp_gemm_args* a, mtp_stream_t stream) {

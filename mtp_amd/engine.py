@@ -194,16 +194,17 @@ class BackboneEngine:
         T = dx2.shape[0]
         # ---- MLP branch
         # (bias gradients = column sums of dY: by-product of the dW GEMM that streams dY anyway)
-        ops.gemm_tn(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], colsum=G[pre + "mlp.fc2.bias"])
+        pend = []   # split-K partial tiles of this block's four weight gradients: reduced by ONE launch at the end of the block
+        ops.gemm_tn(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], colsum=G[pre + "mlp.fc2.bias"], defer=pend)
         du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_DGELU, aux=s["u"])
-        ops.gemm_tn(du, s["ln2"], G[pre + "mlp.fc1.weight"], colsum=G[pre + "mlp.fc1.bias"])
+        ops.gemm_tn(du, s["ln2"], G[pre + "mlp.fc1.weight"], colsum=G[pre + "mlp.fc1.bias"], defer=pend)
         dln2 = ops.gemm_nt(du, b.w1T, self._e(T, C))
         del du
         dx1, dx1_act = self._e(T, C, dtype=F32), self._e(T, C)
         self._ln_bwd(dln2, s["x1"], s["mean2"], s["rstd2"], P[pre + "norm2.weight"], dx1, G[pre + "norm2.weight"], G[pre + "norm2.bias"],
                           dres=dx2, dx_copy=dx1_act, copy_scale=dps[0], rows_per_sample=N)
         # ---- attention branch
-        ops.gemm_tn(dx1_act, s["o"], G[pre + "attn.proj.weight"], colsum=G[pre + "attn.proj.bias"])
+        ops.gemm_tn(dx1_act, s["o"], G[pre + "attn.proj.weight"], colsum=G[pre + "attn.proj.bias"], defer=pend)
         do = ops.gemm_nt(dx1_act, b.wprojT, self._e(T, C))
         dqkv = self._e(T, 3 * C)
         if b.window:
@@ -230,13 +231,14 @@ class BackboneEngine:
                 drel_h, drel_w = self._e(*rel_h.shape, dtype=F32), self._e(*rel_w.shape, dtype=F32)
             ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, self.heads, self.scale,
                               accumulate=True)
-        ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], colsum=G[pre + "attn.qkv.bias"])
+        ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], colsum=G[pre + "attn.qkv.bias"], defer=pend)
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         if b.window:
             ops.rvsa_pool_bwd(dpooled, s["avg"], dln1, B, Hp, Wp, accumulate=True)
         dx0, dx0_act = self._e(T, C, dtype=F32), self._e(T, C)
         self._ln_bwd(dln1, s["x"], s["mean1"], s["rstd1"], P[pre + "norm1.weight"], dx0, G[pre + "norm1.weight"], G[pre + "norm1.bias"],
                           dres=dx1, extra=extra, dx_copy=dx0_act, copy_scale=prev_scale, rows_per_sample=N)
+        ops.sum_partials(pend)
         return dx0, dx0_act
 
     # ------------------------------------------------------------------ whole forward

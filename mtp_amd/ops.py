@@ -77,7 +77,7 @@ def pick_split_k(M, N, K):
     return max(1, min(split, K // 1024))
 
 
-def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None):
+def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None, defer=None):
     """out (M,N) f32 = a (K,M)^T @ b (K,N)   (weight gradient dW = dY^T X).
     colsum (M,) f32, optional: colsum += a.sum(0) -- the bias gradient, produced by the same pass over dY."""
     K, M = a.shape
@@ -96,8 +96,22 @@ def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None)
     if g.split_k > 1 and use_workspace:
         ws = torch.empty(g.split_k * M * N, device=out.device, dtype=torch.float32)   # split-K partials (summed by the callee)
         g.aux = _p(ws)
+        if defer is not None:     # ... or later, together with the other weight gradients of the block (sum_partials)
+            g.defer_sum = 1
+            defer.append((ws, out, M * N, g.split_k))
     check(lib().mtp_gemm_tn(C.byref(g), _s()), "mtp_gemm_tn")
     return out
+
+
+def sum_partials(jobs):
+    """finish the deferred split-K reductions collected by gemm_tn(..., defer=jobs): one launch per 12 GEMMs"""
+    while jobs:
+        chunk, jobs[:] = jobs[:12], jobs[12:]
+        n = len(chunk)
+        P = C.c_void_p * n
+        parts, outs = P(*[j[0].data_ptr() for j in chunk]), P(*[j[1].data_ptr() for j in chunk])
+        numel, splits = (C.c_int64 * n)(*[j[2] for j in chunk]), (C.c_int * n)(*[j[3] for j in chunk])
+        check(lib().mtp_sum_partials_batch(parts, outs, numel, splits, n, _s()), "mtp_sum_partials_batch")
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

@@ -26,8 +26,8 @@ def test_gemm_args_struct_layout():
     import ctypes as C
     from mtp_amd._lib import GemmArgs
     # mirrors `mtp_gemm_args` in the header: 3 ptrs, 6 i64, 3 i32 (+pad), ptr, i64, ptr, 2 i64, ptr, i64, ptr, i64, 2 i32, ptr
-    assert C.sizeof(GemmArgs) == 3 * 8 + 6 * 8 + 3 * 4 + 4 + 8 + 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 8
-    assert GemmArgs.bias.offset == 88 and GemmArgs.split_k.offset == 160 and GemmArgs.colsum.offset == 168
+    assert C.sizeof(GemmArgs) == 3 * 8 + 6 * 8 + 3 * 4 + 4 + 8 + 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert GemmArgs.bias.offset == 88 and GemmArgs.split_k.offset == 160 and GemmArgs.colsum.offset == 168 and GemmArgs.defer_sum.offset == 176
 
 
 def test_weight_image_descriptor_layout():

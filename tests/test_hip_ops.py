@@ -122,6 +122,21 @@ def test_gemm_tn_bias_gradient_byproduct(ops, dtype, Kc, M, N, split):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_gemm_tn_deferred_partial_sums(ops, dtype):
+    """split-K partial tiles left in the workspace (defer=...) and reduced later by one batched launch == the immediate path"""
+    jobs, outs, refs = [], [], []
+    for i, (Kc, M, N, split) in enumerate([(1024, 256, 128, 4), (2048, 128, 384, 2), (512, 128, 128, 1), (1536, 384, 256, 3)]):
+        a, b = dev(rnd(Kc, M, dtype=dtype, scale=0.5, seed=i), dtype), dev(rnd(Kc, N, dtype=dtype, seed=10 + i, scale=0.5), dtype)
+        refs.append(ops.gemm_tn(a, b, e(M, N), split_k=split))
+        outs.append(ops.gemm_tn(a, b, e(M, N), split_k=split, defer=jobs))
+    assert len(jobs) == 3            # the split = 1 GEMM writes its result directly
+    ops.sum_partials(jobs)
+    assert not jobs
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_weight_images_one_launch(ops, dtype):
     """every GEMM-side image (W, W^T in ACT; stacked f32 head weights / biases) out of one descriptor-table launch"""
     ws = [rnd(192, 128, seed=1), rnd(64, 256, seed=2), rnd(100, 36, seed=3), rnd(32, 128, seed=4), rnd(16, 128, seed=5), rnd(1, 32, seed=6)]
