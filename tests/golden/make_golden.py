@@ -337,7 +337,46 @@ def f10():
     save("f10_taps.npz", **out)
 
 
+# ------------------------------------------------------------------ f11: DCNv3 core (InternImage), reference = dcnv3_core_pytorch
+DCN_CASES = [   # name, N, H, W, group, group_channels, kh, kw, stride, pad, dil, offset_scale, remove_center
+    ("base", 2, 8, 8, 4, 16, 3, 3, 1, 1, 1, 2.0, 0),        # ops_dcnv3/test.py:19-30 (its forward / timing case)
+    ("bwd4", 2, 8, 8, 2, 4, 3, 3, 1, 1, 1, 2.0, 0),         # test.py:94-100 (backward cases: M = 2, D = channels)
+    ("odd", 2, 8, 8, 2, 5, 3, 3, 1, 1, 1, 2.0, 0),
+    ("wide", 1, 6, 7, 3, 32, 3, 3, 1, 1, 1, 1.0, 0),
+    ("stride2", 2, 9, 8, 4, 16, 3, 3, 2, 1, 1, 2.0, 0),
+    ("dil2", 2, 8, 10, 4, 16, 3, 3, 1, 2, 2, 1.5, 0),
+    ("nopad", 1, 8, 8, 4, 16, 3, 3, 1, 0, 1, 2.0, 0),
+    ("rmc", 2, 8, 8, 4, 16, 3, 3, 1, 1, 1, 2.0, 1),
+    ("k5rmc", 1, 9, 9, 2, 16, 5, 5, 1, 2, 1, 1.0, 1),
+    ("k1x3", 1, 6, 8, 2, 16, 1, 3, 1, 1, 1, 2.0, 0),
+]
+
+
+def f11():
+    """inputs by ops_dcnv3/test.py's recipe (rand*0.01 input, rand*10 offset, normalised positive mask), in float64;
+    outputs and gradients of sum(out * G) from the reference's dcnv3_core_pytorch (dcnv3_func.py:168-236)"""
+    core = ref_loader.load_reference_dcnv3().dcnv3_core_pytorch
+    torch.manual_seed(3)
+    out = {"cases": np.array([c[0] for c in DCN_CASES])}
+    for name, N, H, W, M, D, kh, kw, st, pad, dil, osc, rmc in DCN_CASES:
+        P = kh * kw - rmc
+        Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // st + 1
+        Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // st + 1
+        inp = (torch.rand(N, H, W, M * D, dtype=torch.float64) * 0.01).requires_grad_(True)
+        off = (torch.rand(N, Ho, Wo, M * P * 2, dtype=torch.float64) * 10 - (0 if name == "base" else 4)).requires_grad_(True)
+        mask = torch.rand(N, Ho, Wo, M, P, dtype=torch.float64) + 1e-5
+        mask = (mask / mask.sum(-1, keepdim=True)).reshape(N, Ho, Wo, M * P).requires_grad_(True)
+        G = torch.randn(N, Ho, Wo, M * D, dtype=torch.float64)
+        y = core(inp, off, mask, kh, kw, st, st, pad, pad, dil, dil, M, D, osc, rmc)
+        assert y.shape == G.shape, (name, y.shape, G.shape)
+        (y * G).sum().backward()
+        out.update({name + ".cfg": np.array([N, H, W, M, D, kh, kw, st, pad, dil, rmc], dtype=np.int64), name + ".offset_scale": np.float64(osc),
+                    name + ".input": inp, name + ".offset": off, name + ".mask": mask, name + ".grad_output": G, name + ".output": y,
+                    name + ".grad_input": inp.grad, name + ".grad_offset": off.grad, name + ".grad_mask": mask.grad})
+    save("f11_dcnv3.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10"]
+    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11"]
     for w in which:
         globals()[w]()

@@ -107,3 +107,23 @@ def load_reference_cls():
     sys.modules["ref_vit_cls"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+REF_DCN_FUNC = "/root/reference/Multi-Task_Pretrain/backbone/ops_dcnv3/functions/dcnv3_func.py"
+
+
+def load_reference_dcnv3():
+    """`dcnv3_core_pytorch` -- the pure-torch DCNv3 core the reference's own test (ops_dcnv3/test.py) checks its CUDA extension
+    against.  Stubs: the compiled `DCNv3` extension module (never called here) and `pkg_resources.get_distribution('DCNv3')`
+    (dcnv3_func.py:16-19 reads only `.version`)."""
+    if "ref_dcnv3_func" in sys.modules:
+        return sys.modules["ref_dcnv3_func"]
+    sys.modules.setdefault("DCNv3", types.ModuleType("DCNv3"))
+    pkg = types.ModuleType("pkg_resources")
+    pkg.get_distribution = lambda name: types.SimpleNamespace(version="1.1")
+    sys.modules.setdefault("pkg_resources", pkg)
+    spec = importlib.util.spec_from_file_location("ref_dcnv3_func", REF_DCN_FUNC)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_dcnv3_func"] = mod
+    spec.loader.exec_module(mod)
+    return mod
