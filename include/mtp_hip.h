@@ -195,6 +195,36 @@ int mtp_sqnorm_f32(const float* g, float* out, int64_t n, mtp_stream_t stream);
 int mtp_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_start, const float* seg_wd, int nseg,
                    const float* hyper, const float* sqnorm, float max_norm, float grad_scale, mtp_stream_t stream);
 
+/* ---- DCNv3 core (InternImage) ------------------------------------------------------------------------
+ * The reference's own native extension: `dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h,
+ * pad_w, dilation_h, dilation_w, group, group_channels, offset_scale, im2col_step, remove_center) -> output` and
+ * `dcnv3_backward(..., grad_output, im2col_step, remove_center) -> [grad_input, grad_offset, grad_mask]`
+ * (Multi-Task_Pretrain/backbone/ops_dcnv3/src/vision.cpp:14-17, dcnv3.h:20-59; kernels src/cuda/dcnv3_im2col_cuda.cuh).
+ * Same argument list, carried in one struct.  Tensors are the reference's: input (N, H, W, group*group_channels)
+ * channels-last; offset (N, Ho, Wo, group*P*2) as (group, point, (x, y)); mask (N, Ho, Wo, group*P); output
+ * (N, Ho, Wo, group*group_channels); P = kernel_h*kernel_w - remove_center, points ordered i*kernel_h + j with i over
+ * kernel_w.  Differences, all on the caller-owns-buffers side of the boundary: outputs are passed in instead of being
+ * allocated by the callee (dcnv3_cuda.cu:55-57, 131-133); dtypes are f32 and bf16 (the reference dispatches float / double /
+ * half, :61, :150); gradients are always f32 (the reference promotes half to float the same way, :125-128).
+ * im2col_step is validated as the reference does (batch % min(batch, im2col_step) == 0, dcnv3_cuda.cu:46-49) but does not
+ * chunk the launch.  Errors: the reference's AT_ASSERTM exceptions become MTP_ERR_ARG. */
+typedef struct {
+    int64_t N, H, W;
+    int kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w;
+    int group, group_channels;
+    float offset_scale;
+    int im2col_step;
+    int remove_center;
+    int pad_;
+} mtp_dcnv3_geom;
+/* Ho = (H + 2 pad_h - (dilation_h (kernel_h - 1) + 1)) / stride_h + 1, Wo likewise (dcnv3_cuda.cu:40-45) */
+int mtp_dcnv3_out_size(const mtp_dcnv3_geom* geom, int64_t* Ho, int64_t* Wo);
+int mtp_dcnv3_fwd(const void* input, const void* offset, const void* mask, void* output, int dtype, const mtp_dcnv3_geom* geom, mtp_stream_t stream);
+/* grad_input (N, H, W, C), grad_offset, grad_mask: f32, shaped like input / offset / mask; zero-filled by the callee where
+ * the kernel accumulates into them (grad_input always: bilinear scatter with f32 atomics, like the reference). */
+int mtp_dcnv3_bwd(const void* input, const void* offset, const void* mask, const void* grad_output, int dtype, float* grad_input, float* grad_offset,
+                  float* grad_mask, const mtp_dcnv3_geom* geom, mtp_stream_t stream);
+
 const char* mtp_version(void);
 
 #ifdef __cplusplus

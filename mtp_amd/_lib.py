@@ -29,9 +29,19 @@ class WimgDesc(C.Structure):
     _fields_ = [("src", p), ("w", p), ("wt", p), ("R", i64), ("C", i64), ("tile0", i64), ("f32_out", C.c_int32), ("pad_", C.c_int32)]
 
 
+class Dcnv3Geom(C.Structure):
+    """mtp_dcnv3_geom"""
+    _fields_ = [("N", i64), ("H", i64), ("W", i64), ("kernel_h", C.c_int32), ("kernel_w", C.c_int32), ("stride_h", C.c_int32), ("stride_w", C.c_int32),
+                ("pad_h", C.c_int32), ("pad_w", C.c_int32), ("dilation_h", C.c_int32), ("dilation_w", C.c_int32), ("group", C.c_int32),
+                ("group_channels", C.c_int32), ("offset_scale", C.c_float), ("im2col_step", C.c_int32), ("remove_center", C.c_int32), ("pad_", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list EVERY function declared in include/mtp_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
     "mtp_weight_images": (i32, [p, i32, i64, i32, p]),
+    "mtp_dcnv3_out_size": (i32, [C.POINTER(Dcnv3Geom), C.POINTER(i64), C.POINTER(i64)]),
+    "mtp_dcnv3_fwd": (i32, [p, p, p, p, i32, C.POINTER(Dcnv3Geom), p]),
+    "mtp_dcnv3_bwd": (i32, [p, p, p, p, i32, p, p, p, C.POINTER(Dcnv3Geom), p]),
     "mtp_gemm_nt": (i32, [C.POINTER(GemmArgs), p]),
     "mtp_gemm_tn": (i32, [C.POINTER(GemmArgs), p]),
     "mtp_sum_partials_batch": (i32, [p, p, p, p, i32, p]),

@@ -1,0 +1,280 @@
+// DCNv3 core operator (InternImage) for gfx950: the reference's only native extension, dcnv3_forward / dcnv3_backward
+// (Multi-Task_Pretrain/backbone/ops_dcnv3/src/dcnv3.h:20-59, kernels in src/cuda/dcnv3_im2col_cuda.cuh), rebuilt for 64-wide
+// waves.  HBM / gather-bound byte work: no matrix cores here.
+//
+//   out[n, ho, wo, g, c] = sum_p mask[n, ho, wo, g, p] * bilinear(input[n, :, :, g, c], loc_h(p), loc_w(p))
+//   loc_w = p0_w - ((dil_w (kw-1)) >> 1) os + (i dil_w + off_x) os,  p0_w = ((dil_w (kw-1)) >> 1) - pad_w + wo stride_w
+//   point p = i * kh + j (i over kernel_w, j over kernel_h), the centre skipped when remove_center
+//
+// Forward: one lane = (pixel, group, 8-channel chunk) -- 16-byte gathers, two lanes per 16-channel group, every load
+// unconditional on a clamped address with the border rule folded into the weights (a branch around a load makes hipcc wait
+// for each load separately).  Backward: one lane = (pixel, group, channel) so that the 16 lanes of a group issue ONE
+// 64-byte-coalesced atomic per corner (the reference's layout too), the channel sums for d(offset) / d(mask) are butterfly
+// reductions inside the 16-lane row instead of the reference's shared-memory tree.
+#include "common.h"
+
+namespace {
+
+struct DcnGeom {
+    int N, H, W, Ho, Wo, G, GC, kh, kw, sh, sw, ph, pw, dh, dw, P, remove_center;
+    float os;
+};
+
+struct Item {   // (pixel, group, chunk) of a flat lane index
+    int64_t item, pix;
+    int n, ho, wo, gi, chunk;
+};
+__device__ __forceinline__ Item decode(const DcnGeom& g, int64_t idx, int chunks) {
+    Item it;
+    it.chunk = (int)(idx % chunks);
+    it.item = idx / chunks;
+    it.gi = (int)(it.item % g.G);
+    it.pix = it.item / g.G;
+    it.wo = (int)(it.pix % g.Wo);
+    const int64_t t = it.pix / g.Wo;
+    it.ho = (int)(t % g.Ho);
+    it.n = (int)(t / g.Ho);
+    return it;
+}
+
+struct Point {   // one sampling point: corner rows (clamped), corner flags and bilinear fractions
+    int o00, o01, o10, o11;       // element offsets of the four corner pixels inside one image (clamped into the map; H*W*C < 2^31)
+    float lh, lw;                 // fractions; hh = 1 - lh, hw = 1 - lw
+    float k00, k01, k10, k11;     // 1.0 where the corner is inside the map AND the point is valid, else 0.0
+};
+__device__ __forceinline__ Point make_point(const DcnGeom& g, float loc_h, float loc_w, int C) {
+    Point p;
+    const bool valid = loc_h > -1.f && loc_w > -1.f && loc_h < (float)g.H && loc_w < (float)g.W;   // false for NaN too
+    // keep floor / int conversion defined for far-away or NaN locations (they carry zero weight)
+    const float ch = fminf(fmaxf(loc_h, -2.f), (float)g.H + 1.f), cw = fminf(fmaxf(loc_w, -2.f), (float)g.W + 1.f);
+    const float fh = floorf(ch), fw = floorf(cw);
+    const int h0 = (int)fh, w0 = (int)fw, h1 = h0 + 1, w1 = w0 + 1;
+    p.lh = ch - fh;
+    p.lw = cw - fw;
+    const bool a0 = h0 >= 0, a1 = h1 <= g.H - 1, b0 = w0 >= 0, b1 = w1 <= g.W - 1;
+    p.k00 = (valid && a0 && b0) ? 1.f : 0.f;
+    p.k01 = (valid && a0 && b1) ? 1.f : 0.f;
+    p.k10 = (valid && a1 && b0) ? 1.f : 0.f;
+    p.k11 = (valid && a1 && b1) ? 1.f : 0.f;
+    const int h0c = min(max(h0, 0), g.H - 1), h1c = min(max(h1, 0), g.H - 1), w0c = min(max(w0, 0), g.W - 1), w1c = min(max(w1, 0), g.W - 1);
+    const int r0 = h0c * g.W, r1 = h1c * g.W;
+    p.o00 = (r0 + w0c) * C;
+    p.o01 = (r0 + w1c) * C;
+    p.o10 = (r1 + w0c) * C;
+    p.o11 = (r1 + w1c) * C;
+    return p;
+}
+
+template <typename T, int CPL>
+__device__ __forceinline__ void load_chunk(const T* p, float (&v)[CPL]) {
+    if constexpr (CPL == 8) {
+        load8(p, v);
+    } else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) v[c] = Elem<T>::load(p + c);
+    }
+}
+template <typename T, int CPL>
+__device__ __forceinline__ void store_chunk(T* p, const float (&v)[CPL]) {
+    if constexpr (CPL == 8) {
+        store8(p, v);
+    } else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) Elem<T>::store(p + c, v[c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, T* __restrict__ out,
+                                                        DcnGeom g, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int chunks = g.GC / CPL;
+    const Item it = decode(g, idx, chunks);
+    const int C = g.G * g.GC;
+    const int chan = it.gi * g.GC + it.chunk * CPL;
+    const T* in_n = input + (int64_t)it.n * g.H * g.W * C + chan;
+    const T* offp = offset + it.item * (2 * g.P);
+    const T* mp = mask + it.item * g.P;
+    const int halfw = (g.dw * (g.kw - 1)) >> 1, halfh = (g.dh * (g.kh - 1)) >> 1;
+    const float p0w = (float)(halfw - g.pw + it.wo * g.sw) - (float)halfw * g.os;
+    const float p0h = (float)(halfh - g.ph + it.ho * g.sh) - (float)halfh * g.os;
+    const int cw = g.kw / 2, chh = g.kh / 2;
+    float acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+    int p = 0;
+    for (int i = 0; i < g.kw; ++i) {
+        for (int j = 0; j < g.kh; ++j) {
+            if (g.remove_center && i == cw && j == chh) continue;
+            const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
+            ++p;
+            const Point pt = make_point(g, p0h + ((float)(j * g.dh) + oh) * g.os, p0w + ((float)(i * g.dw) + ow) * g.os, C);
+            const float hh = 1.f - pt.lh, hw = 1.f - pt.lw;
+            const float w00 = hh * hw * pt.k00 * m, w01 = hh * pt.lw * pt.k01 * m, w10 = pt.lh * hw * pt.k10 * m, w11 = pt.lh * pt.lw * pt.k11 * m;
+            float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
+            load_chunk<T, CPL>(in_n + pt.o00, v00);
+            load_chunk<T, CPL>(in_n + pt.o01, v01);
+            load_chunk<T, CPL>(in_n + pt.o10, v10);
+            load_chunk<T, CPL>(in_n + pt.o11, v11);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] += w00 * v00[c] + w01 * v01[c] + w10 * v10[c] + w11 * v11[c];
+        }
+    }
+    store_chunk<T, CPL>(out + it.pix * C + chan, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SHFL: group_channels is a power of two <= 64, so the lanes of one (pixel, group) are an aligned lane group of the wave and
+// the channel sums are butterflies + one plain store; otherwise they go through f32 atomics into zero-filled outputs.
+template <typename T, bool SHFL>
+__global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
+                                                        float* __restrict__ grad_input, float* __restrict__ grad_offset, float* __restrict__ grad_mask, DcnGeom g, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const Item it = decode(g, idx, g.GC);
+    const int C = g.G * g.GC;
+    const int chan = it.gi * g.GC + it.chunk;
+    const int64_t img = (int64_t)it.n * g.H * g.W * C + chan;
+    const T* in_n = input + img;
+    float* gin_n = grad_input + img;
+    const T* offp = offset + it.item * (2 * g.P);
+    const T* mp = mask + it.item * g.P;
+    float* goffp = grad_offset + it.item * (2 * g.P);
+    float* gmp = grad_mask + it.item * g.P;
+    const float top = Elem<T>::load(grad_out + it.pix * C + chan);
+    const int halfw = (g.dw * (g.kw - 1)) >> 1, halfh = (g.dh * (g.kh - 1)) >> 1;
+    const float p0w = (float)(halfw - g.pw + it.wo * g.sw) - (float)halfw * g.os;
+    const float p0h = (float)(halfh - g.ph + it.ho * g.sh) - (float)halfh * g.os;
+    const int cw = g.kw / 2, chh = g.kh / 2;
+    int p = 0;
+    for (int i = 0; i < g.kw; ++i) {
+        for (int j = 0; j < g.kh; ++j) {
+            if (g.remove_center && i == cw && j == chh) continue;
+            const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
+            const Point pt = make_point(g, p0h + ((float)(j * g.dh) + oh) * g.os, p0w + ((float)(i * g.dw) + ow) * g.os, C);
+            const float hh = 1.f - pt.lh, hw = 1.f - pt.lw;
+            const float v00 = Elem<T>::load(in_n + pt.o00) * pt.k00, v01 = Elem<T>::load(in_n + pt.o01) * pt.k01;
+            const float v10 = Elem<T>::load(in_n + pt.o10) * pt.k10, v11 = Elem<T>::load(in_n + pt.o11) * pt.k11;
+            const float tg = top * m;
+            if (pt.k00 != 0.f) atomicAdd(gin_n + pt.o00, hh * hw * tg);
+            if (pt.k01 != 0.f) atomicAdd(gin_n + pt.o01, hh * pt.lw * tg);
+            if (pt.k10 != 0.f) atomicAdd(gin_n + pt.o10, pt.lh * hw * tg);
+            if (pt.k11 != 0.f) atomicAdd(gin_n + pt.o11, pt.lh * pt.lw * tg);
+            float gm = top * (hh * hw * v00 + hh * pt.lw * v01 + pt.lh * hw * v10 + pt.lh * pt.lw * v11);
+            float gw = g.os * tg * (hh * (v01 - v00) + pt.lh * (v11 - v10));
+            float gh = g.os * tg * (hw * (v10 - v00) + pt.lw * (v11 - v01));
+            if constexpr (SHFL) {
+                for (int o = g.GC >> 1; o > 0; o >>= 1) {
+                    gm += __shfl_xor(gm, o, 64);
+                    gw += __shfl_xor(gw, o, 64);
+                    gh += __shfl_xor(gh, o, 64);
+                }
+                if (it.chunk == 0) {
+                    gmp[p] = gm;
+                    goffp[2 * p] = gw;
+                    goffp[2 * p + 1] = gh;
+                }
+            } else {
+                atomicAdd(gmp + p, gm);
+                atomicAdd(goffp + 2 * p, gw);
+                atomicAdd(goffp + 2 * p + 1, gh);
+            }
+            ++p;
+        }
+    }
+}
+
+int make_geom(const mtp_dcnv3_geom* a, DcnGeom& g) {
+    MTP_CHECK_ARG(a != nullptr);
+    MTP_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0 && a->group > 0 && a->group_channels > 0);
+    MTP_CHECK_ARG(a->kernel_h > 0 && a->kernel_w > 0 && a->stride_h > 0 && a->stride_w > 0 && a->dilation_h > 0 && a->dilation_w > 0 && a->pad_h >= 0 && a->pad_w >= 0);
+    MTP_CHECK_ARG(a->N < (1 << 30) && a->H < (1 << 15) && a->W < (1 << 15));
+    // the reference's batching rule (dcnv3_cuda.cu:46-49): batch must be a multiple of min(batch, im2col_step)
+    MTP_CHECK_ARG(a->im2col_step > 0 && a->N % (a->N < a->im2col_step ? a->N : a->im2col_step) == 0);
+    // remove_center is defined for square odd kernels only (dcnv3_func.py:184-185, modules/dcnv3.py:258-259)
+    MTP_CHECK_ARG(!a->remove_center || (a->kernel_h == a->kernel_w && (a->kernel_h & 1)));
+    const int64_t Ho = (a->H + 2 * a->pad_h - (a->dilation_h * (a->kernel_h - 1) + 1)) / a->stride_h + 1;
+    const int64_t Wo = (a->W + 2 * a->pad_w - (a->dilation_w * (a->kernel_w - 1) + 1)) / a->stride_w + 1;
+    MTP_CHECK_ARG(Ho > 0 && Wo > 0);
+    g.N = (int)a->N; g.H = (int)a->H; g.W = (int)a->W; g.Ho = (int)Ho; g.Wo = (int)Wo;
+    g.G = a->group; g.GC = a->group_channels;
+    g.kh = a->kernel_h; g.kw = a->kernel_w; g.sh = a->stride_h; g.sw = a->stride_w; g.ph = a->pad_h; g.pw = a->pad_w; g.dh = a->dilation_h; g.dw = a->dilation_w;
+    g.remove_center = a->remove_center ? 1 : 0;
+    g.P = a->kernel_h * a->kernel_w - g.remove_center;
+    MTP_CHECK_ARG(g.P > 0);
+    if ((int64_t)g.H * g.W * g.G * g.GC >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;   // 32-bit element offsets inside one image
+    g.os = a->offset_scale;
+    return 0;
+}
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+int launch_fwd(const void* input, const void* offset, const void* mask, void* output, const DcnGeom& g, hipStream_t s) {
+    const int64_t items = (int64_t)g.N * g.Ho * g.Wo * g.G;
+    if (g.GC % 8 == 0 && aligned16(input) && aligned16(output)) {
+        const int64_t total = items * (g.GC / 8);
+        hipLaunchKernelGGL((dcnv3_fwd_kernel<T, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (T*)output, g, total);
+    } else {
+        const int64_t total = items * g.GC;
+        hipLaunchKernelGGL((dcnv3_fwd_kernel<T, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (T*)output, g, total);
+    }
+    return mtp_launch_status();
+}
+
+template <typename T>
+int launch_bwd(const void* input, const void* offset, const void* mask, const void* grad_output, float* grad_input, float* grad_offset, float* grad_mask, const DcnGeom& g,
+               hipStream_t s) {
+    const int64_t items = (int64_t)g.N * g.Ho * g.Wo * g.G, total = items * g.GC;
+    const bool shfl = g.GC <= 64 && (g.GC & (g.GC - 1)) == 0;
+    hipError_t e = hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)g.N * g.H * g.W * g.G * g.GC, s);   // the reference's at::zeros_like (dcnv3_cuda.cu:131)
+    if (e != hipSuccess) return (int)e;
+    if (!shfl) {
+        e = hipMemsetAsync(grad_offset, 0, sizeof(float) * (size_t)items * 2 * g.P, s);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)items * g.P, s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((dcnv3_bwd_kernel<T, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (const T*)grad_output,
+                           grad_input, grad_offset, grad_mask, g, total);
+    } else {
+        hipLaunchKernelGGL((dcnv3_bwd_kernel<T, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (const T*)grad_output,
+                           grad_input, grad_offset, grad_mask, g, total);
+    }
+    return mtp_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mtp_dcnv3_out_size(const mtp_dcnv3_geom* geom, int64_t* Ho, int64_t* Wo) {
+    DcnGeom g;
+    const int rc = make_geom(geom, g);
+    if (rc) return rc;
+    MTP_CHECK_ARG(Ho && Wo);
+    *Ho = g.Ho;
+    *Wo = g.Wo;
+    return 0;
+}
+
+extern "C" int mtp_dcnv3_fwd(const void* input, const void* offset, const void* mask, void* output, int dtype, const mtp_dcnv3_geom* geom, mtp_stream_t stream) {
+    DcnGeom g;
+    const int rc = make_geom(geom, g);
+    if (rc) return rc;
+    MTP_CHECK_ARG(input && offset && mask && output);
+    MTP_CHECK_ARG(dtype == MTP_F32 || dtype == MTP_BF16);
+    if ((int64_t)g.N * g.Ho * g.Wo * g.G * g.GC >= ((int64_t)1 << 32) - 256) return MTP_ERR_UNSUPPORTED;   // one lane per element at most
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == MTP_F32 ? launch_fwd<float>(input, offset, mask, output, g, s) : launch_fwd<bf16_t>(input, offset, mask, output, g, s);
+}
+
+extern "C" int mtp_dcnv3_bwd(const void* input, const void* offset, const void* mask, const void* grad_output, int dtype, float* grad_input, float* grad_offset,
+                             float* grad_mask, const mtp_dcnv3_geom* geom, mtp_stream_t stream) {
+    DcnGeom g;
+    const int rc = make_geom(geom, g);
+    if (rc) return rc;
+    MTP_CHECK_ARG(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask);
+    MTP_CHECK_ARG(dtype == MTP_F32 || dtype == MTP_BF16);
+    if ((int64_t)g.N * g.Ho * g.Wo * g.G * g.GC >= ((int64_t)1 << 32) - 256) return MTP_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == MTP_F32 ? launch_bwd<float>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s)
+                            : launch_bwd<bf16_t>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s);
+}
