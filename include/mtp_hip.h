@@ -215,7 +215,7 @@ typedef struct {
     float offset_scale;
     int im2col_step;
     int remove_center;
-    int pad_;
+    int variant;   /* 0 = default; bit0 = plain workgroup order instead of one contiguous pixel range per XCD (A/B) */
 } mtp_dcnv3_geom;
 /* Ho = (H + 2 pad_h - (dilation_h (kernel_h - 1) + 1)) / stride_h + 1, Wo likewise (dcnv3_cuda.cu:40-45) */
 int mtp_dcnv3_out_size(const mtp_dcnv3_geom* geom, int64_t* Ho, int64_t* Wo);

@@ -33,7 +33,7 @@ class Dcnv3Geom(C.Structure):
     """mtp_dcnv3_geom"""
     _fields_ = [("N", i64), ("H", i64), ("W", i64), ("kernel_h", C.c_int32), ("kernel_w", C.c_int32), ("stride_h", C.c_int32), ("stride_w", C.c_int32),
                 ("pad_h", C.c_int32), ("pad_w", C.c_int32), ("dilation_h", C.c_int32), ("dilation_w", C.c_int32), ("group", C.c_int32),
-                ("group_channels", C.c_int32), ("offset_scale", C.c_float), ("im2col_step", C.c_int32), ("remove_center", C.c_int32), ("pad_", C.c_int32)]
+                ("group_channels", C.c_int32), ("offset_scale", C.c_float), ("im2col_step", C.c_int32), ("remove_center", C.c_int32), ("variant", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list EVERY function declared in include/mtp_hip.h (tests/test_abi.py checks)

@@ -18,7 +18,17 @@ namespace {
 struct DcnGeom {
     int N, H, W, Ho, Wo, G, GC, kh, kw, sh, sw, ph, pw, dh, dw, P, remove_center;
     float os;
+    int xcd_order;   // 1: each of the 8 XCDs takes a contiguous range of workgroups (= of pixels), see block_index()
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring pixels gather from / scatter into the
+// same input rows, so with the plain order every XCD touches every line; giving each XCD a contiguous range of the flat
+// (n, ho, wo, g) order keeps a line's readers and its atomic writers on one L2 (bijective for any grid size).
+__device__ __forceinline__ int64_t block_index(const DcnGeom& g) {
+    if (!g.xcd_order) return blockIdx.x;
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    return (int64_t)(xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
 
 struct Item {   // (pixel, group, chunk) of a flat lane index
     int64_t item, pix;
@@ -88,7 +98,7 @@ __device__ __forceinline__ void store_chunk(T* p, const float (&v)[CPL]) {
 template <typename T, int CPL>
 __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, T* __restrict__ out,
                                                         DcnGeom g, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t idx = block_index(g) * 256 + threadIdx.x;
     if (idx >= total) return;
     const int chunks = g.GC / CPL;
     const Item it = decode(g, idx, chunks);
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T* __restrict__ in
 template <typename T, bool SHFL>
 __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
                                                         float* __restrict__ grad_input, float* __restrict__ grad_offset, float* __restrict__ grad_mask, DcnGeom g, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t idx = block_index(g) * 256 + threadIdx.x;
     if (idx >= total) return;
     const Item it = decode(g, idx, g.GC);
     const int C = g.G * g.GC;
@@ -206,6 +216,7 @@ int make_geom(const mtp_dcnv3_geom* a, DcnGeom& g) {
     MTP_CHECK_ARG(g.P > 0);
     if ((int64_t)g.H * g.W * g.G * g.GC >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;   // 32-bit element offsets inside one image
     g.os = a->offset_scale;
+    g.xcd_order = (a->variant & 1) ? 0 : 1;
     return 0;
 }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -14,6 +14,7 @@ Dtypes: float32 and bfloat16 (the reference dispatches float / double / half).  
 as the reference promotes half to float (dcnv3_cuda.cu:125-128).
 """
 import ctypes as C
+import os
 
 import torch
 from torch.autograd import Function
@@ -30,6 +31,7 @@ def _geom(input, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_
     g.pad_h, g.pad_w, g.dilation_h, g.dilation_w = int(pad_h), int(pad_w), int(dilation_h), int(dilation_w)
     g.group, g.group_channels, g.offset_scale = int(group), int(group_channels), float(offset_scale)
     g.im2col_step, g.remove_center = int(im2col_step), int(remove_center)
+    g.variant = int(os.environ.get("MTP_DCNV3_VARIANT", "0"))     # A/B switch, see mtp_hip.h
     return g
 
 
