@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
+    ap.add_argument("--host-input", action="store_true", help="additionally time the step fed from HOST uint8 batches (pinned staging, side-stream H2D, "
+                                                              "fused preprocess): reported as `host_input`, never as `value`")
     ap.add_argument("--image-size", type=int, default=224, help="224 = the headline metric; 448 = what MTP actually pretrains at (use --batch 16)")
     args = ap.parse_args()
 
@@ -182,6 +184,32 @@ def main():
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
+    host_input = None
+    if args.host_input:
+        # PCIe-inclusive variant of the same step: raw uint8 HWC batches start in pageable HOST memory, are staged
+        # through pinned buffers and copied on a side stream while the previous step computes; normalise / flip / pad / im2col
+        # run on the device inside the patch-embed kernel.  Reported next to `value`, never instead of it.
+        import itertools
+        from mtp_amd.data import HostBatchPrefetcher
+        net.set_data_preprocessor()
+        pool = [torch.randint(0, 256, (B, args.image_size, args.image_size, 3), dtype=torch.uint8) for _ in range(4)]
+        pf = HostBatchPrefetcher(itertools.islice(itertools.cycle(pool), args.warmup + args.steps), device="cuda", depth=2)
+        for _ in range(args.warmup):
+            trainer.step(next(pf), loss_and_grads)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(next(pf), loss_and_grads)
+        sync()
+        dth = time.perf_counter() - t1
+        th = torch.tensor([dth], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        dth = float(th.item())
+        host_input = dict(value=round(world * B * args.steps / dth, 2), unit="images/sec", ms_per_step=round(dth / args.steps * 1e3, 3),
+                          h2d_bytes_per_step=B * args.image_size * args.image_size * 3,
+                          note="same step fed from pageable host uint8 (B,H,W,3) batches: pinned staging + side-stream H2D + fused preprocess")
+
     if rank == 0:
         fams = timer.summary()
         roof = None
@@ -215,6 +243,8 @@ def main():
             "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if args.image_size == 224 else None,
             "roofline": roof,
         }
+        if host_input is not None:
+            out["host_input"] = host_input
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(out), flush=True)

@@ -208,6 +208,27 @@ def test_uint8_input_through_fused_preprocessor_equals_preprocessed_f32_input():
         net(raw.cuda())
 
 
+def test_host_batches_through_the_double_buffered_prefetcher():
+    """host uint8 batches -> pinned staging -> side-stream H2D -> fused preprocess + patch-embed; every batch must
+    give exactly what a plain .cuda() copy of it gives, with two device buffers recycled under a running stream of work"""
+    from mtp_amd.data import HostBatchPrefetcher
+    net = build(128, 4, 2, 2, [0, 1, 2, 3], "fp32").eval()
+    net.set_data_preprocessor()
+    g = torch.Generator().manual_seed(11)
+    host = [torch.randint(0, 256, (2, 224, 224, 3), generator=g, dtype=torch.uint8) for _ in range(5)]
+    pf = HostBatchPrefetcher(iter(host), device="cuda", depth=2)
+    outs = []
+    with torch.no_grad():
+        for dev_batch in pf:
+            assert dev_batch.is_cuda and dev_batch.dtype == torch.uint8
+            outs.append([f.clone() for f in net(dev_batch)])
+        torch.cuda.synchronize()
+        for b, got in zip(host, outs):
+            for fa, fb in zip(got, net(b.cuda())):
+                assert torch.equal(fa, fb)
+    assert len(outs) == 5 and len(pf.slots) == 2 and pf.bytes_copied == 5 * 2 * 224 * 224 * 3
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
 def test_vitdet_style_finetune_variant_vs_reference(golden, precision, tol):
     """fixture f9 = the reference's mmdet `RVSA_MTP`: full attention without rel-pos, last block -> final norm ->
