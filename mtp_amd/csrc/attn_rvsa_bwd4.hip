@@ -1,4 +1,6 @@
 // 4-wave variant of the RVSA backward (see attn_mfma.hip for the algorithm and the single-wave forward).
+#include <stdlib.h>
+
 #include "attn_mfma.h"
 #include "common.h"
 
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv, float* __restrict__ dkv, float* __restrict__ dsamp,
                                                             float* __restrict__ rel_part, float* __restrict__ tab_part,
                                                             const float* __restrict__ rel_h, const float* __restrict__ rel_w, const float* __restrict__ bias_table,
-                                                            RvsaGeom g, float scale) {
+                                                            RvsaGeom g, float scale, int dense_scatter) {
     __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
     __shared__ __attribute__((aligned(16))) char R2[2 * 64 * TP];
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     __shared__ float tab[176];
     __shared__ float lses[64];
     __shared__ float delta[64];
-    __shared__ float smp[SMP_F * 64];
+    __shared__ __attribute__((aligned(16))) float smp[SMP_F * 64];
     __shared__ float vsum[8];
     char* Kt = R2;
     char* Qt = R2;
@@ -418,21 +420,33 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 dv2[dt] = mma(pfb[kk], dotf, dv2[dt]);
             }
         }
+        if (dense_scatter) {
+            // dK_sel^T / dV_sel^T -> bf16 [d][key] images over Q^T | dO^T (every wave is past its last read of them); the
+            // scatter itself runs after the coordinate gradients, see the end of the kernel
+            __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key2 = 16 * kt + 4 * gq + r, k2 = key2 < 48 ? key2 : 48;
-            const float fx2 = smp[0 * 64 + k2], fy2 = smp[1 * 64 + k2];
-            const int x02 = __float_as_int(smp[2 * 64 + k2]), y02 = __float_as_int(smp[3 * 64 + k2]);
+            for (int dt = 0; dt < 4; ++dt) {
+                const int o = (16 * dt + fr) * TP + (16 * kt + 4 * gq) * 2;
+                *reinterpret_cast<uint2*>(R2 + o) = make_uint2(pack_bf16x2(dk2[dt][0], dk2[dt][1]), pack_bf16x2(dk2[dt][2], dk2[dt][3]));
+                *reinterpret_cast<uint2*>(R2 + 64 * TP + o) = make_uint2(pack_bf16x2(dv2[dt][0], dv2[dt][1]), pack_bf16x2(dv2[dt][2], dv2[dt][3]));
+            }
+        } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float w;
-                const int tok = key2 < 49 ? neighbour(g, x02, y02, fx2, fy2, k, w) : -1;
-                if (tok >= 0) {
-                    float* drow = dkv + ((int64_t)b * N + tok) * (2 * C) + h * HD + fr;
+            for (int r = 0; r < 4; ++r) {
+                const int key2 = 16 * kt + 4 * gq + r, k2 = key2 < 48 ? key2 : 48;
+                const float fx2 = smp[0 * 64 + k2], fy2 = smp[1 * 64 + k2];
+                const int x02 = __float_as_int(smp[2 * 64 + k2]), y02 = __float_as_int(smp[3 * 64 + k2]);
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        atomicAdd(drow + 16 * dt, w * dk2[dt][r]);
-                        atomicAdd(drow + C + 16 * dt, w * dv2[dt][r]);
+                for (int k = 0; k < 4; ++k) {
+                    float w;
+                    const int tok = key2 < 49 ? neighbour(g, x02, y02, fx2, fy2, k, w) : -1;
+                    if (tok >= 0) {
+                        float* drow = dkv + ((int64_t)b * N + tok) * (2 * C) + h * HD + fr;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            atomicAdd(drow + 16 * dt, w * dk2[dt][r]);
+                            atomicAdd(drow + C + 16 * dt, w * dv2[dt][r]);
+                        }
                     }
                 }
             }
@@ -480,6 +494,75 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         float* dp = dsamp + (int64_t)bw * 5 * H;
         dp[2 * h] = vsum[0]; dp[2 * h + 1] = vsum[1]; dp[2 * H + 2 * h] = vsum[2]; dp[2 * H + 2 * h + 1] = vsum[3]; dp[4 * H + h] = vsum[4];
     }
+    if (dense_scatter) {
+        // ================= scatter of dK_sel / dV_sel through the bilinear weights, as a product on the matrix cores =========
+        // dK[token][d] += sum_key W[token][key] dK_sel[key][d],  W = hat(ix_key - X_token) hat(iy_key - Y_token) -- the same four
+        // corner weights, summed per TOKEN before they leave the workgroup.  The memory side retires ~31 G 64-byte f32 atomics/s
+        // (measured) and the per-(key, corner) scatter issued 49 x 4 x 8 of them per workgroup: it was the
+        // kernel's floor.  Neighbouring keys share corners, so per token it is ~81 x 8 for near-identity sampling.
+        // wave = token tiles w, w+4, ... of 16 tokens inside the row range the samples can touch.
+        const char* dKt = R2;
+        const char* dVt = R2 + 64 * TP;
+        float kx[16], ky[16];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int e4 = 0; e4 < 2; ++e4) {
+                const int k0 = 32 * kk + 8 * gq + 4 * e4;
+                const float4 fxv = *reinterpret_cast<const float4*>(smp + 0 * 64 + k0), fyv = *reinterpret_cast<const float4*>(smp + 1 * 64 + k0);
+                const float4 x0v = *reinterpret_cast<const float4*>(smp + 2 * 64 + k0), y0v = *reinterpret_cast<const float4*>(smp + 3 * 64 + k0);
+                const int i = 8 * kk + 4 * e4;
+                kx[i] = (float)__float_as_int(x0v.x) + fxv.x; kx[i + 1] = (float)__float_as_int(x0v.y) + fxv.y;
+                kx[i + 2] = (float)__float_as_int(x0v.z) + fxv.z; kx[i + 3] = (float)__float_as_int(x0v.w) + fxv.w;
+                ky[i] = (float)__float_as_int(y0v.x) + fyv.x; ky[i + 1] = (float)__float_as_int(y0v.y) + fyv.y;
+                ky[i + 2] = (float)__float_as_int(y0v.z) + fyv.z; ky[i + 3] = (float)__float_as_int(y0v.w) + fyv.w;
+            }
+        const float iy = (float)__float_as_int(smp[3 * 64 + lane]) + smp[1 * 64 + lane];   // clamped to [-4, He + 4] by make_sample
+        const float ymin = -wave_max(lane < 49 ? -iy : -1e30f), ymax = wave_max(lane < 49 ? iy : -1e30f);
+        const int ty_lo = min(max((int)floorf(ymin) - g.pad_t, 0), g.Hp - 1), ty_hi = min(max((int)floorf(ymax) + 1 - g.pad_t, 0), g.Hp - 1);
+        const int t_lo = __builtin_amdgcn_readfirstlane((ty_lo * g.Wp) >> 4), t_hi = __builtin_amdgcn_readfirstlane(((ty_hi + 1) * g.Wp - 1) >> 4);
+        uint4 bk[4][2], bv[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int o = (16 * dt + fr) * TP + (32 * kk + 8 * gq) * 2;
+                bk[dt][kk] = ld8x2(dKt + o, dKt + o + 8);
+                bv[dt][kk] = ld8x2(dVt + o, dVt + o + 8);
+            }
+        for (int ti = t_lo + wave; ti <= t_hi; ti += 4) {
+            const int tok = 16 * ti + fr, tyy = tok / g.Wp, txx = tok - tyy * g.Wp;
+            const float X = (float)(txx + g.pad_l), Y = (float)(tyy + g.pad_t);
+            const float live = tok < N ? 1.f : 0.f;
+            uint4 af[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    w[e] = live * fmaxf(0.f, 1.f - fabsf(kx[8 * kk + e] - X)) * fmaxf(0.f, 1.f - fabsf(ky[8 * kk + e] - Y));
+                af[kk] = pack_bf16x8(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4_t ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    ak = mma(af[kk], bk[dt][kk], ak);     // lane (token = 16 ti + 4 gq + r; d = 16 dt + fr)
+                    av = mma(af[kk], bv[dt][kk], av);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t2 = 16 * ti + 4 * gq + r;
+                    if (t2 < N) {
+                        float* drow = dkv + ((int64_t)b * N + t2) * (2 * C) + h * HD + 16 * dt + fr;
+                        if (ak[r] != 0.f) atomicAdd(drow, ak[r]);
+                        if (av[r] != 0.f) atomicAdd(drow + C, av[r]);
+                    }
+                }
+            }
+        }
+    }
 }
 
 RvsaGeom make_geom(int64_t Hp, int64_t Wp, int64_t heads) {
@@ -501,7 +584,8 @@ int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, 
                              float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     const RvsaGeom g = make_geom(Hp, Wp, heads);
+    static const int dense = []() { const char* e = getenv("MTP_RVSA_SCATTER"); return (e && e[0] == 'c') ? 0 : 1; }();   // "corner": per-(key, corner) atomics (A/B)
     hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
-                       (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale);
+                       (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, dense);
     return mtp_launch_status();
 }
