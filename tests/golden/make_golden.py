@@ -13,6 +13,7 @@ import io
 import json
 import os
 import sys
+import zlib
 
 import numpy as np
 import torch
@@ -376,7 +377,39 @@ def f11():
     save("f11_dcnv3.npz", **out)
 
 
+# ------------------------------------------------------------------ f12: InternImage backbone (reference, core_op='DCNv3_pytorch')
+def f12():
+    from oracle import internimage_oracle as IO
+    II = ref_loader.load_reference_internimage()
+    cfg = recipe.II_CFG
+    net = quiet(II.InternImage, core_op="DCNv3_pytorch", channels=cfg["channels"], depths=cfg["depths"], groups=cfg["groups"], mlp_ratio=4.0,
+                drop_path_rate=0.0, norm_layer="LN", layer_scale=cfg["layer_scale"], offset_scale=cfg["offset_scale"], post_norm=True, with_cp=False,
+                out_indices=(0, 1, 2, 3))
+    sd = net.state_dict()
+    shapes = IO.state_shapes(cfg["channels"], cfg["depths"], cfg["groups"])
+    assert list(sd.keys()) == list(shapes.keys()), "state_shapes() order/names differ from the reference"
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    params = recipe.internimage_params(shapes)
+    net.load_state_dict(params, strict=True)
+    net = net.double().eval()     # float64 run: what is left against an exact evaluation is dcnv3_core_pytorch's float32 sampling grid
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(12)).double().requires_grad_(True)
+    feats = net(img)
+    gs = [torch.randn(f.shape, generator=torch.Generator().manual_seed(100 + i)).double() for i, f in enumerate(feats)]
+    sum((f * g).sum() for f, g in zip(feats, gs)).backward()
+    grads = dict(net.named_parameters())
+    keep = ["patch_embed.conv1.weight", "levels.0.blocks.0.dcn.offset.weight", "levels.0.blocks.0.dcn.mask.bias", "levels.0.blocks.0.gamma1",
+            "levels.1.blocks.0.dcn.dw_conv.0.weight", "levels.2.blocks.1.dcn.input_proj.weight", "levels.2.blocks.0.norm1.0.weight",
+            "levels.0.downsample.conv.weight", "levels.3.blocks.0.mlp.fc2.bias", "levels.3.blocks.0.dcn.output_proj.weight"]
+    out = {"keys": np.array(list(sd.keys())), "shapes": np.array([str(tuple(v.shape)) for v in sd.values()]), "grad_img": img.grad}
+    for i, f in enumerate(feats):
+        out["feat%d" % i] = f
+    for k in keep:
+        out["grad." + k] = grads[k].grad
+    save("f12_internimage.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11"]
+    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
     for w in which:
         globals()[w]()

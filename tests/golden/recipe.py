@@ -102,3 +102,32 @@ def summarize(t, n=512, seed=7):
     a = t.detach().double().reshape(-1).numpy()
     idx = sample_indices(a.size, n, seed)
     return np.array([a.sum(), np.abs(a).sum()]), a[idx].astype(np.float32)
+
+
+# ---- InternImage (fixture f12): tiny configuration of the BASELINE config-5 family (16-channel groups, layer scale, post-norm)
+II_CFG = dict(channels=32, depths=[1, 1, 2, 1], groups=[2, 4, 8, 16], offset_scale=2.0, layer_scale=0.5)
+
+
+def internimage_params(shapes, seed=77):
+    """seeded parameters for f12: the reference zero-initialises the offset / mask heads (dcnv3.py:176-179) -- randomised so the
+    sampling really deforms; LayerNorm weights and layer-scale gammas around their init values"""
+    out = {}
+    for name, shape in shapes.items():
+        g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(name.encode()) % 1000003)
+        t = torch.randn(*shape, generator=g)
+        if name.endswith("gamma1") or name.endswith("gamma2"):
+            t = 0.5 + 0.1 * t
+        elif ("norm" in name or "dw_conv.1.1" in name) and name.endswith(".weight"):
+            t = 1.0 + 0.1 * t
+        elif "offset.weight" in name:
+            t = 0.3 * t
+        elif "mask.weight" in name:
+            t = 0.2 * t
+        elif name.endswith(".bias"):
+            t = 0.05 * t
+        elif "conv" in name:
+            t = 0.15 * t
+        else:
+            t = t / (shape[-1] ** 0.5)
+        out[name] = t
+    return out

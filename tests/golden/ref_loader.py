@@ -127,3 +127,31 @@ def load_reference_dcnv3():
     sys.modules["ref_dcnv3_func"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+REF_BACKBONE_DIR = "/root/reference/Multi-Task_Pretrain/backbone"
+
+
+def load_reference_internimage():
+    """`backbone/intern_image.py` with `core_op='DCNv3_pytorch'` (last row).  The file does a relative import of
+    its `ops_dcnv3` package, so it is loaded as the submodule `ref_backbone.intern_image` of a synthetic package whose path is
+    the reference's backbone directory.  Extra stubs: `timm.models.layers.DropPath` (identity when drop_prob == 0 or eval),
+    the compiled `DCNv3` extension and `pkg_resources` (see load_reference_dcnv3)."""
+    if "ref_backbone.intern_image" in sys.modules:
+        return sys.modules["ref_backbone.intern_image"]
+    load_reference()              # timm / mmengine stubs
+    load_reference_dcnv3()        # DCNv3 / pkg_resources stubs
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            return _drop_path(x, self.drop_prob, self.training)
+    sys.modules["timm.models.layers"].DropPath = DropPath
+    pkg = types.ModuleType("ref_backbone")
+    pkg.__path__ = [REF_BACKBONE_DIR]
+    sys.modules["ref_backbone"] = pkg
+    import importlib
+    return importlib.import_module("ref_backbone.intern_image")
