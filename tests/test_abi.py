@@ -48,3 +48,17 @@ def test_arg_checks_reject_without_gpu():
     assert lib.mtp_layernorm_fwd(None, 0, None, None, None, 0, None, None, 4, 8, 1e-6, 0, None) == -1
     assert lib.mtp_full_attn_fwd(None, None, None, 0, None, None, 1, 14, 14, 2, 64, 0.125, None) == -1
     assert lib.mtp_layernorm_bwd_partial_rows(12544) == 512 and lib.mtp_layernorm_bwd_partial_rows(10) == 3
+
+
+def test_every_entry_point_rejects_null_arguments_before_launching():
+    """the whole ABI: all-NULL pointers / zero sizes must come back as MTP_ERR_ARG (-1) from the argument checks -- no launch,
+    no dereference, no GPU needed.  (Pure query functions are exercised in the other tests.)"""
+    import ctypes as C
+    from mtp_amd import _lib
+    lib = _lib.load()
+    queries = {"mtp_version", "mtp_layernorm_bwd_partial_rows", "mtp_full_attn_bwd_workspace_floats"}
+    for name, (_, argtypes) in sorted(_lib.SIGNATURES.items()):
+        if name in queries:
+            continue
+        args = [0.0 if a is C.c_float else (None if (a is C.c_void_p or hasattr(a, "contents")) else 0) for a in argtypes]
+        assert getattr(lib, name)(*args) == -1, name
