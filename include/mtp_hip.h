@@ -64,8 +64,9 @@ typedef struct {
     int variant;        /* 0 = default kernels and heuristics; other values force A/B choices (debug): bit0 NT register-
                          * staged loads; bits1-2 tile order (1 plain, 2 grouped / M-fastest, 3 row-major); bit3 NT
                          * double-buffered / TN single-stage; bit4 TN register-transposing; bit5 / bit6 force / forbid
-                         * the 256x128 8-wave NT tile; bit7 NT at 5 workgroups per CU (complete tiles only).
-                         * All variants of one problem give bit-identical results. */
+                         * the 256x128 8-wave NT tile; bit7 NT at 5 workgroups per CU (complete tiles only); bits8-9 the
+                         * 256x256 8-wave pipelined NT kernel (1 = one workgroup per tile, 2 = persistent workgroups),
+                         * bit10 forbids it.  All variants of one problem give bit-identical results. */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
     int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them
@@ -76,8 +77,20 @@ typedef struct {
 /* y = x W^T (+epilogue): nn.Linear fwd/dgrad (VIT:50,52,78,87,256,262), patch-embed conv as GEMM (VIT:529),
  * ConvTranspose2d(2,2) as GEMM (VIT:642-649).  C[m][n] = sum_k A[m][k] * B[n][k]. */
 int mtp_gemm_nt(const mtp_gemm_args* args, mtp_stream_t stream);
+/* Query: the tile width of the kernel family mtp_gemm_nt runs these arguments on -- 256 = the 8-wave pipelined
+ * 256 x 256 x 64 kernel (bf16, K % 128 == 0, M % 8 == 0, N % 8 == 0), 128 = the 128-wide kernels (every other case, and f32).
+ * Both families accumulate in the same k order: results are bit-identical. */
+int mtp_gemm_nt_tile(const mtp_gemm_args* args);
 /* weight gradient: C[m][n] = sum_k A[k][m] * B[k][n]  (dW = dY^T X), f32 output. */
 int mtp_gemm_tn(const mtp_gemm_args* args, mtp_stream_t stream);
+/* Grouped weight gradients: `count` (<= MTP_MAX_GROUPED_GEMMS) independent problems C_i (M_i, N_i) f32 = A_i (K_i, M_i)^T B_i (K_i, N_i)
+ * (+ colsum_i += column sums of A_i) in ONE launch of 256 x 256 output tiles, each workgroup running the whole contraction of
+ * its tile through the 8-phase pipeline (no split-K, no partial tiles).  Meant for the weight gradients of several transformer
+ * blocks at once (4 ViT-L blocks = 768 tiles = three full rounds of the 256 CUs); results overwrite C_i.  Every problem must be
+ * bf16 in / f32 out with M_i % 256 == 0, N_i % 256 == 0, K_i % 128 == 0; otherwise MTP_ERR_UNSUPPORTED and nothing is launched
+ * (use mtp_gemm_tn per problem).  Fields epilogue / bias / res / aux / split_k / defer_sum of the entries are ignored. */
+#define MTP_MAX_GROUPED_GEMMS 32
+int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_stream_t stream);
 /* out[i] = sum over `splits[i]` partial tiles of numel[i] f32 each, stored back to back at parts[i] -- the deferred split-K
  * reductions of up to MTP_MAX_SEGMENTS weight-gradient GEMMs (args.defer_sum) in one launch.  Host arrays. */
 int mtp_sum_partials_batch(const float* const* parts, float* const* outs, const int64_t* numel, const int* splits, int count,

@@ -43,7 +43,9 @@ SIGNATURES = {
     "mtp_dcnv3_fwd": (i32, [p, p, p, p, i32, C.POINTER(Dcnv3Geom), p]),
     "mtp_dcnv3_bwd": (i32, [p, p, p, p, i32, p, p, p, C.POINTER(Dcnv3Geom), p]),
     "mtp_gemm_nt": (i32, [C.POINTER(GemmArgs), p]),
+    "mtp_gemm_nt_tile": (i32, [C.POINTER(GemmArgs)]),
     "mtp_gemm_tn": (i32, [C.POINTER(GemmArgs), p]),
+    "mtp_gemm_tn_grouped": (i32, [C.POINTER(GemmArgs), i32, p]),
     "mtp_sum_partials_batch": (i32, [p, p, p, p, i32, p]),
     "mtp_layernorm_fwd": (i32, [p, i32, p, p, p, i32, p, p, i64, i64, f32, i32, p]),
     "mtp_layernorm_bwd_partial_rows": (i64, [i64]),

@@ -17,7 +17,7 @@
 //                                         LDS untransposed (LDS-DMA) and the fragments come out of ds_read_b64_tr_b16
 //                                         (gemm_tn_tr_kernel); f32 / ragged shapes: tiles are transposed in registers (ExE
 //                                         blocks) between the coalesced global loads and the ds_write_b128.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -29,58 +29,7 @@ constexpr int OPER_BYTES = BM * ROW_BYTES;  // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * OPER_BYTES; // A + B
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;  // double buffered: 64 KiB -> 2 blocks / CU
 
-template <typename T>
-struct Mma;
-template <>
-struct Mma<bf16_t> {
-    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-    }
-};
-template <>
-struct Mma<float> {
-    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-    }
-};
-
-// 16 zero bytes in HBM: out-of-range tile elements load from here (address select BEFORE the load keeps it branch-free)
-__device__ __attribute__((aligned(16))) const uint4 g_zero16 = {0u, 0u, 0u, 0u};
-
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
-
-// bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous range of tiles
-__device__ __forceinline__ int xcd_remap(int bid, int nb) {
-    int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-struct KArgs {
-    const char* A;
-    const char* B;
-    char* C;
-    int M, N, K;
-    int64_t lda, ldb, ldc;  // in elements
-    const float* bias;
-    int bias_mod;
-    const float* res;
-    int64_t res_ld;
-    int res_mod;
-    const float* rowscale;
-    int rows_per_sample;
-    char* aux;
-    int64_t aux_ld;
-    int tiles_n;
-    int k_tiles;          // total k tiles
-    int k_tiles_per_split;
-    int atomic_out;
-    int order;              // tile order experiment: bit0 = no XCD remap, bit1 = M-fastest instead of N-fastest
-    int64_t split_stride;   // TN split-K with workspace: partial tile of split z lives at C + z*split_stride (f32 elements)
-    float* colsum;          // TN (transpose-read kernel): colsum[m] += sum_k A[k][m], or nullptr
-};
 
 // out[i] = sum_s part[s][i]   (float4 granules; deterministic split-K reduction)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n4, int split) {
@@ -110,71 +59,6 @@ __device__ __forceinline__ void compute_stage(const char* sA, const char* sB, f3
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) Mma<T>::run(acc[ni][mi], b[ni], a[mi]);
-    }
-}
-
-// ---- epilogue: lane holds C[m0 + wm*64 + mi*16 + (lane&15)][n0 + wn*64 + ni*16 + 4*(lane>>4) + 0..3] -------------
-template <typename Tout, int EPI>
-__device__ __forceinline__ void epilogue(const KArgs& p, f32x4_t (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
-    const int fr = lane & 15, g = lane >> 4;
-    Tout* C = reinterpret_cast<Tout*>(p.C);
-    // All epilogue LOADS are unconditional on clamped addresses (a branch around a load makes hipcc wait for it inside
-    // the branch: 16 serialised HBM latencies per tile); only the stores are predicated.
-    int nn[4];
-    bool nok[4];
-    float4 bias[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + g * 4;
-        nok[ni] = n < p.N;
-        nn[ni] = nok[ni] ? n : 0;
-        const float* bp = (EPI != MTP_EPI_DGELU && p.bias) ? p.bias + (p.bias_mod > 0 ? nn[ni] % p.bias_mod : nn[ni]) : reinterpret_cast<const float*>(&g_zero16);
-        const uint4 b = ldg16(bp);
-        bias[ni] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + fr;
-        const bool mok = m < p.M;
-        const int mc = mok ? m : 0;
-        if (p.atomic_out) {   // split-K weight gradient: f32 atomics into a zeroed buffer
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                if (mok && nok[ni]) {
-                    float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nn[ni];
-                    atomicAdd(c + 0, acc[ni][mi][0]); atomicAdd(c + 1, acc[ni][mi][1]); atomicAdd(c + 2, acc[ni][mi][2]); atomicAdd(c + 3, acc[ni][mi][3]);
-                }
-            continue;
-        }
-        float rs = 1.0f;
-        float4 side[4];
-        if (EPI == MTP_EPI_BIAS_RES) {
-            const float* rsp = p.rowscale ? p.rowscale + mc / p.rows_per_sample : nullptr;
-            const float* resrow = p.res + (int64_t)(p.res_mod > 0 ? mc % p.res_mod : mc) * p.res_ld;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const uint4 r = ldg16(resrow + nn[ni]);
-                side[ni] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
-            }
-            if (rsp) rs = *rsp;
-        } else if (EPI == MTP_EPI_DGELU) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) side[ni] = load4(reinterpret_cast<const Tout*>(p.aux) + (int64_t)mc * p.aux_ld + nn[ni]);
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            float4 v = make_float4(acc[ni][mi][0] + bias[ni].x, acc[ni][mi][1] + bias[ni].y, acc[ni][mi][2] + bias[ni].z, acc[ni][mi][3] + bias[ni].w);
-            const bool ok = mok && nok[ni];
-            if (EPI == MTP_EPI_BIAS_GELU) {
-                if (ok) store4(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + nn[ni], v);
-                v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
-            } else if (EPI == MTP_EPI_DGELU) {
-                v = make_float4(v.x * dgelu_f(side[ni].x), v.y * dgelu_f(side[ni].y), v.z * dgelu_f(side[ni].z), v.w * dgelu_f(side[ni].w));
-            } else if (EPI == MTP_EPI_BIAS_RES) {
-                v = make_float4(side[ni].x + rs * v.x, side[ni].y + rs * v.y, side[ni].z + rs * v.z, side[ni].w + rs * v.w);
-            }
-            if (ok) store4(C + (int64_t)m * p.ldc + nn[ni], v);
-        }
     }
 }
 
@@ -280,7 +164,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             store_nt_regs<T>(r, nxt, nxt + OPER_BYTES, tid);
         }
     }
-    epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
+    epilogue<Tout, EPI, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // Single-LDS-stage variant (32 KiB -> 4 workgroups / 16 waves per CU): thread-level parallelism across resident workgroups
@@ -315,7 +199,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         compute_stage<T>(smem, smem + OPER_BYTES, acc, wm, wn, lane);
         __syncthreads();
     }
-    epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
+    epilogue<Tout, EPI, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // Same single-stage structure at FIVE workgroups per CU (5 x 32 KiB = the whole LDS, <= 96 VGPRs): the tile loads are issued as
@@ -364,7 +248,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5
         compute_stage<T>(smem, smem + OPER_BYTES, acc, wm, wn, lane);
         __syncthreads();
     }
-    epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
+    epilogue<Tout, EPI, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), one 48 KiB stage, 2 workgroups per CU: same occupancy and per-wave work as
@@ -421,7 +305,7 @@ __global__ __launch_bounds__(NT8_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         compute_stage<T>(sA, sB, acc, wm, wn, lane);
         __syncthreads();
     }
-    epilogue<Tout, EPI>(p, acc, m0, n0, wm, wn, lane);
+    epilogue<Tout, EPI, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // ---- TN staging: ExE register transposes ------------------------------------------------------------------------------
@@ -567,7 +451,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         __builtin_amdgcn_sched_barrier(0);
         store_tn_regs<T>(r, nxt, tid);
     }
-    epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
+    epilogue<float, MTP_EPI_BIAS, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // Single-LDS-stage TN variant (32 KiB, 3 workgroups per CU): the prefetched tile waits in registers during the MFMAs and is
@@ -602,7 +486,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         __syncthreads();
         store_tn_regs<T>(r, smem, tid);
     }
-    epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
+    epilogue<float, MTP_EPI_BIAS, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // ---- TN, bf16, complete tiles: LDS-DMA staging of the UNtransposed tiles + hardware transpose reads ----------------------
@@ -714,7 +598,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             atomicAdd(p.colsum + m0 + tid, s);
         }
     }
-    epilogue<float, MTP_EPI_BIAS>(p, acc, m0, n0, wm, wn, lane);
+    epilogue<float, MTP_EPI_BIAS, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 template <typename T>
@@ -741,6 +625,20 @@ int fill_common(const mtp_gemm_args* a, KArgs& k) {
     return 0;
 }
 
+// which NT kernel family runs a bf16 problem: 0 = the 128-wide kernels of this file, 1 = gemm_p8.hip with one workgroup per
+// 256 x 256 tile, 2 = gemm_p8.hip with persistent workgroups.  variant bits 8-9 force 1 / 2 (when the problem fits), bit 10
+// forbids the kernel; bits 11-14 select an ablation build (tools/ab_gemm.py).
+int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k) {
+    if (a->in_dtype != MTP_BF16 || (a->variant & 1024) || !mtp_nt_p8_fits(k, a->out_dtype, a->epilogue)) return 0;
+    const int forced = (a->variant >> 8) & 3;
+    if (forced) return forced == 3 ? 2 : forced;
+    // default: the pipelined kernel once its 256 x 256 tiles occupy most of the 256 CUs (one workgroup per CU); below that the
+    // 128-wide kernels with 4 workgroups per CU spread a small problem better.  Measured on the ViT-L shapes (tools/ab_gemm.py):
+    // +15 % (N = 3072 / 4096, K = 1024) ... +25 % (N = 1024, K = 3072 / 4096), +23 % on the FPN GEMM.
+    const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    return tiles >= 160 ? 1 : 0;
+}
+
 template <typename T, typename Tout, int EPI>
 int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     constexpr int E = Elem<T>::kPerChunk;
@@ -751,6 +649,12 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     if (EPI == MTP_EPI_BIAS_RES && (!a->res || (a->res_ld % 4))) return MTP_ERR_ARG;
     if ((EPI == MTP_EPI_BIAS_GELU || EPI == MTP_EPI_DGELU) && (!a->aux || (a->aux_ld % 4))) return MTP_ERR_ARG;
     if (a->bias && a->bias_mod > 0 && (a->bias_mod % 4)) return MTP_ERR_ARG;
+    // 256 x 256 8-wave pipelined kernel (gemm_p8.hip; bf16, whole K-tile pairs): variant bits 8-9 = 1 one workgroup per tile,
+    // 2 persistent workgroups; falls through to the 128-wide kernels when the problem does not fit it
+    if constexpr (sizeof(T) == 2) {
+        const int p8 = nt_p8_mode(a, k);
+        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4), stream);
+    }
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);
     const bool glds = ((a->variant & 1) == 0) && (a->K % (8 * E) == 0);
@@ -892,6 +796,14 @@ extern "C" int mtp_gemm_nt(const mtp_gemm_args* a, mtp_stream_t stream) {
     if (a->in_dtype == MTP_F32 && a->out_dtype == MTP_F32) return dispatch_epi<float, float>(a, s);
     if (a->in_dtype == MTP_BF16 && a->out_dtype == MTP_F32 && a->epilogue == MTP_EPI_BIAS) return launch_nt<bf16_t, float, MTP_EPI_BIAS>(a, s);
     return MTP_ERR_UNSUPPORTED;
+}
+
+extern "C" int mtp_gemm_nt_tile(const mtp_gemm_args* a) {
+    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return MTP_ERR_ARG;
+    if (a->in_dtype != MTP_BF16) return 128;
+    KArgs k;
+    if (fill_common<bf16_t>(a, k)) return MTP_ERR_ARG;
+    return nt_p8_mode(a, k) ? 256 : 128;
 }
 
 extern "C" int mtp_sum_partials_batch(const float* const* parts, float* const* outs, const int64_t* numel, const int* splits, int count, mtp_stream_t stream) {

@@ -1,0 +1,272 @@
+// bf16 NT GEMM for gfx950, 256 x 256 x 64 tile, 8 waves (2 in M x 4 in N, 128 x 64 outputs each), ONE workgroup per CU.
+//   C[m][n] = epilogue( sum_k A[m][k] * B[n][k] )      A = activations (M, K), B = weights (N, K), both K-contiguous
+// nn.Linear forward and dgrad (VIT:50-52, 78, 87), patch-embed / ConvTranspose2d as GEMM (VIT:529, 642-649) at the
+// training shapes (M = B*196 tokens, K and N multiples of 128 / 256).
+//
+// Why this kernel exists: the 128 x 128 single-stage kernels of gemm.hip drain `vmcnt(0)` and double-barrier every K step and
+// rely on 4 resident workgroups per CU to cover it -- 0.30 of the bf16 MFMA peak in the training step.  Here the main loop is a
+// software pipeline in which no wait ever drains the load queue and the matrix pipe of every SIMD always has a wave to run:
+//
+// * LDS: 8 slots of 16 KiB = 2 K-tile buffers x 4 "half tiles" {A0, B0, B1, A1}.  A half tile is 128 rows x 64 k (128-B rows,
+//   16-B slot = chunk ^ (row & 7): the measured conflict-free image of gemm.hip).  A-half h holds the tile rows with
+//   (row >> 6) & 1 == h, i.e. the rows that are "sub-tile h" of BOTH wave rows; B-half h the columns with (col >> 5) & 1 == h.
+//   So ONE half tile is exactly what all 8 waves read in ONE phase, and its slot can be refilled one phase later.
+// * A phase = { R: ds_read one half tile into registers (8 or 4 x ds_read_b128), issue the LDS-DMA of ONE future half tile
+//   (2 x global_load_lds_dwordx4 per lane), s_waitcnt vmcnt(12), s_waitcnt lgkmcnt(0); s_barrier;  M: 16 MFMAs = one
+//   64 x 32 quadrant of the wave's outputs x K = 64; s_barrier }.  8 phases = 2 K-tiles per loop iteration:
+//       even tile (buffer 0): read A0 | B0 | A1 | B0' ; quadrants (0,1) (0,0) (1,0) (1,1)
+//       odd  tile (buffer 1): read A0'| B1'| A1'| B1''; quadrants (0,0) (0,1) (1,1) (1,0)        (' = odd tile, '' = next even)
+//   The B fragments alternate between two register sets so that the half tile a phase reads is never needed by that phase's
+//   own MFMAs' *other* operand set: every phase reads exactly one half tile (8, 4, 8, 4 ... reads) and issues one.
+// * The stream of half tiles S_0, S_1, ... is issued in the order it is read: S_{g+1} is read in phase g, S_{g+8} is issued
+//   in phase g (into the slot S_g was read from in phase g-1).  After the issue, `vmcnt(12)` leaves S_{g+3} .. S_{g+8} in
+//   flight (6 half tiles = 96 KiB per workgroup, ~7 phases ~ 1.5 us ahead of their use) and guarantees S_{g+2}, which the
+//   NEXT phase reads.  Waits are counted; the queue never drains in the loop.
+// * The two wave groups (waves 0-3 = wave row 0, waves 4-7 = wave row 1; one wave of each group per SIMD) run ONE barrier
+//   apart: while one group issues its 16 MFMAs the other does its R part, so each SIMD's matrix pipe is handed from one wave
+//   to the other at every barrier.  Hazards under that stagger (interval = span between two barriers; group 0 does R_g in
+//   interval 2g, group 1 in 2g+1):
+//     RAW  every lane waits for its own DMA pieces of S_{g+2} in R_g, i.e. by the end of interval 2g+1 all pieces have landed;
+//          S_{g+2} is read in R_{g+1} = interval 2g+2 (group 0) / 2g+3 (group 1).
+//     WAR  the reads of R_g are retired (lgkmcnt(0)) before R_g's barrier, i.e. by the end of interval 2g+1 for both groups;
+//          the slot is overwritten by DMA issued in R_{g+1} >= interval 2g+2.
+// * ds_read / LDS-DMA / waits are inline asm: hipcc neither counts nor drains them (its own bookkeeping would put vmcnt(0)
+//   in front of every ds_read that follows an LDS-DMA).  Data dependencies are made explicit with "+v" ties on the
+//   lgkmcnt(0) statement; sched_barrier(0) pins the MFMA blocks between their barriers.
+// * Accumulation order per output element is the same as in gemm.hip (k ascending, one MFMA per 32 k): results are
+//   bit-identical to the 128-wide kernels.
+#include "gemm_p8.h"
+
+namespace {
+
+struct P8Ctx {
+    uint32_t addrA[2][2];    // ds_read base of the wave's A fragments, [buffer][k-step]  (per lane)
+    uint32_t addrB[2][2];
+    uint32_t voffA, voffB;   // per-lane byte offset of the DMA source (row-in-piece, swizzled chunk, current k)
+    const char* pA[2][2];    // wave-uniform DMA source row bases [half][piece]
+    const char* pB[2][2];
+    uint32_t m0base;         // LDS address of this wave's first DMA piece in slot 0
+};
+
+template <int IMM>
+__device__ __forceinline__ void dsr(u32x4_t& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(IMM));
+}
+
+template <int SK, int SBUF>
+__device__ __forceinline__ void nt_stage(const P8Ctx& c) {
+    constexpr int h = (SK == KA1 || SK == KB1) ? 1 : 0;
+    const uint32_t l0 = c.m0base + SBUF * P8_BUF + SK * P8_HALF;
+    if constexpr (SK == KA0 || SK == KA1)
+        glds2(c.voffA, c.pA[h][0], c.pA[h][1], l0, l0 + 1024);
+    else
+        glds2(c.voffB, c.pB[h][0], c.pB[h][1], l0, l0 + 1024);
+}
+
+// read one A half tile (8 fragments) / one B half tile (4 fragments) of buffer BUF, slot K
+template <int K, int BUF>
+__device__ __forceinline__ void nt_read_a(const P8Ctx& c, u32x4_t (&a)[2][4]) {
+    constexpr int o = K * P8_HALF;
+    dsr<o + 0 * 2048>(a[0][0], c.addrA[BUF][0]); dsr<o + 1 * 2048>(a[0][1], c.addrA[BUF][0]);
+    dsr<o + 2 * 2048>(a[0][2], c.addrA[BUF][0]); dsr<o + 3 * 2048>(a[0][3], c.addrA[BUF][0]);
+    dsr<o + 0 * 2048>(a[1][0], c.addrA[BUF][1]); dsr<o + 1 * 2048>(a[1][1], c.addrA[BUF][1]);
+    dsr<o + 2 * 2048>(a[1][2], c.addrA[BUF][1]); dsr<o + 3 * 2048>(a[1][3], c.addrA[BUF][1]);
+}
+template <int K, int BUF>
+__device__ __forceinline__ void nt_read_b(const P8Ctx& c, u32x4_t (&b)[2][2]) {
+    constexpr int o = K * P8_HALF;
+    dsr<o + 0 * 2048>(b[0][0], c.addrB[BUF][0]); dsr<o + 1 * 2048>(b[0][1], c.addrB[BUF][0]);
+    dsr<o + 0 * 2048>(b[1][0], c.addrB[BUF][1]); dsr<o + 1 * 2048>(b[1][1], c.addrB[BUF][1]);
+}
+// retire the ds_reads; the "+v" ties make every consumer of the fragments depend on this statement
+__device__ __forceinline__ void wait_a(u32x4_t (&a)[2][4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+}
+__device__ __forceinline__ void wait_b(u32x4_t (&b)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
+}
+
+// operand policy of the pipeline (gemm_p8.h) for K-contiguous operands
+struct NtOps {
+    typedef P8Ctx Ctx;
+    static constexpr int kLoadsPerPiecePair = 2;   // DMA instructions per lane and half tile
+    template <int K, int BUF> static __device__ __forceinline__ void read_a(Ctx& c, u32x4_t (&a)[2][4]) { nt_read_a<K, BUF>(c, a); }
+    template <int K, int BUF> static __device__ __forceinline__ void read_b(Ctx& c, u32x4_t (&b)[2][2]) { nt_read_b<K, BUF>(c, b); }
+    template <int SK, int SBUF> static __device__ __forceinline__ void stage(Ctx& c) { nt_stage<SK, SBUF>(c); }
+    template <int K, int BUF> static __device__ __forceinline__ void retire_a(Ctx&, u32x4_t (&a)[2][4]) { wait_a(a); }
+    static __device__ __forceinline__ void retire_b(u32x4_t (&b)[2][2]) { wait_b(b); }
+    static __device__ __forceinline__ void next_ktile(Ctx& c) { c.voffA += 128; c.voffB += 128; }
+};
+
+template <typename Tout, int EPI, bool PERSIST, int XP>
+__global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_p8_kernel(KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, g = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
+    const int tiles_m = (p.M + P8_BM - 1) / P8_BM, tiles_n = p.tiles_n, ntiles = tiles_m * tiles_n;
+    const int plain = p.order & 1;
+    const int pairs = p.k_tiles >> 1;
+
+    P8Ctx c;
+    {
+        // fragment row fr of a 16-row group, 16-B slot (chunk ^ (row & 7)) with chunk = 4 * kstep + g: k-step 1 flips byte bit 6
+        const uint32_t lanepart = (uint32_t)(fr * 128 + ((g ^ (fr & 7)) << 4));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            c.addrA[b][0] = lds0 + b * P8_BUF + wr * 8192 + lanepart;
+            c.addrA[b][1] = lds0 + b * P8_BUF + wr * 8192 + (lanepart ^ 64u);
+            c.addrB[b][0] = lds0 + b * P8_BUF + wc * 4096 + lanepart;
+            c.addrB[b][1] = lds0 + b * P8_BUF + wc * 4096 + (lanepart ^ 64u);
+        }
+        c.m0base = lds0 + wave * 2048;
+    }
+    const uint32_t lanesrc = (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
+    const uint32_t voffA0 = (uint32_t)((lane >> 3) * (int)p.lda * 2) + lanesrc;
+    const uint32_t voffB0 = (uint32_t)((lane >> 3) * (int)p.ldb * 2) + lanesrc;
+
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        int tm, tn;
+        tile_coords(plain ? vb : xcd_remap(vb, ntiles), tiles_m, tiles_n, plain, tm, tn);
+        const int m0 = tm * P8_BM, n0 = tn * P8_BN;
+        // DMA source rows of this wave: A-half h, piece i: tile row (wave>>2)*128 + h*64 + (wave&3)*16 + i*8 (+ lane>>3);
+        // B-half h, piece i: tile column (wave>>1)*64 + h*32 + (wave&1)*16 + i*8 (+ lane>>3).  Rows past the edge are
+        // clamped to the last complete 8-row piece (their outputs are never stored).
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int ra = m0 + (wave >> 2) * 128 + h * 64 + (wave & 3) * 16 + i * 8;
+                int rb = n0 + (wave >> 1) * 64 + h * 32 + (wave & 1) * 16 + i * 8;
+                ra = ra < p.M - 8 ? ra : p.M - 8;
+                rb = rb < p.N - 8 ? rb : p.N - 8;
+                c.pA[h][i] = p.A + (int64_t)ra * p.lda * 2;
+                c.pB[h][i] = p.B + (int64_t)rb * p.ldb * 2;
+            }
+        c.voffA = voffA0;
+        c.voffB = voffB0;
+
+        u32x4_t a[2][4], b0[2][2], b1[2][2];
+        f32x4_t acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        // ---- prologue: S_0 .. S_7 = B1 A0 B0 A1 of tile 0 (buffer 0), B0 A0 B1 A1 of tile 1 (buffer 1)
+        nt_stage<KB1, 0>(c); nt_stage<KA0, 0>(c); nt_stage<KB0, 0>(c); nt_stage<KA1, 0>(c);
+        c.voffA += 128; c.voffB += 128;
+        nt_stage<KB0, 1>(c); nt_stage<KA0, 1>(c); nt_stage<KB1, 1>(c); nt_stage<KA1, 1>(c);
+        c.voffA += 128; c.voffB += 128;
+        if (PERSIST && vb != (int)blockIdx.x)
+            wait_vm<0>();    // the previous tile's epilogue stores are in the queue as well: drain everything once per tile
+        else
+            wait_vm<12>();   // S_0, S_1 have landed (this lane's pieces)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        nt_read_b<KB1, 0>(c, b1);
+        wait_b(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (!(XP & 2) && wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
+        __builtin_amdgcn_sched_barrier(0);
+
+        for (int it = 0; it < pairs - 1; ++it) two_tiles<NtOps, false, XP>(c, a, b0, b1, acc);
+        two_tiles<NtOps, true, XP>(c, a, b0, b1, acc);
+
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(XP & 2) && wr == 0) __builtin_amdgcn_s_barrier();   // re-align: every wave has finished its last phase behind this barrier
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (!(XP & 4) || p.M < 0) {
+            if constexpr (XP & 16)   // A/B: straight out of the MFMA layout (the epilogue of the 128-wide kernels)
+                epilogue<Tout, EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+            else
+                epilogue_lds<Tout, EPI>(p, acc, smem + wave * P8_HALF, m0 + wr * 128, n0 + wc * 64, lane);
+        }
+        if (!PERSIST) break;
+        __syncthreads();   // the next tile's DMA lands in every wave's epilogue region
+    }
+}
+
+int p8_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        ncu = prop.multiProcessorCount;
+    }
+    return ncu;
+}
+
+template <typename Tout, int EPI, bool PERSIST, int XP>
+int launch_p8_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
+    static bool attr = false;   // 128 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<Tout, EPI, PERSIST, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    const int ncu = p8_cus();
+    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, PERSIST, XP>), dim3(PERSIST ? (ntiles < ncu ? ntiles : ncu) : ntiles), dim3(P8_THREADS), P8_LDS, stream, a);
+    return mtp_launch_status();
+}
+
+template <typename Tout, int EPI>
+int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
+    const int tiles_m = (k.M + P8_BM - 1) / P8_BM, tiles_n = (k.N + P8_BN - 1) / P8_BN;
+    KArgs a = k;
+    a.tiles_n = tiles_n;
+    a.k_tiles = k.K / 64;
+    a.order = (flags >> 1) & 1;
+    a.atomic_out = 0;
+    const int ntiles = tiles_m * tiles_n;
+    if constexpr (EPI == MTP_EPI_BIAS && sizeof(Tout) == 2) {   // ablation builds of the plain bf16 kernel only
+        switch ((flags >> 4) & 15) {
+            case 0: break;
+            case 1: return launch_p8_kernel<Tout, EPI, false, 1>(a, ntiles, stream);
+            case 2: return launch_p8_kernel<Tout, EPI, false, 2>(a, ntiles, stream);
+            case 3: return launch_p8_kernel<Tout, EPI, false, 3>(a, ntiles, stream);
+            case 4: return launch_p8_kernel<Tout, EPI, false, 4>(a, ntiles, stream);
+            case 8: return launch_p8_kernel<Tout, EPI, false, 8>(a, ntiles, stream);
+            case 12: return launch_p8_kernel<Tout, EPI, false, 12>(a, ntiles, stream);
+            case 15: return launch_p8_kernel<Tout, EPI, false, 16>(a, ntiles, stream);   // (variant field is 4 bits wide: 15 = direct epilogue)
+            default: return MTP_ERR_UNSUPPORTED;
+        }
+    }
+    if (flags & 1) return launch_p8_kernel<Tout, EPI, true, 0>(a, ntiles, stream);
+    return launch_p8_kernel<Tout, EPI, false, 0>(a, ntiles, stream);
+}
+
+template <typename Tout>
+int dispatch_p8(const KArgs& k, int epi, int flags, hipStream_t s) {
+    switch (epi) {
+        case MTP_EPI_BIAS: return launch_p8<Tout, MTP_EPI_BIAS>(k, flags, s);
+        case MTP_EPI_BIAS_GELU: return launch_p8<Tout, MTP_EPI_BIAS_GELU>(k, flags, s);
+        case MTP_EPI_DGELU: return launch_p8<Tout, MTP_EPI_DGELU>(k, flags, s);
+        default: return MTP_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+int mtp_nt_p8_fits(const KArgs& k, int out_dtype, int epi) {
+    // preconditions: whole K tiles in pairs, 8-row DMA pieces, 32-bit DMA offsets, an epilogue instantiation
+    if (k.K < 128 || (k.K % 128) || (k.M % 8) || (k.N % 8) || k.M < 8 || k.N < 8) return 0;
+    if ((uint64_t)k.lda * 2 * 8 + (uint64_t)k.K * 2 >= (1ull << 31) || (uint64_t)k.ldb * 2 * 8 + (uint64_t)k.K * 2 >= (1ull << 31)) return 0;
+    if (epi == MTP_EPI_BIAS_RES) return out_dtype == MTP_F32;
+    if (out_dtype == MTP_BF16) return epi == MTP_EPI_BIAS || epi == MTP_EPI_BIAS_GELU || epi == MTP_EPI_DGELU;
+    return out_dtype == MTP_F32 && epi == MTP_EPI_BIAS;
+}
+
+int mtp_nt_p8_launch(const KArgs& k, int out_dtype, int epi, int flags, hipStream_t stream) {
+    if (!mtp_nt_p8_fits(k, out_dtype, epi)) return MTP_ERR_UNSUPPORTED;
+    if (epi == MTP_EPI_BIAS_RES) return launch_p8<float, MTP_EPI_BIAS_RES>(k, flags, stream);
+    if (out_dtype == MTP_BF16) return dispatch_p8<bf16_t>(k, epi, flags, stream);
+    return launch_p8<float, MTP_EPI_BIAS>(k, flags, stream);
+}

@@ -1,0 +1,266 @@
+// Grouped weight-gradient GEMM for gfx950 on the 8-phase pipeline of gemm_p8.h:  dW_j[m][n] = sum_t dY_j[t][m] * X_j[t][n]
+// (nn.Linear backward w.r.t. the weight, VIT:50-52, 78, 87; f32 out) for a LIST of problems in one launch, 256 x 256 tiles,
+// the whole contraction (T = B*196 tokens) inside one workgroup.
+//
+// Why grouped: one such GEMM has 16 .. 64 tiles of 256 x 256 -- far fewer than the 256 CUs.  The 128-wide kernels of gemm.hip
+// therefore split the contraction 4-16 ways and pay for it: 64 MB of f32 partial tiles written and re-read per GEMM plus a
+// reduction launch (0.71 of ~1.0 PF/s in the step, 11.6 ms).  The four weight gradients of a transformer block do not depend
+// on each other, only on tensors the backward pass keeps anyway (dY of the layer and its saved input), so the host defers them
+// and launches the weight gradients of FOUR blocks together: 4 x (48 + 16 + 64 + 64) = 768 tiles = exactly three rounds of one
+// workgroup per CU, each tile accumulating all 196 K-tiles in registers and storing its f32 result once.  No split-K, no
+// partials, no reduction kernel, no quantisation loss.
+//
+// Operands are token-major as they lie in memory ([t][feature], feature contiguous): both go HBM -> LDS untransposed by LDS-DMA
+// and the MFMA fragments (8 consecutive t per lane) come out of the gfx950 transpose read ds_read_b64_tr_b16 -- the layout of
+// gemm_tn_tr_kernel (gemm.hip; probed with tools/tr_probe.hip): half tile = [64 t][128 features] (256-B rows), 32-B slot pair
+// (16 features) ^= f(t), f = (t & 3) | ((t >> 3) & 1) << 2, applied on the per-lane DMA SOURCE address.  A-half h holds the 64
+// feature columns "sub-tile h" of each of the two wave rows, B-half j the 32 columns "sub-tile j" of each of the four wave
+// columns, exactly as in the NT kernel, so the phase schedule is shared.
+// Bias gradient (column sums of dY) as a by-product: the workgroups of tile column 0 also add up the dY half tiles out of LDS.
+#include "gemm_p8.h"
+
+namespace {
+
+typedef short tr_v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char_t;
+constexpr int TN_MAX_PROBLEMS = MTP_MAX_GROUPED_GEMMS;
+
+struct TnProb {
+    const char* A;      // dY (Kc, M) bf16, lda
+    const char* B;      // X  (Kc, N) bf16, ldb
+    float* C;           // dW (M, N) f32, ldc
+    float* colsum;      // += column sums of A (M entries) or nullptr
+    int M, N, K;
+    int lda, ldb, ldc;
+    int tile0, tiles_m, tiles_n;
+    int pad_;
+};
+struct TnGroup {
+    TnProb p[TN_MAX_PROBLEMS];
+    int nprob, ntiles, plain;
+};
+
+struct T8Ctx {
+    lds_char_t* smem;        // LDS base (the transpose reads go through the builtin: compiler-visible LDS loads)
+    uint32_t offA[2][4];     // per-lane byte offset of fragment mi (k-step 0, rows 0-3) in buffer b
+    uint32_t offB[2][2];
+    uint32_t voffA, voffB;   // per-lane DMA source offsets (row in piece, swizzled 16-B chunk, current k)
+    uint32_t kstepA, kstepB; // bytes per K-tile: 64 rows
+    const char* pA[2][2];    // wave-uniform DMA source bases [half][piece]
+    const char* pB[2][2];
+    uint32_t m0base;         // LDS address of this wave's first DMA piece in slot 0
+    bool colsum;             // workgroup-uniform: also sum the A half tiles over t
+    uint32_t csoff;          // per-lane byte offset of the column-sum reads inside a half tile
+    float cs[2][8];          // [half][column of the lane's 16-B chunk]
+};
+
+__device__ __forceinline__ u32x4_t tr_frag8(lds_char_t* s) {
+    const tr_v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s_t*)(s));
+    const tr_v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s_t*)(s + 1024));
+    const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return u32x4_t{l.x, l.y, h.x, h.y};
+}
+
+struct TnOps {
+    typedef T8Ctx Ctx;
+    static constexpr int kLoadsPerPiecePair = 2;
+    template <int K, int BUF>
+    static __device__ __forceinline__ void read_a(Ctx& c, u32x4_t (&a)[2][4]) {
+        lds_char_t* s = c.smem + K * P8_HALF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[ks][mi] = tr_frag8(s + c.offA[BUF][mi] + ks * 8192);
+    }
+    template <int K, int BUF>
+    static __device__ __forceinline__ void read_b(Ctx& c, u32x4_t (&b)[2][2]) {
+        lds_char_t* s = c.smem + K * P8_HALF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ks][ni] = tr_frag8(s + c.offB[BUF][ni] + ks * 8192);
+    }
+    template <int SK, int SBUF>
+    static __device__ __forceinline__ void stage(Ctx& c) {
+        constexpr int h = (SK == KA1 || SK == KB1) ? 1 : 0;
+        const uint32_t l0 = c.m0base + SBUF * P8_BUF + SK * P8_HALF;
+        if constexpr (SK == KA0 || SK == KA1)
+            glds2(c.voffA, c.pA[h][0], c.pA[h][1], l0, l0 + 1024);
+        else
+            glds2(c.voffB, c.pB[h][0], c.pB[h][1], l0, l0 + 1024);
+    }
+    // the fragment reads are compiler-visible LDS loads: the asm wait below (a memory barrier for the compiler) retires them
+    // before the phase's barrier, which is what lets the slot be refilled one phase later (WAR rule of gemm_p8.hip)
+    template <int K, int BUF>
+    static __device__ __forceinline__ void retire_a(Ctx& c, u32x4_t (&)[2][4]) {
+        if (c.colsum) {   // rows r and r + 32 of the half tile share the swizzle, i.e. the lane's 16-B piece is the same 8 columns
+            constexpr int h = K == KA1 ? 1 : 0;
+            typedef __attribute__((address_space(3))) const u32x4_t lds_u32x4_t;
+            const u32x4_t w0 = *reinterpret_cast<lds_u32x4_t*>(c.smem + BUF * P8_BUF + K * P8_HALF + c.csoff);
+            const u32x4_t w1 = *reinterpret_cast<lds_u32x4_t*>(c.smem + BUF * P8_BUF + K * P8_HALF + c.csoff + 8192);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                c.cs[h][2 * e] += __uint_as_float(w0[e] << 16) + __uint_as_float(w1[e] << 16);
+                c.cs[h][2 * e + 1] += __uint_as_float(w0[e] & 0xffff0000u) + __uint_as_float(w1[e] & 0xffff0000u);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    static __device__ __forceinline__ void retire_b(u32x4_t (&)[2][2]) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    static __device__ __forceinline__ void next_ktile(Ctx& c) {
+        c.voffA += c.kstepA;
+        c.voffB += c.kstepB;
+    }
+};
+
+__global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_p8_kernel(TnGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
+
+    // ---- which problem, which tile
+    const int vt = grp.plain ? (int)blockIdx.x : xcd_remap(blockIdx.x, grp.ntiles);
+    int pi = 0;
+#pragma unroll 1
+    while (pi + 1 < grp.nprob && vt >= grp.p[pi + 1].tile0) ++pi;
+    const TnProb& q = grp.p[pi];
+    int tm, tn;
+    tile_coords(vt - q.tile0, q.tiles_m, q.tiles_n, grp.plain, tm, tn);
+    const int m0 = tm * P8_BM, n0 = tn * P8_BN;
+    const int pairs = q.K >> 7;
+
+    T8Ctx c;
+    c.smem = (lds_char_t*)smem;
+    {
+        const int i = lane & 15, g = lane >> 4;
+        const int fr_ = (i >> 2) | ((g & 1) << 2);                                   // f(t) of the rows this lane addresses
+        const uint32_t rowoff = (uint32_t)((8 * g + (i >> 2)) * 256 + (i & 3) * 8);   // row 8g + i/4 (+4: second read), columns 4(i&3)..
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) c.offA[b][mi] = b * P8_BUF + rowoff + (uint32_t)((((wr * 4 + mi) ^ fr_)) << 5);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) c.offB[b][ni] = b * P8_BUF + rowoff + (uint32_t)((((wc * 2 + ni) ^ fr_)) << 5);
+        }
+        c.m0base = lds0 + wave * 2048;
+        // DMA: piece (wave, i) = half-tile rows wave*8 + i*4 + (lane >> 4); LDS 16-B position lane & 15 receives global chunk
+        // (lane & 15) ^ (f << 1) with f = f(row) = (lane >> 4) | (wave & 1) << 2
+        const int fd = (lane >> 4) | ((wave & 1) << 2);
+        const int ch = (lane & 15) ^ (fd << 1);
+        const int colA = (ch >> 3) * 128 + (ch & 7) * 8;    // A-half: wave row (ch >> 3), 64 columns of it
+        const int colB = (ch >> 2) * 64 + (ch & 3) * 8;     // B-half: wave column (ch >> 2), 32 columns of it
+        c.voffA = (uint32_t)((lane >> 4) * q.lda * 2 + colA * 2);
+        c.voffB = (uint32_t)((lane >> 4) * q.ldb * 2 + colB * 2);
+        c.kstepA = (uint32_t)(64 * q.lda * 2);
+        c.kstepB = (uint32_t)(64 * q.ldb * 2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                c.pA[h][pc] = q.A + ((int64_t)(wave * 8 + pc * 4) * q.lda + m0 + h * 64) * 2;
+                c.pB[h][pc] = q.B + ((int64_t)(wave * 8 + pc * 4) * q.ldb + n0 + h * 32) * 2;
+            }
+        c.colsum = q.colsum != nullptr && tn == 0;
+        c.csoff = (uint32_t)((tid >> 4) * 256 + (tid & 15) * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c.cs[h][e] = 0.f;
+    }
+
+    u32x4_t a[2][4], b0[2][2], b1[2][2];
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: S_0 .. S_7 = B1 A0 B0 A1 of K-tile 0 (buffer 0), B0 A0 B1 A1 of K-tile 1 (buffer 1)
+    TnOps::stage<KB1, 0>(c); TnOps::stage<KA0, 0>(c); TnOps::stage<KB0, 0>(c); TnOps::stage<KA1, 0>(c);
+    c.voffA += c.kstepA; c.voffB += c.kstepB;
+    TnOps::stage<KB0, 1>(c); TnOps::stage<KA0, 1>(c); TnOps::stage<KB1, 1>(c); TnOps::stage<KA1, 1>(c);
+    c.voffA += c.kstepA; c.voffB += c.kstepB;
+    wait_vm<12>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    TnOps::read_b<KB1, 0>(c, b1);
+    TnOps::retire_b(b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int it = 0; it < pairs - 1; ++it) two_tiles<TnOps, false, 0>(c, a, b0, b1, acc);
+    two_tiles<TnOps, true, 0>(c, a, b0, b1, acc);
+
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (c.colsum) {
+        // 32 row groups (tid >> 4) hold partial sums of the same 8 columns: reduce through LDS, one atomic per column
+        float* red = reinterpret_cast<float*>(smem);
+        const int rg = tid >> 4;
+        const int f = (rg & 3) | ((rg >> 1) & 4);
+        const int ch = (tid & 15) ^ (f << 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(red + (h * 32 + rg) * 128 + ch * 8) = make_float4(c.cs[h][0], c.cs[h][1], c.cs[h][2], c.cs[h][3]);
+            *reinterpret_cast<float4*>(red + (h * 32 + rg) * 128 + ch * 8 + 4) = make_float4(c.cs[h][4], c.cs[h][5], c.cs[h][6], c.cs[h][7]);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int h = tid >> 7, x = tid & 127;     // x = chunk * 8 + e inside the half tile image
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) s += red[(h * 32 + r) * 128 + x];
+            const int col = (x >> 6) * 128 + h * 64 + (x & 63);
+            atomicAdd(q.colsum + m0 + col, s);
+        }
+        __syncthreads();
+    }
+
+    KArgs o = {};
+    o.C = reinterpret_cast<char*>(q.C);
+    o.M = q.M; o.N = q.N; o.ldc = q.ldc;
+    epilogue_lds<float, MTP_EPI_BIAS>(o, acc, smem + wave * P8_HALF, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
+}  // namespace
+
+// Every problem: bf16 operands, f32 output, M and N multiples of 256, contraction a multiple of 128, 16-byte aligned rows.
+extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_stream_t stream) {
+    if (!args || count <= 0) return MTP_ERR_ARG;
+    if (count > TN_MAX_PROBLEMS) return MTP_ERR_UNSUPPORTED;
+    TnGroup g = {};
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const mtp_gemm_args& a = args[i];
+        if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return MTP_ERR_ARG;
+        if (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15) return MTP_ERR_ARG;
+        if (a.in_dtype != MTP_BF16 || a.out_dtype != MTP_F32) return MTP_ERR_UNSUPPORTED;
+        if ((a.M % P8_BM) || (a.N % P8_BN) || (a.K % 128) || (a.lda % 8) || (a.ldb % 8) || (a.ldc % 4)) return MTP_ERR_UNSUPPORTED;
+        if ((uint64_t)a.K * (uint64_t)a.lda * 2 >= (1ull << 32) || (uint64_t)a.K * (uint64_t)a.ldb * 2 >= (1ull << 32)) return MTP_ERR_UNSUPPORTED;
+        TnProb& q = g.p[i];
+        q.A = (const char*)a.A; q.B = (const char*)a.B; q.C = (float*)a.C; q.colsum = a.colsum;
+        q.M = (int)a.M; q.N = (int)a.N; q.K = (int)a.K;
+        q.lda = (int)a.lda; q.ldb = (int)a.ldb; q.ldc = (int)a.ldc;
+        q.tiles_m = q.M / P8_BM; q.tiles_n = q.N / P8_BN;
+        q.tile0 = tiles;
+        tiles += q.tiles_m * q.tiles_n;
+    }
+    g.nprob = count;
+    g.ntiles = tiles;
+    g.plain = (args[0].variant >> 1) & 1;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_p8_kernel, dim3(tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);
+    return mtp_launch_status();
+}

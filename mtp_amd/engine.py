@@ -194,17 +194,18 @@ class BackboneEngine:
         T = dx2.shape[0]
         # ---- MLP branch
         # (bias gradients = column sums of dY: by-product of the dW GEMM that streams dY anyway)
-        pend = []   # split-K partial tiles of this block's four weight gradients: reduced by ONE launch at the end of the block
-        ops.gemm_tn(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], colsum=G[pre + "mlp.fc2.bias"], defer=pend)
+        # (weight gradients: queued, launched together with those of the neighbouring blocks -- ops.WgradQueue)
+        wq = self._wq
+        wq.add(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], G[pre + "mlp.fc2.bias"])
         du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_DGELU, aux=s["u"])
-        ops.gemm_tn(du, s["ln2"], G[pre + "mlp.fc1.weight"], colsum=G[pre + "mlp.fc1.bias"], defer=pend)
+        wq.add(du, s["ln2"], G[pre + "mlp.fc1.weight"], G[pre + "mlp.fc1.bias"])
         dln2 = ops.gemm_nt(du, b.w1T, self._e(T, C))
         del du
         dx1, dx1_act = self._e(T, C, dtype=F32), self._e(T, C)
         self._ln_bwd(dln2, s["x1"], s["mean2"], s["rstd2"], P[pre + "norm2.weight"], dx1, G[pre + "norm2.weight"], G[pre + "norm2.bias"],
                           dres=dx2, dx_copy=dx1_act, copy_scale=dps[0], rows_per_sample=N)
         # ---- attention branch
-        ops.gemm_tn(dx1_act, s["o"], G[pre + "attn.proj.weight"], colsum=G[pre + "attn.proj.bias"], defer=pend)
+        wq.add(dx1_act, s["o"], G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"])
         do = ops.gemm_nt(dx1_act, b.wprojT, self._e(T, C))
         dqkv = self._e(T, 3 * C)
         if b.window:
@@ -231,14 +232,13 @@ class BackboneEngine:
                 drel_h, drel_w = self._e(*rel_h.shape, dtype=F32), self._e(*rel_w.shape, dtype=F32)
             ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, self.heads, self.scale,
                               accumulate=True)
-        ops.gemm_tn(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], colsum=G[pre + "attn.qkv.bias"], defer=pend)
+        wq.add(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], G[pre + "attn.qkv.bias"])
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         if b.window:
             ops.rvsa_pool_bwd(dpooled, s["avg"], dln1, B, Hp, Wp, accumulate=True)
         dx0, dx0_act = self._e(T, C, dtype=F32), self._e(T, C)
         self._ln_bwd(dln1, s["x"], s["mean1"], s["rstd1"], P[pre + "norm1.weight"], dx0, G[pre + "norm1.weight"], G[pre + "norm1.bias"],
                           dres=dx1, extra=extra, dx_copy=dx0_act, copy_scale=prev_scale, rows_per_sample=N)
-        ops.sum_partials(pend)
         return dx0, dx0_act
 
     # ------------------------------------------------------------------ whole forward
@@ -423,6 +423,8 @@ class BackboneEngine:
         dx = tapgrad[last]
         # ACT copy of the output gradient of the last block, scaled by its mlp drop-path factor
         dx_act = self._scaled_copy(dx, dps[last][1], N)
+        self._wq = wq = ops.WgradQueue()
+        waiting = []     # blocks whose weight gradients are still queued: on_block_done fires once they have been launched
         for i in range(last, -1, -1):
             s = saved[i]
             if ctx["ckpt"]:
@@ -431,8 +433,13 @@ class BackboneEngine:
             prev_scale = dps[i - 1][1] if i > 0 else None
             dx, dx_act = self._block_bwd(i, s, dx, dx_act, B, Hp, Wp, dps[i], G, extra, prev_scale)
             saved[i] = None
-            if on_block_done is not None:
-                on_block_done(i)
+            waiting.append(i)
+            if i == 0 or wq.should_flush():
+                wq.flush()
+                if on_block_done is not None:
+                    for j in waiting:
+                        on_block_done(j)
+                waiting = []
         # ---- patch embed / pos embed
         ops.gemm_tn(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1), colsum=G["patch_embed.proj.bias"])
         if "pos_embed" in G:

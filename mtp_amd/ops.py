@@ -45,9 +45,7 @@ def _f32(t):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-def gemm_nt(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0, rowscale=None, rows_per_sample=0,
-            aux=None, variant=0):
-    """out (M,N) = epilogue(a (M,K) @ w (N,K)^T)."""
+def _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sample, aux, variant):
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and tuple(out.shape) == (M, N) and a.dtype == w.dtype
@@ -63,8 +61,25 @@ def gemm_nt(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0,
     if aux is not None:
         assert aux.dtype == out.dtype and tuple(aux.shape) == (M, N)
     g.split_k, g.variant = 1, variant or _NT_VARIANT
+    return g
+
+
+def gemm_nt(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0, rowscale=None, rows_per_sample=0,
+            aux=None, variant=0):
+    """out (M,N) = epilogue(a (M,K) @ w (N,K)^T)."""
+    g = _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sample, aux, variant)
     check(lib().mtp_gemm_nt(C.byref(g), _s()), "mtp_gemm_nt")
     return out
+
+
+def gemm_nt_tile(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0, rowscale=None, rows_per_sample=0,
+                 aux=None, variant=0):
+    """tile width (256 / 128) of the kernel family gemm_nt(...) runs these arguments on (no launch)"""
+    g = _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sample, aux, variant)
+    rc = lib().mtp_gemm_nt_tile(C.byref(g))
+    if rc < 0:
+        check(rc, "mtp_gemm_nt_tile")
+    return rc
 
 
 def pick_split_k(M, N, K):
@@ -101,6 +116,64 @@ def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None,
             defer.append((ws, out, M * N, g.split_k))
     check(lib().mtp_gemm_tn(C.byref(g), _s()), "mtp_gemm_tn")
     return out
+
+
+MAX_GROUPED = 32      # MTP_MAX_GROUPED_GEMMS
+_NO_GROUPED = bool(int(__import__("os").environ.get("MTP_NO_GROUPED_WGRAD", "0")))   # A/B: every weight gradient through mtp_gemm_tn
+
+
+def grouped_tiles(M, N):
+    """256 x 256 output tiles of one problem in mtp_gemm_tn_grouped, or 0 when it cannot take the problem"""
+    return (M // 256) * (N // 256) if M % 256 == 0 and N % 256 == 0 else 0
+
+
+class WgradQueue:
+    """Deferred weight gradients dW = dY^T X (+ bias gradient = column sums of dY): the weight gradients of a transformer block
+    depend only on tensors the backward pass has anyway, so they are collected and launched together -- ONE
+    mtp_gemm_tn_grouped launch whose 256 x 256 tiles fill the 256 CUs in whole rounds (4 ViT-L blocks = 768 tiles = 3 rounds),
+    each tile with the full contraction: no split-K partials, no reduction launches.  Problems the grouped kernel cannot take
+    (f32 parity mode, sizes that are not multiples of 256 / 128) run immediately through gemm_tn."""
+
+    def __init__(self, cus=256):
+        self.jobs, self.tiles, self.cus = [], 0, cus
+
+    def add(self, dy, x, dw, colsum=None):
+        K, M = dy.shape
+        N = x.shape[1]
+        t = grouped_tiles(M, N)
+        if _NO_GROUPED or t == 0 or K % 128 or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
+            gemm_tn(dy, x, dw, colsum=colsum)
+            return False
+        assert x.shape[0] == K and dw.dtype == torch.float32 and dw.numel() == M * N and dw.is_contiguous()
+        self.jobs.append((dy, x, dw, colsum))     # (the references keep dY / X alive until the launch)
+        self.tiles += t
+        return True
+
+    def should_flush(self, next_tiles=0, next_jobs=4):
+        """whole rounds of the CUs, or no room for another block's problems"""
+        if not self.jobs:
+            return False
+        if len(self.jobs) + next_jobs > MAX_GROUPED:
+            return True
+        rounds = -(-self.tiles // self.cus)
+        return self.tiles / (rounds * self.cus) >= 0.93
+
+    def flush(self):
+        while self.jobs:
+            chunk, self.jobs = self.jobs[:MAX_GROUPED], self.jobs[MAX_GROUPED:]
+            arr = (GemmArgs * len(chunk))()
+            for g, (dy, x, dw, cs) in zip(arr, chunk):
+                K, M = dy.shape
+                N = x.shape[1]
+                g.A, g.B, g.C = _p(dy), _p(x), _p(dw)
+                g.M, g.N, g.K = M, N, K
+                g.lda, g.ldb, g.ldc = M, N, N
+                g.in_dtype, g.out_dtype = MTP_BF16, MTP_F32
+                if cs is not None:
+                    assert cs.dtype == torch.float32 and cs.numel() == M and cs.is_contiguous()
+                    g.colsum = _p(cs)
+            check(lib().mtp_gemm_tn_grouped(arr, len(chunk), _s()), "mtp_gemm_tn_grouped")
+        self.tiles = 0
 
 
 def sum_partials(jobs):

@@ -100,6 +100,75 @@ def test_gemm_nt_tile_variants_bit_identical(ops, dtype):
             assert torch.equal(x, y), v
 
 
+# ---- the 256 x 256 8-wave pipelined kernel (gemm_p8.hip): variant 256 = one workgroup per tile, 512 = persistent workgroups
+P8_SHAPES = [(256, 256, 128),      # one tile, the shortest pipeline (one K-tile pair: prologue + drain only)
+             (512, 768, 256),      # 6 tiles, two pairs
+             (392, 264, 384),      # ragged M and N edges (clamped DMA rows, predicated stores)
+             (6272, 1024, 768),    # ViT-B token count (24.5 tile rows), patch-embed contraction
+             (1568, 2304, 1024)]   # more tiles than a quick run has CUs busy: several rounds / persistent tile loop
+
+
+@pytest.mark.parametrize("variant", [256, 512, 258])
+@pytest.mark.parametrize("M,N,K", P8_SHAPES)
+def test_gemm_nt_p8_vs_oracle(ops, variant, M, N, K):
+    dtype = torch.bfloat16
+    a, w, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.1), rnd(N, seed=2)
+    da, dw, out = dev(a, dtype), dev(w, dtype), e(M, N, dtype=dtype)
+    assert ops.gemm_nt_tile(da, dw, out, bias=dev(b), variant=variant) == 256      # really the new kernel, not the fall-through
+    ops.gemm_nt(da, dw, out, bias=dev(b), variant=variant)
+    assert rel_err(out.float().cpu(), a @ w.t() + b) < TOL[dtype]
+
+
+def test_gemm_nt_p8_asymmetric_identity(ops):
+    """A = I against an asymmetric B: catches transposed / permuted fragments and a wrong half-tile <-> slot mapping"""
+    M = N = K = 512
+    w = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :]) % 251).float()     # exact in bf16, no two rows alike
+    a = torch.eye(M)
+    for variant in (256, 512):
+        out = ops.gemm_nt(dev(a, torch.bfloat16), dev(w, torch.bfloat16), e(M, N), variant=variant)
+        assert torch.equal(out.cpu(), w.t().contiguous()), variant
+
+
+@pytest.mark.parametrize("M,N,K", P8_SHAPES)
+def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
+    """same k order of accumulation as the 128-wide kernels -> every epilogue bit-identical (variant 1024 forbids the new kernel);
+    repeated launches screen the counted-wait pipeline for races (a stale or half-landed LDS tile shows up as a mismatch)"""
+    dtype, rps = torch.bfloat16, 196
+    a, w, b = dev(rnd(M, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.1), dtype), dev(rnd(N, seed=2))
+    res, uu = dev(rnd(M, N, seed=3)), dev(rnd(M, N, dtype=dtype, seed=5), dtype)
+    rs = dev(1.0 + 0.1 * rnd((M + rps - 1) // rps, seed=6))
+
+    def run(v):
+        u = e(M, N, dtype=dtype)
+        h = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU, bias=b, aux=u, variant=v)
+        r = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=v)
+        d = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_DGELU, aux=uu, variant=v)
+        f = ops.gemm_nt(a, w, e(M, N), bias=b, variant=v)
+        return u, h, r, d, f
+    ref = run(1024)
+    assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
+    for v in (256, 512):
+        for rep in range(4):
+            for x, y in zip(ref, run(v)):
+                assert torch.equal(x, y), (v, rep)
+
+
+def test_gemm_nt_p8_vit_l_shapes_race_screen(ops):
+    """the training shapes themselves (M = 64 x 196 tokens; qkv / proj / fc1 / fc2 / dqkv contractions), every launch compared
+    bit for bit with the 128-wide kernels; under a full grid the DMA runs far ahead of / behind the readers"""
+    T, C = 12544, 1024
+    dtype = torch.bfloat16
+    for (N, K) in [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C), (C, 3 * C)]:
+        a, w, b = dev(rnd(T, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.05), dtype), dev(rnd(N, seed=2))
+        ref = ops.gemm_nt(a, w, e(T, N, dtype=dtype), bias=b, variant=1024)
+        for v in (256, 512):
+            out = e(T, N, dtype=dtype)
+            for rep in range(6):
+                out.zero_()
+                ops.gemm_nt(a, w, out, bias=b, variant=v)
+                assert torch.equal(out, ref), (N, K, v, rep)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Kc,M,N,split", [(392, 384, 128, 1), (392, 256, 128, 3), (1000, 128, 768, 4), (64, 128, 128, 1), (12544, 256, 128, None)])
 def test_gemm_tn(ops, dtype, Kc, M, N, split):
@@ -119,6 +188,75 @@ def test_gemm_tn_bias_gradient_byproduct(ops, dtype, Kc, M, N, split):
     out = ops.gemm_tn(dev(a, dtype), dev(b, dtype), e(M, N), split_k=split, colsum=cs)
     assert rel_err(out.cpu(), a.t() @ b) < 3e-4
     assert rel_err(cs.cpu(), cs0 + a.sum(0)) < 1e-4
+
+
+# ---- grouped weight gradients on the 8-phase pipeline (gemm_tn_p8.hip)
+def _wgrad_group(ops, shapes, seed=0):
+    q, refs = ops.WgradQueue(), []
+    for i, (Kc, M, N, with_cs) in enumerate(shapes):
+        a = rnd(Kc, M, dtype=torch.bfloat16, scale=0.5, seed=seed + i)
+        b = rnd(Kc, N, dtype=torch.bfloat16, seed=seed + 50 + i, scale=0.5)
+        cs0 = rnd(M, seed=seed + 90 + i) if with_cs else None
+        dw, cs = e(M, N), (dev(cs0) if with_cs else None)
+        dw.fill_(float("nan"))                                   # the launch must overwrite every element
+        assert q.add(dev(a, torch.bfloat16), dev(b, torch.bfloat16), dw, cs)
+        refs.append((a, b, cs0, dw, cs))
+    return q, refs
+
+
+@pytest.mark.parametrize("shapes", [
+    [(128, 256, 256, True)],                                                                  # one tile, one K-tile pair
+    [(256, 512, 256, True), (384, 256, 768, False), (1024, 256, 256, True)],                   # different contractions in one launch
+    [(1536, 768, 256, True), (1536, 256, 256, True), (1536, 1024, 256, False), (1536, 256, 1024, True)]])   # a block's four gradients
+def test_gemm_tn_grouped_vs_oracle(ops, shapes):
+    q, refs = _wgrad_group(ops, shapes)
+    q.flush()
+    for a, b, cs0, dw, cs in refs:
+        assert rel_err(dw.cpu(), a.t() @ b) < 3e-4
+        if cs is not None:
+            assert rel_err(cs.cpu(), cs0 + a.sum(0)) < 1e-4
+
+
+def test_gemm_tn_grouped_vit_l_block_repeatable(ops):
+    """the four weight gradients of a ViT-L block at the training size (T = 12544 tokens, 192 tiles, 98 K-tile pairs each) against
+    the split-K kernels of gemm.hip, and launch-to-launch bit-identical (no atomics on dW; one atomic per bias-gradient entry):
+    a stale or half-landed LDS tile in the counted-wait pipeline would show up as a difference"""
+    T, C = 12544, 1024
+    shapes = [(T, 3 * C, C, True), (T, C, C, True), (T, 4 * C, C, True), (T, C, 4 * C, True)]
+    ins = [(dev(rnd(K, M, dtype=torch.bfloat16, scale=0.5, seed=i), torch.bfloat16), dev(rnd(K, N, dtype=torch.bfloat16, scale=0.5, seed=9 + i), torch.bfloat16))
+           for i, (K, M, N, _) in enumerate(shapes)]
+    first = None
+    for rep in range(3):
+        q = ops.WgradQueue()
+        outs = []
+        for (a, b), (K, M, N, _) in zip(ins, shapes):
+            dw, cs = e(M, N), torch.zeros(M, device="cuda")
+            assert q.add(a, b, dw, cs)
+            outs.append((dw, cs))
+        q.flush()
+        torch.cuda.synchronize()
+        if first is None:
+            first = outs
+            for (a, b), (dw, cs) in zip(ins, outs):
+                ref, rcs = e(*dw.shape), torch.zeros_like(cs)
+                ops.gemm_tn(a, b, ref, colsum=rcs)
+                assert rel_err(dw, ref) < 2e-5 and rel_err(cs, rcs) < 2e-5
+        else:
+            for (x, xc), (y, yc) in zip(first, outs):
+                assert torch.equal(x, y) and torch.equal(xc, yc), rep
+
+
+def test_wgrad_queue_falls_back_for_other_problems(ops):
+    """f32 parity mode and sizes off the 256 / 128 grid do not queue: they run at once through mtp_gemm_tn"""
+    q = ops.WgradQueue()
+    a, b = rnd(392, 384, scale=0.5), rnd(392, 128, scale=0.5, seed=1)
+    dw = e(384, 128)
+    assert not q.add(dev(a), dev(b), dw) and not q.jobs
+    assert rel_err(dw.cpu(), a.t() @ b) < 3e-4
+    ab, bb = rnd(392, 256, dtype=torch.bfloat16), rnd(392, 256, dtype=torch.bfloat16, seed=1)   # contraction not a multiple of 128
+    dw = e(256, 256)
+    assert not q.add(dev(ab, torch.bfloat16), dev(bb, torch.bfloat16), dw)
+    assert rel_err(dw.cpu(), ab.t() @ bb) < 3e-4
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -1,20 +1,74 @@
-"""A/B of NT GEMM kernel variants on the ViT-L shapes (variant bits: see include/mtp_hip.h); checks each variant against variant 0."""
-import sys, os
+"""A/B of the NT GEMM kernel families / variants on the ViT-L training shapes (variant bits: include/mtp_hip.h).
+Interleaved rounds in ONE process (guide rule 24), random operands (rule 25), every variant checked bit for bit against the
+128-wide kernels.  usage: python tools/ab_gemm.py [rounds] [variant ...]"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import statistics
+
 import torch
+
 from mtp_amd import ops
-from tools.bench_ops import timeit, r
+from tools.bench_ops import r
+
 T, C = 12544, 1024
-variants = [int(v) for v in (sys.argv[1:] or ["0", "4"])]
-for (M, N, K) in [(T, 3*C, C), (T, C, C), (T, 4*C, C), (T, C, 4*C), (T, C, 3*C)]:
-    a, w, out = r(M, K), r(N, K, scale=0.02), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    ref = torch.empty_like(out)
-    bias = torch.zeros(N, device="cuda")
-    ops.gemm_nt(a, w, ref, bias=bias, variant=0)
-    res = []
-    for variant in variants:
-        ops.gemm_nt(a, w, out, bias=bias, variant=variant)
-        ok = torch.equal(out, ref)
-        ts = [timeit(lambda: ops.gemm_nt(a, w, out, bias=bias, variant=variant), iters=30) for _ in range(3)]
-        res.append("v%d %.0f TF%s" % (variant, 2*M*N*K/min(ts)/1e12, "" if ok else " MISMATCH"))
-    print(M, N, K, " | ".join(res), flush=True)
+NAMES = {1024: "w128", 256: "p8", 512: "p8-persist", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
+         256 + (3 << 11): "p8-noprio-nostagger", 256 + (4 << 11): "p8-nostore", 256 + (8 << 11): "p8-nomfma", 256 + (12 << 11): "p8-nomfma-nostore", 256 + (15 << 11): "p8-direct-epi"}
+
+
+def time_many(fn, iters):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    variants = [int(v) for v in sys.argv[2:]] or [1024, 256, 512, 258]
+    bf = torch.bfloat16
+    cases = []
+    for (M, N, K) in [(T, 3 * C, C), (T, C, C), (T, 4 * C, C), (T, C, 4 * C), (T, C, 3 * C), (4 * T, 4 * C, C), (T, C, 768)]:
+        cases.append(("bias", M, N, K))
+    cases += [("gelu", T, 4 * C, C), ("dgelu", T, 4 * C, C), ("res", T, C, C), ("res", T, C, 4 * C)]
+    for (epi, M, N, K) in cases:
+        a, w = r(M, K), r(N, K, scale=0.02)
+        bias = torch.randn(N, device="cuda")
+        kw = dict(bias=bias)
+        odt = bf
+        if epi == "gelu":
+            kw.update(epi=ops.EPI_BIAS_GELU, aux=torch.empty(M, N, device="cuda", dtype=bf))
+        elif epi == "dgelu":
+            kw = dict(epi=ops.EPI_DGELU, aux=r(M, N))
+        elif epi == "res":
+            kw.update(epi=ops.EPI_BIAS_RES, res=torch.randn(M, N, device="cuda"))
+            odt = torch.float32
+        out, ref = torch.empty(M, N, device="cuda", dtype=odt), torch.empty(M, N, device="cuda", dtype=odt)
+        ops.gemm_nt(a, w, ref, variant=1024, **kw)
+        ts = {v: [] for v in variants}
+        okv = {}
+        iters = 10 if M > T else 20
+        for v in variants:
+            if v not in (1024, 256, 512, 258) and epi != "bias":
+                continue
+            out.zero_()
+            ops.gemm_nt(a, w, out, variant=v, **kw)
+            okv[v] = torch.equal(out, ref) or ((v >> 11) & 12) != 0     # the nostore / nomfma ablations compute nothing to compare
+            time_many(lambda: ops.gemm_nt(a, w, out, variant=v, **kw), 3)
+        for _ in range(rounds):
+            for v in okv:
+                ts[v].append(time_many(lambda: ops.gemm_nt(a, w, out, variant=v, **kw), iters))
+        fl = 2.0 * M * N * K
+        cells = []
+        for v in okv:
+            cells.append("%s %.1fus %.0f/%.0fTF%s" % (NAMES.get(v, str(v)), min(ts[v]) * 1e6, fl / statistics.median(ts[v]) / 1e12, fl / min(ts[v]) / 1e12,
+                                                      "" if okv[v] else " MISMATCH"))
+        print("%-5s M=%d N=%d K=%d | " % (epi, M, N, K) + " | ".join(cells), flush=True)
+
+
+if __name__ == "__main__":
+    main()
