@@ -119,7 +119,10 @@ __device__ __forceinline__ float4 ld4f(const float* p) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <typename Tout, int EPI>
+// The wave's 128 x 64 block may be two row strips / two column strips of the tile: pass h (accumulator rows 4h .. 4h+3) starts at
+// tile row mrow0 + h * RSTRIDE, block columns [32s, 32s + 32) sit at tile column ncol0 + s * CSTRIP (NT kernel: one solid block,
+// RSTRIDE = 64, CSTRIP = 32; TN kernel: strips 128 apart, so that its DMA reads whole 256-B runs of the token-major operands).
+template <typename Tout, int EPI, int RSTRIDE = 64, int CSTRIP = 32>
 __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8], char* wsm, int mrow0, int ncol0, int lane) {
     const int fr = lane & 15, g = lane >> 4;
     const uint32_t wbase = (uint32_t)(fr * 256);
@@ -127,7 +130,7 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
     constexpr int ITS = WIDE ? 8 : 16, RSTEP = WIDE ? 8 : 4, NV = WIDE ? 8 : 4;
     const int cg = WIDE ? (lane & 7) : (lane & 15);   // column group of this lane
     const int rsub = WIDE ? (lane >> 3) : (lane >> 4);
-    const int n = ncol0 + cg * NV;
+    const int n = ncol0 + ((cg * NV) >> 5) * CSTRIP + ((cg * NV) & 31);
     const bool nok = n < p.N;
     const int nc = nok ? n : 0;
     // bias of the lane's columns (row-independent)
@@ -151,7 +154,7 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
         // ---- back in row layout, 8 wave instructions (= 64 or 32 rows) per batch
 #pragma unroll
         for (int bt = 0; bt < ITS / 8; ++bt) {
-            const int mb = mrow0 + h * 64 + bt * 8 * RSTEP + rsub;     // first row of this lane in the batch; rows mb + it * RSTEP
+            const int mb = mrow0 + h * RSTRIDE + bt * 8 * RSTEP + rsub;     // first row of this lane in the batch; rows mb + it * RSTEP
             // side inputs of the whole batch first (unconditional loads on clamped rows), so that they are all in flight together
             float4 side[(EPI == MTP_EPI_BIAS_RES) ? 8 : 1];
             uint4 sideb[(EPI == MTP_EPI_DGELU) ? 8 : 1];

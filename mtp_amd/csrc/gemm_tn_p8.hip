@@ -13,9 +13,10 @@
 // Operands are token-major as they lie in memory ([t][feature], feature contiguous): both go HBM -> LDS untransposed by LDS-DMA
 // and the MFMA fragments (8 consecutive t per lane) come out of the gfx950 transpose read ds_read_b64_tr_b16 -- the layout of
 // gemm_tn_tr_kernel (gemm.hip; probed with tools/tr_probe.hip): half tile = [64 t][128 features] (256-B rows), 32-B slot pair
-// (16 features) ^= f(t), f = (t & 3) | ((t >> 3) & 1) << 2, applied on the per-lane DMA SOURCE address.  A-half h holds the 64
-// feature columns "sub-tile h" of each of the two wave rows, B-half j the 32 columns "sub-tile j" of each of the four wave
-// columns, exactly as in the NT kernel, so the phase schedule is shared.
+// (16 features) ^= f(t), f = (t & 3) | ((t >> 3) & 1) << 2, applied on the per-lane DMA SOURCE address.  A-half h holds the
+// feature columns "sub-tile h" of the two wave rows, B-half j the columns "sub-tile j" of the four wave columns, as in the NT
+// kernel, so the phase schedule is shared -- but here a half tile is 128 CONSECUTIVE columns and a wave's sub-tiles are strips
+// 128 columns apart (whole 256-B runs per DMA row).
 // Bias gradient (column sums of dY) as a by-product: the workgroups of tile column 0 also add up the dY half tiles out of LDS.
 #include "gemm_p8.h"
 
@@ -113,6 +114,7 @@ struct TnOps {
     }
 };
 
+template <int XP>
 __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_p8_kernel(TnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -149,18 +151,20 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // (lane & 15) ^ (f << 1) with f = f(row) = (lane >> 4) | (wave & 1) << 2
         const int fd = (lane >> 4) | ((wave & 1) << 2);
         const int ch = (lane & 15) ^ (fd << 1);
-        const int colA = (ch >> 3) * 128 + (ch & 7) * 8;    // A-half: wave row (ch >> 3), 64 columns of it
-        const int colB = (ch >> 2) * 64 + (ch & 3) * 8;     // B-half: wave column (ch >> 2), 32 columns of it
-        c.voffA = (uint32_t)((lane >> 4) * q.lda * 2 + colA * 2);
-        c.voffB = (uint32_t)((lane >> 4) * q.ldb * 2 + colB * 2);
+        // a half tile = 128 CONSECUTIVE feature columns (256-B runs: whole cache lines for every DMA row): A-half h = tile
+        // columns [128h, 128h + 128), of which wave row wr multiplies [64 wr, 64 wr + 64); B-half j likewise with 32 columns per
+        // wave column.  (Splitting the wave's columns in two strips instead of splitting each strip's lines in two: measured
+        // 871 us of a 1050-us launch were the DMA / read stream alone when B-half rows were 4 x 64-B pieces.)
+        c.voffA = (uint32_t)((lane >> 4) * q.lda * 2 + ch * 16);
+        c.voffB = (uint32_t)((lane >> 4) * q.ldb * 2 + ch * 16);
         c.kstepA = (uint32_t)(64 * q.lda * 2);
         c.kstepB = (uint32_t)(64 * q.ldb * 2);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) {
-                c.pA[h][pc] = q.A + ((int64_t)(wave * 8 + pc * 4) * q.lda + m0 + h * 64) * 2;
-                c.pB[h][pc] = q.B + ((int64_t)(wave * 8 + pc * 4) * q.ldb + n0 + h * 32) * 2;
+                c.pA[h][pc] = q.A + ((int64_t)(wave * 8 + pc * 4) * q.lda + m0 + h * 128) * 2;
+                c.pB[h][pc] = q.B + ((int64_t)(wave * 8 + pc * 4) * q.ldb + n0 + h * 128) * 2;
             }
         c.colsum = q.colsum != nullptr && tn == 0;
         c.csoff = (uint32_t)((tid >> 4) * 256 + (tid & 15) * 16);
@@ -190,14 +194,14 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     TnOps::retire_b(b1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
+    if (!(XP & 2) && wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int it = 0; it < pairs - 1; ++it) two_tiles<TnOps, false, 0>(c, a, b0, b1, acc);
-    two_tiles<TnOps, true, 0>(c, a, b0, b1, acc);
+    for (int it = 0; it < pairs - 1; ++it) two_tiles<TnOps, false, XP>(c, a, b0, b1, acc);
+    two_tiles<TnOps, true, XP>(c, a, b0, b1, acc);
 
     __builtin_amdgcn_sched_barrier(0);
-    if (wr == 0) __builtin_amdgcn_s_barrier();
+    if (!(XP & 2) && wr == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     if (c.colsum) {
@@ -217,8 +221,7 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             float s = 0.f;
 #pragma unroll 8
             for (int r = 0; r < 32; ++r) s += red[(h * 32 + r) * 128 + x];
-            const int col = (x >> 6) * 128 + h * 64 + (x & 63);
-            atomicAdd(q.colsum + m0 + col, s);
+            atomicAdd(q.colsum + m0 + h * 128 + x, s);
         }
         __syncthreads();
     }
@@ -226,7 +229,8 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     KArgs o = {};
     o.C = reinterpret_cast<char*>(q.C);
     o.M = q.M; o.N = q.N; o.ldc = q.ldc;
-    epilogue_lds<float, MTP_EPI_BIAS>(o, acc, smem + wave * P8_HALF, m0 + wr * 128, n0 + wc * 64, lane);
+    // accumulator rows 4i .. 4i+3 = tile rows 128 i + 64 wr + ..., accumulator columns 2j, 2j+1 = tile columns 128 j + 32 wc + ...
+    epilogue_lds<float, MTP_EPI_BIAS, 128, 128>(o, acc, smem + wave * P8_HALF, m0 + wr * 64, n0 + wc * 32, lane);
 }
 
 }  // namespace
@@ -255,12 +259,15 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     g.nprob = count;
     g.ntiles = tiles;
     g.plain = (args[0].variant >> 1) & 1;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    const int xp = (args[0].variant >> 11) & 15;   // ablation builds (tools/ab_wgrad.py): 2 = no stagger, 8 = no MFMAs
+    void (*kern)(TnGroup) = xp == 2 ? gemm_tn_p8_kernel<2> : xp == 8 ? gemm_tn_p8_kernel<8> : gemm_tn_p8_kernel<0>;
+    static bool attr[3] = {false, false, false};
+    const int ai = xp == 2 ? 1 : xp == 8 ? 2 : 0;
+    if (!attr[ai]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        attr[ai] = true;
     }
-    hipLaunchKernelGGL(gemm_tn_p8_kernel, dim3(tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);
     return mtp_launch_status();
 }

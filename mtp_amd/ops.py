@@ -134,8 +134,8 @@ class WgradQueue:
     each tile with the full contraction: no split-K partials, no reduction launches.  Problems the grouped kernel cannot take
     (f32 parity mode, sizes that are not multiples of 256 / 128) run immediately through gemm_tn."""
 
-    def __init__(self, cus=256):
-        self.jobs, self.tiles, self.cus = [], 0, cus
+    def __init__(self, cus=256, variant=0):
+        self.jobs, self.tiles, self.cus, self.variant = [], 0, cus, variant
 
     def add(self, dy, x, dw, colsum=None):
         K, M = dy.shape
@@ -168,7 +168,7 @@ class WgradQueue:
                 g.A, g.B, g.C = _p(dy), _p(x), _p(dw)
                 g.M, g.N, g.K = M, N, K
                 g.lda, g.ldb, g.ldc = M, N, N
-                g.in_dtype, g.out_dtype = MTP_BF16, MTP_F32
+                g.in_dtype, g.out_dtype, g.variant = MTP_BF16, MTP_F32, self.variant
                 if cs is not None:
                     assert cs.dtype == torch.float32 and cs.numel() == M and cs.is_contiguous()
                     g.colsum = _p(cs)

@@ -34,8 +34,8 @@ def main():
                 probs.append((r(T, M), r(T, N), torch.empty(M, N, device="cuda"), torch.zeros(M, device="cuda")))
         fl = sum(2.0 * T * a.shape[1] * b.shape[1] for a, b, _, _ in probs)
 
-        def grouped():
-            q = ops.WgradQueue()
+        def grouped(variant=0):
+            q = ops.WgradQueue(variant=variant)
             for a, b, dw, cs in probs:
                 q.add(a, b, dw, cs)
             q.flush()
@@ -47,10 +47,13 @@ def main():
             ops.sum_partials(pend)
 
         grouped(); split()
-        tg, ts = [], []
+        tg, ts, abl = [], [], {"nostagger": [], "nomfma": []}
         for _ in range(rounds):
             tg.append(timed(grouped, 5))
             ts.append(timed(split, 5))
+            abl["nostagger"].append(timed(lambda: grouped(2 << 11), 3))
+            abl["nomfma"].append(timed(lambda: grouped(8 << 11), 3))
+        print("   ablations: " + "  ".join("%s %.1f us" % (k, statistics.median(v) * 1e6) for k, v in abl.items()))
         print("%d block(s), %d tiles: grouped %.1f us  %.0f TF/s (min %.1f us) | split-K %.1f us  %.0f TF/s" % (
             nblk, sum((a.shape[1] // 256) * (b.shape[1] // 256) for a, b, _, _ in probs), statistics.median(tg) * 1e6, fl / statistics.median(tg) / 1e12,
             min(tg) * 1e6, statistics.median(ts) * 1e6, fl / statistics.median(ts) / 1e12), flush=True)
