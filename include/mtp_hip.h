@@ -65,7 +65,7 @@ typedef struct {
                          * staged loads; bits1-2 tile order (1 plain, 2 grouped / M-fastest, 3 row-major); bit3 NT
                          * double-buffered / TN single-stage; bit4 TN register-transposing; bit5 / bit6 force / forbid
                          * the 256x128 8-wave NT tile; bit7 NT at 5 workgroups per CU (complete tiles only); bits8-9 the
-                         * 256x256 8-wave pipelined NT kernel (1 = one workgroup per tile, 2 = persistent workgroups),
+                         * 8-wave pipelined NT kernel (1 = tile height picked per problem, 2 = 224 x 256 tiles, 3 = 256 x 256 tiles),
                          * bit10 forbids it.  All variants of one problem give bit-identical results. */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */

@@ -625,14 +625,14 @@ int fill_common(const mtp_gemm_args* a, KArgs& k) {
     return 0;
 }
 
-// which NT kernel family runs a bf16 problem: 0 = the 128-wide kernels of this file, 1 = gemm_p8.hip with one workgroup per
-// 256 x 256 tile, 2 = gemm_p8.hip with persistent workgroups.  variant bits 8-9 force 1 / 2 (when the problem fits), bit 10
+// which NT kernel family runs a bf16 problem: 0 = the 128-wide kernels of this file, else gemm_p8.hip: 1 = tile height picked per
+// problem (256 or 224 rows), 2 = 224-row tiles, 3 = 256-row tiles.  variant bits 8-9 force 1 / 2 / 3 (when the problem fits), bit 10
 // forbids the kernel; bits 11-14 select an ablation build (tools/ab_gemm.py).
 int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k) {
     if (a->in_dtype != MTP_BF16 || (a->variant & 1024) || !mtp_nt_p8_fits(k, a->out_dtype, a->epilogue)) return 0;
     const int forced = (a->variant >> 8) & 3;
-    if (forced) return forced == 3 ? 2 : forced;
-    // default: the pipelined kernel once its 256 x 256 tiles occupy most of the 256 CUs (one workgroup per CU); below that the
+    if (forced) return forced;
+    // default: the pipelined kernel once its 256-wide tiles occupy most of the 256 CUs (one workgroup per CU); below that the
     // 128-wide kernels with 4 workgroups per CU spread a small problem better.  Measured on the ViT-L shapes (tools/ab_gemm.py):
     // +15 % (N = 3072 / 4096, K = 1024) ... +25 % (N = 1024, K = 3072 / 4096), +23 % on the FPN GEMM.
     const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
@@ -653,7 +653,7 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     // 2 persistent workgroups; falls through to the 128-wide kernels when the problem does not fit it
     if constexpr (sizeof(T) == 2) {
         const int p8 = nt_p8_mode(a, k);
-        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4), stream);
+        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4), stream);
     }
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);

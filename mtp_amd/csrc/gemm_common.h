@@ -27,8 +27,8 @@ struct KArgs {
     float* colsum;          // TN (transpose-read kernel): colsum[m] += sum_k A[k][m], or nullptr
 };
 
-// gemm_p8.hip: 256 x 256 x 64 tile, 8 waves, 8-phase LDS-DMA pipeline (bf16 NT, complete K tiles).  flags: bit0 = persistent
-// workgroups (one per CU, tile loop), bit1 = plain tile order (no XCD remap / grouping), bits 4-7 = ablation switches (gemm_p8.hip: XP).  Returns MTP_ERR_UNSUPPORTED when the
+// gemm_p8.hip: 256 x 256 x 64 tile, 8 waves, 8-phase LDS-DMA pipeline (bf16 NT, complete K tiles).  flags: bit0 = 224-row tiles,
+// bit2 = 256-row tiles (neither: picked per problem), bit1 = plain tile order (no XCD remap / grouping), bits 4-7 = ablation switches (gemm_p8.hip: XP).  Returns MTP_ERR_UNSUPPORTED when the
 // problem does not fit the kernel's preconditions (the caller then uses the 128-wide kernels of gemm.hip).
 int mtp_nt_p8_launch(const KArgs& k, int out_dtype, int epilogue, int flags, hipStream_t stream);
 int mtp_nt_p8_fits(const KArgs& k, int out_dtype, int epilogue);   // 1 when mtp_nt_p8_launch would run the problem

@@ -65,7 +65,7 @@ __device__ __forceinline__ void phase(typename OP::Ctx& c, u32x4_t (&a)[2][4], u
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < (QI ? OP::kMi1 : 4); ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 if constexpr (XP & 8)
@@ -122,7 +122,8 @@ __device__ __forceinline__ float4 ld4f(const float* p) {
 // The wave's 128 x 64 block may be two row strips / two column strips of the tile: pass h (accumulator rows 4h .. 4h+3) starts at
 // tile row mrow0 + h * RSTRIDE, block columns [32s, 32s + 32) sit at tile column ncol0 + s * CSTRIP (NT kernel: one solid block,
 // RSTRIDE = 64, CSTRIP = 32; TN kernel: strips 128 apart, so that its DMA reads whole 256-B runs of the token-major operands).
-template <typename Tout, int EPI, int RSTRIDE = 64, int CSTRIP = 32>
+// ROWS = rows of the wave's block that exist (128; 112 in the 224-row NT tile, whose second pass has 48 rows).
+template <typename Tout, int EPI, int RSTRIDE = 64, int CSTRIP = 32, int ROWS = 128>
 __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8], char* wsm, int mrow0, int ncol0, int lane) {
     const int fr = lane & 15, g = lane >> 4;
     const uint32_t wbase = (uint32_t)(fr * 256);
@@ -147,7 +148,7 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
     for (int h = 0; h < 2; ++h) {
         // ---- accumulators of rows [h*64, h*64+64) -> LDS as they lie: row = mfl*16 + fr, unit = nf*4 + g
 #pragma unroll
-        for (int mfl = 0; mfl < 4; ++mfl)
+        for (int mfl = 0; mfl < (h ? (ROWS - 64) / 16 : 4); ++mfl)
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
                 *reinterpret_cast<f32x4_t*>(wsm + mfl * 4096 + wbase + (((nf * 4 + g) ^ (fr & 7)) << 4)) = acc[nf][h * 4 + mfl];
@@ -187,7 +188,7 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
             for (int it = 0; it < 8; ++it) {
                 const int r = (bt * 8 + it) * RSTEP + rsub;
                 const int m = mb + it * RSTEP;
-                const bool ok = nok && m < p.M;
+                const bool ok = nok && m < p.M && (ROWS == 128 || h * 64 + r < ROWS);
                 float v[NV];
                 if constexpr (WIDE) {
                     const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(wsm + r * 256 + (((2 * cg) ^ (r & 7)) << 4));

@@ -41,6 +41,7 @@ namespace {
 
 struct P8Ctx {
     uint32_t addrA[2][2];    // ds_read base of the wave's A fragments, [buffer][k-step]  (per lane)
+    uint32_t addrA1[2][2];   // same for A-half 1 (its rows are packed 48 per wave row in the 224-row tile)
     uint32_t addrB[2][2];
     uint32_t voffA, voffB;   // per-lane byte offset of the DMA source (row-in-piece, swizzled chunk, current k)
     const char* pA[2][2];    // wave-uniform DMA source row bases [half][piece]
@@ -63,14 +64,15 @@ __device__ __forceinline__ void nt_stage(const P8Ctx& c) {
         glds2(c.voffB, c.pB[h][0], c.pB[h][1], l0, l0 + 1024);
 }
 
-// read one A half tile (8 fragments) / one B half tile (4 fragments) of buffer BUF, slot K
-template <int K, int BUF>
+// read one A half tile (8 fragments; 6 for the 48-row half of the 224-row tile) / one B half tile (4 fragments) of buffer BUF, slot K
+template <int K, int BUF, int MI>
 __device__ __forceinline__ void nt_read_a(const P8Ctx& c, u32x4_t (&a)[2][4]) {
     constexpr int o = K * P8_HALF;
-    dsr<o + 0 * 2048>(a[0][0], c.addrA[BUF][0]); dsr<o + 1 * 2048>(a[0][1], c.addrA[BUF][0]);
-    dsr<o + 2 * 2048>(a[0][2], c.addrA[BUF][0]); dsr<o + 3 * 2048>(a[0][3], c.addrA[BUF][0]);
-    dsr<o + 0 * 2048>(a[1][0], c.addrA[BUF][1]); dsr<o + 1 * 2048>(a[1][1], c.addrA[BUF][1]);
-    dsr<o + 2 * 2048>(a[1][2], c.addrA[BUF][1]); dsr<o + 3 * 2048>(a[1][3], c.addrA[BUF][1]);
+    const uint32_t a0 = K == KA1 ? c.addrA1[BUF][0] : c.addrA[BUF][0], a1 = K == KA1 ? c.addrA1[BUF][1] : c.addrA[BUF][1];
+    dsr<o + 0 * 2048>(a[0][0], a0); dsr<o + 1 * 2048>(a[0][1], a0); dsr<o + 2 * 2048>(a[0][2], a0);
+    if constexpr (MI == 4) dsr<o + 3 * 2048>(a[0][3], a0);
+    dsr<o + 0 * 2048>(a[1][0], a1); dsr<o + 1 * 2048>(a[1][1], a1); dsr<o + 2 * 2048>(a[1][2], a1);
+    if constexpr (MI == 4) dsr<o + 3 * 2048>(a[1][3], a1);
 }
 template <int K, int BUF>
 __device__ __forceinline__ void nt_read_b(const P8Ctx& c, u32x4_t (&b)[2][2]) {
@@ -79,35 +81,46 @@ __device__ __forceinline__ void nt_read_b(const P8Ctx& c, u32x4_t (&b)[2][2]) {
     dsr<o + 0 * 2048>(b[1][0], c.addrB[BUF][1]); dsr<o + 1 * 2048>(b[1][1], c.addrB[BUF][1]);
 }
 // retire the ds_reads; the "+v" ties make every consumer of the fragments depend on this statement
+template <int MI>
 __device__ __forceinline__ void wait_a(u32x4_t (&a)[2][4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+    if constexpr (MI == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]));
 }
 __device__ __forceinline__ void wait_b(u32x4_t (&b)[2][2]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
 }
 
-// operand policy of the pipeline (gemm_p8.h) for K-contiguous operands
+// operand policy of the pipeline (gemm_p8.h) for K-contiguous operands; MI1 = 16-row fragments in A sub-tile 1 (4: 256-row
+// tile, 3: 224-row tile)
+template <int MI1>
 struct NtOps {
     typedef P8Ctx Ctx;
     static constexpr int kLoadsPerPiecePair = 2;   // DMA instructions per lane and half tile
-    template <int K, int BUF> static __device__ __forceinline__ void read_a(Ctx& c, u32x4_t (&a)[2][4]) { nt_read_a<K, BUF>(c, a); }
+    static constexpr int kMi1 = MI1;
+    template <int K, int BUF> static __device__ __forceinline__ void read_a(Ctx& c, u32x4_t (&a)[2][4]) { nt_read_a<K, BUF, (K == KA1 ? MI1 : 4)>(c, a); }
     template <int K, int BUF> static __device__ __forceinline__ void read_b(Ctx& c, u32x4_t (&b)[2][2]) { nt_read_b<K, BUF>(c, b); }
     template <int SK, int SBUF> static __device__ __forceinline__ void stage(Ctx& c) { nt_stage<SK, SBUF>(c); }
-    template <int K, int BUF> static __device__ __forceinline__ void retire_a(Ctx&, u32x4_t (&a)[2][4]) { wait_a(a); }
+    template <int K, int BUF> static __device__ __forceinline__ void retire_a(Ctx&, u32x4_t (&a)[2][4]) { wait_a<(K == KA1 ? MI1 : 4)>(a); }
     static __device__ __forceinline__ void retire_b(u32x4_t (&b)[2][2]) { wait_b(b); }
     static __device__ __forceinline__ void next_ktile(Ctx& c) { c.voffA += 128; c.voffB += 128; }
 };
 
-template <typename Tout, int EPI, bool PERSIST, int XP>
+// MI1 = 4: 256 x 256 tile; MI1 = 3: 224 x 256 tile (wave rows of 112 = 64 + 48 rows).  M = 12544 tokens = 49 x 256 = 56 x 224: with
+// 256-row tiles every ViT-L shape runs 0.766 of a whole number of rounds on the 256 CUs (196 / 588 / 784 tiles), with 224-row tiles
+// 0.875 (224 / 672 / 896) at 7/8 of the time per tile -- the host picks the cheaper one per problem (p8_pick_bm).
+template <typename Tout, int EPI, int MI1, int XP>
 __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_p8_kernel(KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WROWS = 64 + 16 * MI1, BM = 2 * WROWS;      // rows per wave row, rows per tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, g = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
-    const int tiles_m = (p.M + P8_BM - 1) / P8_BM, tiles_n = p.tiles_n, ntiles = tiles_m * tiles_n;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.tiles_n, ntiles = tiles_m * tiles_n;
     const int plain = p.order & 1;
     const int pairs = p.k_tiles >> 1;
 
@@ -119,6 +132,8 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int b = 0; b < 2; ++b) {
             c.addrA[b][0] = lds0 + b * P8_BUF + wr * 8192 + lanepart;
             c.addrA[b][1] = lds0 + b * P8_BUF + wr * 8192 + (lanepart ^ 64u);
+            c.addrA1[b][0] = lds0 + b * P8_BUF + wr * (MI1 * 2048) + lanepart;     // A-half 1: MI1 * 16 rows per wave row
+            c.addrA1[b][1] = lds0 + b * P8_BUF + wr * (MI1 * 2048) + (lanepart ^ 64u);
             c.addrB[b][0] = lds0 + b * P8_BUF + wc * 4096 + lanepart;
             c.addrB[b][1] = lds0 + b * P8_BUF + wc * 4096 + (lanepart ^ 64u);
         }
@@ -128,24 +143,35 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const uint32_t voffA0 = (uint32_t)((lane >> 3) * (int)p.lda * 2) + lanesrc;
     const uint32_t voffB0 = (uint32_t)((lane >> 3) * (int)p.ldb * 2) + lanesrc;
 
-    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    {
+        const int vb = blockIdx.x;
         int tm, tn;
         tile_coords(plain ? vb : xcd_remap(vb, ntiles), tiles_m, tiles_n, plain, tm, tn);
-        const int m0 = tm * P8_BM, n0 = tn * P8_BN;
-        // DMA source rows of this wave: A-half h, piece i: tile row (wave>>2)*128 + h*64 + (wave&3)*16 + i*8 (+ lane>>3);
-        // B-half h, piece i: tile column (wave>>1)*64 + h*32 + (wave&1)*16 + i*8 (+ lane>>3).  Rows past the edge are
-        // clamped to the last complete 8-row piece (their outputs are never stored).
+        const int m0 = tm * BM, n0 = tn * P8_BN;
+        // DMA source rows of this wave.  Piece q = 2 * wave + i holds rows [8q, 8q + 8) of the half tile image.
+        //   A-half 0 (64 rows per wave row): image row 64 wr' + x  <->  tile row WROWS wr' + x         (wr' = q >> 3)
+        //   A-half 1 (16 MI1 rows per wave row): image row 16 MI1 wr' + x  <->  tile row WROWS wr' + 64 + x; at MI1 = 3 the last four
+        //     pieces (waves 6, 7) are past the 96 image rows: they fetch a valid row into the unused tail of the 16-KiB slot, so
+        //     that every wave still issues two DMA instructions per half tile (the counted waits rely on it)
+        //   B-half h: image row 32 wc' + x  <->  tile column 64 wc' + 32 h + x                             (wc' = q >> 2)
+        // Rows past the matrix edge are clamped to the last complete 8-row piece (their outputs are never stored).
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 2; ++i) {
+            const int q = wave * 2 + i;
+            int ra0 = m0 + (q >> 3) * WROWS + (q & 7) * 8;
+            const int qw = q / (2 * MI1), qx = q - qw * (2 * MI1);
+            int ra1 = qw < 2 ? m0 + qw * WROWS + 64 + qx * 8 : m0;
+            ra0 = ra0 < p.M - 8 ? ra0 : p.M - 8;
+            ra1 = ra1 < p.M - 8 ? ra1 : p.M - 8;
+            c.pA[0][i] = p.A + (int64_t)ra0 * p.lda * 2;
+            c.pA[1][i] = p.A + (int64_t)ra1 * p.lda * 2;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int ra = m0 + (wave >> 2) * 128 + h * 64 + (wave & 3) * 16 + i * 8;
-                int rb = n0 + (wave >> 1) * 64 + h * 32 + (wave & 1) * 16 + i * 8;
-                ra = ra < p.M - 8 ? ra : p.M - 8;
+            for (int h = 0; h < 2; ++h) {
+                int rb = n0 + (q >> 2) * 64 + h * 32 + (q & 3) * 8;
                 rb = rb < p.N - 8 ? rb : p.N - 8;
-                c.pA[h][i] = p.A + (int64_t)ra * p.lda * 2;
                 c.pB[h][i] = p.B + (int64_t)rb * p.ldb * 2;
             }
+        }
         c.voffA = voffA0;
         c.voffB = voffB0;
 
@@ -161,10 +187,7 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         c.voffA += 128; c.voffB += 128;
         nt_stage<KB0, 1>(c); nt_stage<KA0, 1>(c); nt_stage<KB1, 1>(c); nt_stage<KA1, 1>(c);
         c.voffA += 128; c.voffB += 128;
-        if (PERSIST && vb != (int)blockIdx.x)
-            wait_vm<0>();    // the previous tile's epilogue stores are in the queue as well: drain everything once per tile
-        else
-            wait_vm<12>();   // S_0, S_1 have landed (this lane's pieces)
+        wait_vm<12>();   // S_0, S_1 have landed (this lane's pieces)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -175,8 +198,8 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if (!(XP & 2) && wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
         __builtin_amdgcn_sched_barrier(0);
 
-        for (int it = 0; it < pairs - 1; ++it) two_tiles<NtOps, false, XP>(c, a, b0, b1, acc);
-        two_tiles<NtOps, true, XP>(c, a, b0, b1, acc);
+        for (int it = 0; it < pairs - 1; ++it) two_tiles<NtOps<MI1>, false, XP>(c, a, b0, b1, acc);
+        two_tiles<NtOps<MI1>, true, XP>(c, a, b0, b1, acc);
 
         __builtin_amdgcn_sched_barrier(0);
         if (!(XP & 2) && wr == 0) __builtin_amdgcn_s_barrier();   // re-align: every wave has finished its last phase behind this barrier
@@ -186,10 +209,8 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if constexpr (XP & 16)   // A/B: straight out of the MFMA layout (the epilogue of the 128-wide kernels)
                 epilogue<Tout, EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
             else
-                epilogue_lds<Tout, EPI>(p, acc, smem + wave * P8_HALF, m0 + wr * 128, n0 + wc * 64, lane);
+                epilogue_lds<Tout, EPI, 64, 32, WROWS>(p, acc, smem + wave * P8_HALF, m0 + wr * WROWS, n0 + wc * 64, lane);
         }
-        if (!PERSIST) break;
-        __syncthreads();   // the next tile's DMA lands in every wave's epilogue region
     }
 }
 
@@ -204,22 +225,30 @@ int p8_cus() {
     return ncu;
 }
 
-template <typename Tout, int EPI, bool PERSIST, int XP>
+template <typename Tout, int EPI, int MI1, int XP>
 int launch_p8_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
     static bool attr = false;   // 128 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<Tout, EPI, PERSIST, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    const int ncu = p8_cus();
-    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, PERSIST, XP>), dim3(PERSIST ? (ntiles < ncu ? ntiles : ncu) : ntiles), dim3(P8_THREADS), P8_LDS, stream, a);
+    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP>), dim3(ntiles), dim3(P8_THREADS), P8_LDS, stream, a);
     return mtp_launch_status();
+}
+
+// rows per tile: whole rounds of one workgroup per CU cost (rows per tile) each -- take the cheaper of 256 and 224
+int p8_pick_bm(int64_t M, int64_t N) {
+    const int64_t cus = p8_cus(), tn = (N + P8_BN - 1) / P8_BN;
+    const int64_t t256 = ((M + 255) / 256) * tn, t224 = ((M + 223) / 224) * tn;
+    const int64_t c256 = ((t256 + cus - 1) / cus) * 256, c224 = ((t224 + cus - 1) / cus) * 224;
+    return c224 < c256 ? 224 : 256;
 }
 
 template <typename Tout, int EPI>
 int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
-    const int tiles_m = (k.M + P8_BM - 1) / P8_BM, tiles_n = (k.N + P8_BN - 1) / P8_BN;
+    const int bm = (flags & 1) ? 224 : (flags & 4) ? 256 : p8_pick_bm(k.M, k.N);
+    const int tiles_m = (k.M + bm - 1) / bm, tiles_n = (k.N + P8_BN - 1) / P8_BN;
     KArgs a = k;
     a.tiles_n = tiles_n;
     a.k_tiles = k.K / 64;
@@ -229,18 +258,17 @@ int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
     if constexpr (EPI == MTP_EPI_BIAS && sizeof(Tout) == 2) {   // ablation builds of the plain bf16 kernel only
         switch ((flags >> 4) & 15) {
             case 0: break;
-            case 1: return launch_p8_kernel<Tout, EPI, false, 1>(a, ntiles, stream);
-            case 2: return launch_p8_kernel<Tout, EPI, false, 2>(a, ntiles, stream);
-            case 3: return launch_p8_kernel<Tout, EPI, false, 3>(a, ntiles, stream);
-            case 4: return launch_p8_kernel<Tout, EPI, false, 4>(a, ntiles, stream);
-            case 8: return launch_p8_kernel<Tout, EPI, false, 8>(a, ntiles, stream);
-            case 12: return launch_p8_kernel<Tout, EPI, false, 12>(a, ntiles, stream);
-            case 15: return launch_p8_kernel<Tout, EPI, false, 16>(a, ntiles, stream);   // (variant field is 4 bits wide: 15 = direct epilogue)
+            case 1: return launch_p8_kernel<Tout, EPI, 4, 1>(a, ntiles, stream);
+            case 2: return launch_p8_kernel<Tout, EPI, 4, 2>(a, ntiles, stream);
+            case 4: return launch_p8_kernel<Tout, EPI, 4, 4>(a, ntiles, stream);
+            case 8: return launch_p8_kernel<Tout, EPI, 4, 8>(a, ntiles, stream);
+            case 12: return launch_p8_kernel<Tout, EPI, 4, 12>(a, ntiles, stream);
+            case 15: return launch_p8_kernel<Tout, EPI, 4, 16>(a, ntiles, stream);   // (the variant field is 4 bits wide: 15 = direct epilogue)
             default: return MTP_ERR_UNSUPPORTED;
         }
     }
-    if (flags & 1) return launch_p8_kernel<Tout, EPI, true, 0>(a, ntiles, stream);
-    return launch_p8_kernel<Tout, EPI, false, 0>(a, ntiles, stream);
+    if (bm == 224) return launch_p8_kernel<Tout, EPI, 3, 0>(a, ntiles, stream);
+    return launch_p8_kernel<Tout, EPI, 4, 0>(a, ntiles, stream);
 }
 
 template <typename Tout>

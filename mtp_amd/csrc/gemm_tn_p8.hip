@@ -65,6 +65,7 @@ __device__ __forceinline__ u32x4_t tr_frag8(lds_char_t* s) {
 struct TnOps {
     typedef T8Ctx Ctx;
     static constexpr int kLoadsPerPiecePair = 2;
+    static constexpr int kMi1 = 4;
     template <int K, int BUF>
     static __device__ __forceinline__ void read_a(Ctx& c, u32x4_t (&a)[2][4]) {
         lds_char_t* s = c.smem + K * P8_HALF;

@@ -100,7 +100,7 @@ def test_gemm_nt_tile_variants_bit_identical(ops, dtype):
             assert torch.equal(x, y), v
 
 
-# ---- the 256 x 256 8-wave pipelined kernel (gemm_p8.hip): variant 256 = one workgroup per tile, 512 = persistent workgroups
+# ---- the 8-wave pipelined kernel (gemm_p8.hip): variant 256 = tile height picked per problem, 512 = 224 x 256 tiles, 768 = 256 x 256 tiles
 P8_SHAPES = [(256, 256, 128),      # one tile, the shortest pipeline (one K-tile pair: prologue + drain only)
              (512, 768, 256),      # 6 tiles, two pairs
              (392, 264, 384),      # ragged M and N edges (clamped DMA rows, predicated stores)
@@ -108,7 +108,7 @@ P8_SHAPES = [(256, 256, 128),      # one tile, the shortest pipeline (one K-tile
              (1568, 2304, 1024)]   # more tiles than a quick run has CUs busy: several rounds / persistent tile loop
 
 
-@pytest.mark.parametrize("variant", [256, 512, 258])
+@pytest.mark.parametrize("variant", [256, 512, 768, 514])
 @pytest.mark.parametrize("M,N,K", P8_SHAPES)
 def test_gemm_nt_p8_vs_oracle(ops, variant, M, N, K):
     dtype = torch.bfloat16
@@ -124,7 +124,7 @@ def test_gemm_nt_p8_asymmetric_identity(ops):
     M = N = K = 512
     w = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :]) % 251).float()     # exact in bf16, no two rows alike
     a = torch.eye(M)
-    for variant in (256, 512):
+    for variant in (512, 768):
         out = ops.gemm_nt(dev(a, torch.bfloat16), dev(w, torch.bfloat16), e(M, N), variant=variant)
         assert torch.equal(out.cpu(), w.t().contiguous()), variant
 
@@ -147,7 +147,7 @@ def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
         return u, h, r, d, f
     ref = run(1024)
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
-    for v in (256, 512):
+    for v in (512, 768):
         for rep in range(4):
             for x, y in zip(ref, run(v)):
                 assert torch.equal(x, y), (v, rep)
@@ -161,7 +161,7 @@ def test_gemm_nt_p8_vit_l_shapes_race_screen(ops):
     for (N, K) in [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C), (C, 3 * C)]:
         a, w, b = dev(rnd(T, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.05), dtype), dev(rnd(N, seed=2))
         ref = ops.gemm_nt(a, w, e(T, N, dtype=dtype), bias=b, variant=1024)
-        for v in (256, 512):
+        for v in (512, 768):
             out = e(T, N, dtype=dtype)
             for rep in range(6):
                 out.zero_()
