@@ -40,3 +40,29 @@ def rel_err(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+# ---- measured parity errors: tests call record_parity(group, name, value); the table is written at session end to
+# gpurun_out/parity_errors.json (copied into profiles/ per round): tolerances in the tests are set against these numbers
+_PARITY = {}
+
+
+def record_parity(group, name, value):
+    _PARITY.setdefault(group, {})[name] = float(value)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "parity_errors.json")
+    old = {}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except Exception:
+            old = {}
+    old.update(_PARITY)
+    json.dump(old, open(path, "w"), indent=1, sort_keys=True)

@@ -6,7 +6,8 @@ The reference (/root/reference) is imported through ref_loader.py; only inputs/o
 are stored.  Tests re-create inputs/params from the seeds in recipe.py.  Fixture map:
   f0 state-dict keys/shapes         f1 integer/index ops           f2 calc_rel_pos_spatial
   f3 Attention (full)               f4 RVSA sampling grid          f5 RVSA attention fwd+grads
-  f6 Mlp/Block/PatchEmbed/Norm2d/fpn  f7 ViT-B whole forward (cfg 1)  f8 small whole model fwd+grads(+bf16 autocast)
+  f6 Mlp/Block/PatchEmbed/Norm2d/fpn  f7 ViT-B whole forward (cfg 1)  f8 small whole model fwd+grads (fp32 and bf16 autocast)
+  f9 / f10 fine-tune variants  f11 DCNv3 core  f12 InternImage  f13 ViT-L (the headline model), fwd + grads, fp32 and bf16 autocast
 """
 import contextlib
 import io
@@ -263,10 +264,24 @@ def f8():
             out["g_" + n] = p.grad
         else:
             out["gs_%s_sum" % n], out["gs_%s_samples" % n] = recipe.summarize(p.grad, 1024)
-    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
-        fb = net(img.detach())
-    for i, f in enumerate(fb):
-        out["bf16_f%d_sum" % i], out["bf16_f%d_samples" % i] = recipe.summarize(f.float(), 2048)
+    # the reference under bf16 autocast: forward AND gradients (what the bf16 throughput mode is compared with, relative L2)
+    net.zero_grad()
+    imgb = img.detach().clone().requires_grad_(True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        fb = net(imgb)
+        lossb = 0
+        for i, f in enumerate(fb):
+            out["bf16_f%d_sum" % i], out["bf16_f%d_samples" % i] = recipe.summarize(f.float(), 2048)
+            lossb = lossb + (f.float() * recipe.loss_weights(f.shape, 200 + i)).sum()
+    lossb.backward()
+    out["bf16_dimg_sum"], out["bf16_dimg_samples"] = recipe.summarize(imgb.grad, 2048)
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        if p.numel() <= 4096:
+            out["bf16_g_" + n] = p.grad.float()
+        else:
+            out["bf16_gs_%s_sum" % n], out["bf16_gs_%s_samples" % n] = recipe.summarize(p.grad.float(), 1024)
     save("f8_small.npz", **out)
 
 
@@ -409,7 +424,45 @@ def f12():
     save("f12_internimage.npz", **out)
 
 
+# ------------------------------------------------------------------ f13: ViT-L (BASELINE configs 3/4: the headline model), fp32 + bf16 autocast
+F13_GRADS = ("pos_embed", "patch_embed.proj.weight", "blocks.0.attn.sampling_offsets.2.weight", "blocks.3.attn.relative_position_bias_table",
+             "blocks.5.attn.full_attn_rel_pos_h", "blocks.11.mlp.fc1.weight", "blocks.17.attn.qkv.weight", "blocks.23.attn.proj.bias",
+             "blocks.22.attn.sampling_angles.2.weight", "blocks.20.attn.rel_pos_w", "fpn1.3.weight", "fpn2.0.bias")
+
+
+def f13():
+    class A:
+        image_size = 224
+        use_ckpt = "False"
+    net = quiet(ref.vit_l_rvsa, A)                     # the factory itself (VIT:843-865): 1024 / 24 / 16 heads, interval 6, taps 7 11 15 23
+    shapes = recipe.state_shapes(1024, 24, 16, 6)
+    sd = net.state_dict()
+    assert [k for k, v in sd.items() if v.dtype.is_floating_point] == list(shapes.keys())
+    net.load_state_dict(recipe.make_params(shapes), strict=False)
+    net.eval()                                         # drop_path 0.1 is inactive in eval
+    out = {"out_indices": np.array(net.out_indices), "n_params": np.array([sum(p.numel() for p in net.parameters())])}
+    P = dict(net.named_parameters())
+    for tag, ctx in (("", contextlib.nullcontext()), ("bf16_", torch.autocast("cpu", dtype=torch.bfloat16))):
+        net.zero_grad()
+        img = recipe.make_input(2, 224, 224, seed=2023).requires_grad_(True)
+        with ctx:
+            feats = net(img)
+            loss = 0
+            for i, f in enumerate(feats):
+                out[tag + "f%d_sum" % i], out[tag + "f%d_samples" % i] = recipe.summarize(f.float(), 4096)
+                out[tag + "f%d_shape" % i] = np.array(f.shape)
+                loss = loss + (f.float() * recipe.loss_weights(f.shape, 600 + i)).sum()
+        loss.backward()
+        out[tag + "loss"] = loss.detach()
+        out[tag + "dimg_sum"], out[tag + "dimg_samples"] = recipe.summarize(img.grad, 4096)
+        for n in F13_GRADS:
+            out[tag + "g_%s_sum" % n], out[tag + "g_%s_samples" % n] = recipe.summarize(P[n].grad.float(), 2048)
+        print("f13", tag or "fp32", "loss", float(loss))
+    out["norm_has_grad"] = np.array([net.norm.weight.grad is not None])
+    save("f13_vitl.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
+    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     for w in which:
         globals()[w]()

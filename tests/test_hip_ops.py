@@ -528,6 +528,57 @@ def test_rvsa_attention_fwd_bwd(ops, dtype, Hp, Wp, sscale):
         assert rel_err(dsamp.cpu(), gs) < 10 * TOL[dtype]
 
 
+# ---- the attention kernels at the launch geometry of the headline benchmark: 64 images x 16 heads x 64 dims (ViT-L, B = 64)
+@pytest.mark.parametrize("dtype", DT)
+def test_full_attention_at_vit_l_b64_geometry(ops, dtype):
+    """1024 (image, head) problems of 196 tokens, C = 1024 -- every workgroup of the real launch -- vs the oracle's autograd"""
+    B, heads, hd, Hp, Wp = 64, 16, 64, 14, 14
+    C, N = heads * hd, Hp * Wp
+    T = B * N
+    qkv = _attn_inputs(T, C, dtype, seed=11)
+    rh, rw = 0.3 * rnd(2 * Hp - 1, hd, seed=1), 0.3 * rnd(2 * Wp - 1, hd, seed=2)
+    o, lse = e(T, C, dtype=dtype), e(B * heads * N)
+    ops.full_attn_fwd(dev(qkv, dtype), o, lse, dev(rh), dev(rw), B, Hp, Wp, heads, hd ** -0.5)
+    q = qkv.clone().requires_grad_(True)
+    rhr, rwr = rh.clone().requires_grad_(True), rw.clone().requires_grad_(True)
+    oref, lref = O.full_attn_fwd(q, B, Hp, Wp, heads, rhr, rwr)
+    assert rel_err(o.float().cpu(), oref) < TOL[dtype] and rel_err(lse.cpu().reshape(lref.shape), lref) < (1e-4 if dtype == torch.float32 else 5e-3)
+    do = rnd(T, C, dtype=dtype, seed=3)
+    gq, gh, gw = torch.autograd.grad(oref, (q, rhr, rwr), do)
+    dqkv, drh, drw = e(T, 3 * C, dtype=dtype), e(*rh.shape), e(*rw.shape)
+    ops.full_attn_bwd(dev(qkv, dtype), o, dev(do, dtype), lse, dqkv, dev(rh), dev(rw), drh, drw, B, Hp, Wp, heads, hd ** -0.5)
+    assert rel_err(dqkv.float().cpu(), gq) < TOL[dtype]
+    # the table gradients sum 64 x 16 x 196 x 196 terms: relative to their own size the bf16 rounding noise averages out
+    assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_rvsa_attention_at_vit_l_b64_geometry(ops, dtype):
+    """16384 (image, window, head) problems -- the real launch of a ViT-L RVSA block at batch 64 -- forward and every gradient"""
+    B, heads, hd, Hp, Wp = 64, 16, 64, 14, 14
+    C, T = heads * hd, B * Hp * Wp
+    nh, nw = ops.rvsa_windows(Hp, Wp)
+    R = B * nh * nw
+    qkv = _attn_inputs(T, C, dtype, seed=17)
+    samp = 0.3 * rnd(R, 5 * heads, seed=8)
+    rh, rw, tab = 0.3 * rnd(13, hd, seed=1), 0.3 * rnd(13, hd, seed=2), 0.3 * rnd(169, heads, seed=3)
+    o, lse = e(T, C, dtype=dtype), e(R * heads * 49)
+    ops.rvsa_attn_fwd(dev(qkv, dtype), dev(samp), o, lse, dev(rh), dev(rw), dev(tab), B, Hp, Wp, heads, hd ** -0.5)
+    q, sp = qkv.clone().requires_grad_(True), samp.clone().requires_grad_(True)
+    rhr, rwr, tr = rh.clone().requires_grad_(True), rw.clone().requires_grad_(True), tab.clone().requires_grad_(True)
+    oref, lref = O.rvsa_attn_fwd(q, sp, B, Hp, Wp, heads, rhr, rwr, tr)
+    assert rel_err(o.float().cpu(), oref) < TOL[dtype]
+    do = rnd(T, C, dtype=dtype, seed=4)
+    gq, gs, gh, gw, gt = torch.autograd.grad(oref, (q, sp, rhr, rwr, tr), do)
+    dqkv, dsamp = e(T, 3 * C, dtype=dtype), e(R, 5 * heads)
+    drh, drw, dtab = e(13, hd), e(13, hd), e(169, heads)
+    ops.rvsa_attn_bwd(dev(qkv, dtype), dev(samp), o, dev(do, dtype), lse, dqkv, dsamp, dev(rh), dev(rw), dev(tab), drh, drw, dtab,
+                      B, Hp, Wp, heads, hd ** -0.5)
+    assert rel_err(dqkv.float().cpu(), gq) < TOL[dtype]
+    assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype] and rel_err(dtab.cpu(), gt) < 10 * TOL[dtype]
+    assert rel_err(dsamp.cpu(), gs) < 10 * TOL[dtype]
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def test_adamw_flat_and_sqnorm(ops):
     n = 4096 + 512
