@@ -56,6 +56,20 @@ class GemmTimer:
             self.rec.append(("gemm_tn", 2.0 * a.shape[0] * a.shape[1] * b.shape[1], s, e))
             return r
         self.ops.gemm_nt, self.ops.gemm_tn = nt, tn
+        flush0 = self.ops.WgradQueue.flush
+        timer = self
+
+        def flush(q):      # the grouped weight-gradient launches (the bulk of the TN family)
+            if not timer.on or not q.jobs:
+                return flush0(q)
+            fl = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in q.jobs)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = flush0(q)
+            e.record()
+            timer.rec.append(("gemm_tn", fl, s, e))
+            return r
+        self.ops.WgradQueue.flush = flush
 
     def summary(self):
         fam = {}
@@ -184,6 +198,36 @@ def main():
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
+    comm = None
+    if trainer.reducer.active:
+        # communication report (N > 1, or MTP_FORCE_COMM=1): the same steps once more with HIP events around every collective on the
+        # side stream, and once with the collectives switched off -- the difference is what the overlap does not hide
+        red = trainer.reducer
+        red.timing, red.timed = True, []
+        for _ in range(args.steps):
+            trainer.step(img, loss_and_grads)
+        sync()
+        red.timing = False
+        nbytes = sum(b for b, _, _ in red.timed) / args.steps
+        secs = sum(a.elapsed_time(bb) for _, a, bb in red.timed) * 1e-3 / args.steps
+        ncoll = len(red.timed) // args.steps
+        red.active = False
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(img, loss_and_grads)
+        sync()
+        tnc = torch.tensor([time.perf_counter() - t2], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tnc, op=dist.ReduceOp.MAX)
+        red.active = True
+        ms_nocomm = float(tnc.item()) / args.steps * 1e3
+        busf = 2.0 * (world - 1) / world if world > 1 else 1.0
+        comm = dict(ranks=dist.get_world_size(), backend=dist.get_backend(), collectives_per_step=ncoll, bytes_per_step=int(nbytes),
+                    allreduce_ms_per_step=round(secs * 1e3, 3), bus_GBps=round(nbytes * busf / max(secs, 1e-9) / 1e9, 1),
+                    xgmi_peak_GBps=7 * 153, ms_per_step_without_comm=round(ms_nocomm, 3), exposed_comm_ms=round(ms - ms_nocomm, 3),
+                    note="all-reduce time = HIP events on the side stream around each collective (its own duration, overlapped with the "
+                         "backward); exposed = step time with minus without collectives; bus GB/s = bytes x 2(N-1)/N / all-reduce time")
+
     host_input = None
     if args.host_input:
         # PCIe-inclusive variant of the same step: raw uint8 HWC batches start in pageable HOST memory, are staged
@@ -243,6 +287,8 @@ def main():
             "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if args.image_size == 224 else None,
             "roofline": roof,
         }
+        if comm is not None:
+            out["comm"] = comm
         if host_input is not None:
             out["host_input"] = host_input
         if world == 1 and not args.no_cpu_baseline:

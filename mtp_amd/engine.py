@@ -129,7 +129,14 @@ class BackboneEngine:
         attention has none (mmdet vit_rvsa_mtp.py:73-74, 93) -- adding q.0 is exact, so the same kernels serve both"""
         h = self.P.get(pre + "attn.full_attn_rel_pos_h")
         if h is not None:
-            return h, self.P[pre + "attn.full_attn_rel_pos_w"]
+            w = self.P[pre + "attn.full_attn_rel_pos_w"]
+            # the kernels index rel_h[hq - hk + Hp - 1] / rel_w[wq - wk + Wp - 1] with the RUNTIME grid: a table sized for another
+            # input size would be read (and, in the backward, written) out of bounds.  The reference fails here too
+            # (calc_rel_pos_spatial's reshape / index error, VIT:142-193).
+            if h.shape[0] != 2 * Hp - 1 or w.shape[0] != 2 * Wp - 1:
+                raise ValueError("%sattn.full_attn_rel_pos_h/w have %d / %d rows, a %d x %d token grid needs %d / %d (resize them like "
+                                 "init_weights does, or build the model for this input size)" % (pre, h.shape[0], w.shape[0], Hp, Wp, 2 * Hp - 1, 2 * Wp - 1))
+            return h, w
         key = (Hp, Wp)
         if self._zero_rel.get(key) is None:
             self._zero_rel[key] = (torch.zeros(2 * Hp - 1, self.hd, device=self.dev, dtype=F32),

@@ -31,6 +31,12 @@ def _p(t):
         raise RuntimeError("mtp_amd ops run only on an MI355X device tensor (no CPU fallback)")
     if not t.is_contiguous():
         raise RuntimeError("mtp_amd ops need contiguous tensors")
+    # every launch goes to the current stream of the CURRENT device (_s): a tensor living on another GPU (a module moved with
+    # .to('cuda:1') while cuda:0 is current, as multi-GPU runners do) would be dereferenced by the wrong device, unordered
+    # against its own stream.  One process per GPU with torch.cuda.set_device(local_rank) is the supported setup.
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError("mtp_amd ops: tensor on %s but the current device is cuda:%d -- call torch.cuda.set_device(%d) (or use "
+                           "`with torch.cuda.device(...)`) before running the backbone" % (t.device, torch.cuda.current_device(), t.device.index))
     return t.data_ptr()
 
 
@@ -92,6 +98,15 @@ def pick_split_k(M, N, K):
     return max(1, min(split, K // 1024))
 
 
+def effective_split_k(K, dtype, split):
+    """the split launch_tn (csrc/gemm.hip) really runs: at most one K tile (64 bf16 / 32 f32 rows) per split, and no empty
+    splits -- the number of partial tiles the workspace holds and a deferred reduction has to sum"""
+    k_tiles = -(-K // (64 if dtype == torch.bfloat16 else 32))
+    split = max(1, min(int(split), k_tiles))
+    per = -(-k_tiles // split)
+    return -(-k_tiles // per)
+
+
 def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None, defer=None):
     """out (M,N) f32 = a (K,M)^T @ b (K,N)   (weight gradient dW = dY^T X).
     colsum (M,) f32, optional: colsum += a.sum(0) -- the bias gradient, produced by the same pass over dY."""
@@ -106,7 +121,7 @@ def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None,
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb, g.ldc = M, N, N
     g.in_dtype, g.out_dtype, g.epilogue = _dt(a), MTP_F32, EPI_BIAS
-    g.split_k = pick_split_k(M, N, K) if split_k is None else split_k
+    g.split_k = effective_split_k(K, a.dtype, pick_split_k(M, N, K) if split_k is None else split_k)
     g.variant = variant
     if g.split_k > 1 and use_workspace:
         ws = torch.empty(g.split_k * M * N, device=out.device, dtype=torch.float32)   # split-K partials (summed by the callee)

@@ -7,9 +7,10 @@ with an explicit schedule built for 8 x MI355X (7 xGMI links per GPU, 288 GB HBM
     patch/pos embed), so the gradients completed by each stretch of the backward are one contiguous slice -> few, large
     collectives instead of ~50 small buckets; parameters that never get a gradient (`norm.*`, VIT:638) sit after the
     reduced range, which replaces find_unused_parameters' per-step graph walk;
-  * GradReducer: as soon as the engine reports a bucket's last block done (BackboneEngine.backward(on_block_done=...)),
-    an event is recorded on the compute stream and the bucket's all-reduce (SUM, then 1/world folded into the optimizer)
-    is issued on a side HIP stream, overlapping the rest of the backward;
+  * GradReducer: as soon as the engine reports a stretch of the backward done (BackboneEngine.backward(on_block_done=...): the
+    FPN tail, then bursts of four blocks whose weight gradients were launched together), an event is recorded on the compute
+    stream and the all-reduce of that contiguous slice (SUM, 1/world folded into the optimizer) is issued on a side HIP stream,
+    overlapping the rest of the backward;
   * FlatAdamW: clip_grad_norm_(5) + AdamW (main_pretrain.py:424-457, 783-788) as two HBM-bound kernels over the flat buffers,
     with the reference's no-decay rule (mmcv_custom/layer_decay_optimizer_constructor_vit.py:43-48).
 
@@ -132,28 +133,48 @@ def reference_param_groups(named_params, weight_decay, prefix="encoder."):
 
 
 class GradReducer:
-    """Bucketed gradient all-reduce overlapped with the backward (side stream on GPU; synchronous on CPU/gloo)."""
+    """Gradient all-reduce overlapped with the backward (side stream on GPU; synchronous on CPU / gloo).
 
-    def __init__(self, flat, bucket_bytes=256 << 20, group=None):
-        self.flat, self.group = flat, group
+    The engine reports completed groups in completion order (BackboneEngine.backward(on_block_done=...): FPN tail, then the
+    blocks -- in bursts, because the weight gradients of several blocks are launched together (ops.WgradQueue: 4 ViT-L blocks =
+    ~200 MB of gradients per burst) -- then the embeddings).  Everything between the previous cut and the end of the reported
+    group is contiguous in the flat buffer: it becomes ONE collective as soon as it is at least `bucket_bytes` long (or the
+    last group arrived).  With the default 64 MB that is one ~200 MB all-reduce per burst of blocks, issued while the next four
+    blocks' backward (~4.5 ms) runs; only the last burst (blocks 3..0 + embeddings) is exposed."""
+
+    def __init__(self, flat, bucket_bytes=64 << 20, group=None):
+        self.flat, self.group, self.bucket_bytes = flat, group, bucket_bytes
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.buckets = flat.buckets(bucket_bytes)
-        self.by_gid = {g: (s, e) for g, s, e in self.buckets}
+        self.buckets = flat.buckets(bucket_bytes)       # the partition one-group-at-a-time reporting produces (tests, DESIGN)
+        self.last_gid = self.buckets[-1][0]
         self.cuda = flat.grad.is_cuda
         # MTP_FORCE_COMM=1: issue the collectives even at world size 1 (exercises the RCCL + side-stream path on a 1-GPU box)
         import os
         self.active = self.world > 1 or (os.environ.get("MTP_FORCE_COMM") == "1" and dist.is_available() and dist.is_initialized())
         self.stream = torch.cuda.Stream() if self.cuda and self.active else None
         self.works = []
+        self.start = 0
         self.bytes_reduced = 0
+        self.collectives = 0
+        self.timing = False       # bench.py: HIP events around every collective on the side stream
+        self.timed = []
+
+    def begin_step(self):
+        self.start, self.bytes_reduced, self.collectives = 0, 0, 0
 
     def on_block_done(self, gid):
         """engine hook: gradients of group `gid` (and everything before it in completion order) are on the compute stream."""
-        if not self.active or gid not in self.by_gid:
+        if not self.active:
             return
-        s, e = self.by_gid[gid]
-        buf = self.flat.grad[s:e]
-        self.bytes_reduced += (e - s) * 4
+        if not any(self.flat.groups[n] == gid for n in self.flat.names):
+            return
+        end = self.flat.group_end(gid)
+        if end <= self.start or ((end - self.start) * 4 < self.bucket_bytes and gid != self.last_gid):
+            return
+        buf = self.flat.grad[self.start:end]
+        self.bytes_reduced += (end - self.start) * 4
+        self.collectives += 1
+        self.start = end
         if self.stream is None:
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
@@ -161,10 +182,20 @@ class GradReducer:
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
-            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.timing:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.stream)
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.works.append(w)
+            if self.timing:
+                w.wait()                      # (stream-level wait: orders t1 behind the collective on the side stream)
+                t1.record(self.stream)
+                self.timed.append((buf.numel() * 4, t0, t1))
 
     def finish(self):
         """make the compute stream (or the host, on CPU) wait for every outstanding bucket."""
+        if self.active and self.start < self.flat.reduced:      # (a caller that never reported the last group)
+            self.on_block_done(self.last_gid)
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
                 for w in self.works:
@@ -191,7 +222,8 @@ class FlatAdamW:
         self.seg_start, self.seg_wd = st.to(dev), wd.to(dev)
         self.hyper = torch.zeros(6, device=dev, dtype=torch.float32)
         self.sqn = torch.zeros(1, device=dev, dtype=torch.float32)
-        self.t = 0
+        self.t = 0            # Adam step count (bias correction)
+        self.last_epoch = 0   # CosineAnnealingLR.last_epoch: scheduler steps taken (the reference steps it AFTER saving, MAIN:823-832)
 
     def lr_at(self, t):
         if not self.total_steps:
@@ -200,7 +232,7 @@ class FlatAdamW:
 
     def hyper_values(self):
         b1, b2 = self.betas
-        return [self.lr_at(self.t - 1), b1, b2, self.eps, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t]
+        return [self.lr_at(self.last_epoch), b1, b2, self.eps, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t]
 
     # ---- checkpoint / resume in the reference's formats (MAIN:483-499, 823-829) --------------------------------------------
     def state_dict(self, module):
@@ -218,38 +250,60 @@ class FlatAdamW:
                                   "exp_avg_sq": f.view(self.v, n).detach().cpu().clone()}
                 ids.append(idx)
                 idx += 1
-            pgs.append({"lr": self.lr_at(self.t) * scale, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": wd, "amsgrad": False,
+            pgs.append({"lr": self.lr_at(self.last_epoch) * scale, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": wd, "amsgrad": False,
                         "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                         "initial_lr": self.lr0 * scale, "param_names": list(names), "lr_scale": scale, "group_name": name, "params": ids})
         return {"state": state, "param_groups": pgs}
 
-    def load_state_dict(self, sd, module):
+    def load_state_dict(self, sd, module, prefixes=("encoder.", "module.encoder.", "backbone.", "")):
+        """torch.optim.AdamW.state_dict() -> flat m / v / step.  Entries are matched BY NAME through the `param_names` the
+        reference's constructor stores in every group (mmcv_custom/layer_decay_optimizer_constructor_vit.py:60-66), with the
+        pretrain model's `encoder.` prefix stripped: the reference's checkpoints hold the optimizer of the WHOLE model
+        (encoder + three decoders, MAIN:826-829); the decoders' entries are skipped.  State dicts without names (this class's
+        own older files, plain torch) fall back to positional matching, which needs the same parameter list.
+        Returns the number of parameters restored."""
         f = self.flat
-        groups = reference_param_groups(module.named_parameters(), self.weight_decay)
-        names = [n for g in groups for n in g[3]]
-        ids = [i for pg in sd["param_groups"] for i in pg["params"]]
-        if len(ids) != len(names):
-            raise ValueError("optimizer state has %d parameters, the backbone has %d" % (len(ids), len(names)))
-        t = 0
+        own = [n for g in reference_param_groups(module.named_parameters(), self.weight_decay) for n in g[3]]
+        pairs = []      # (optimizer state index, our parameter name)
+        named = all("param_names" in pg and len(pg["param_names"]) == len(pg["params"]) for pg in sd["param_groups"])
+        if named:
+            known = set(own)
+            for pg in sd["param_groups"]:
+                for i, full in zip(pg["params"], pg["param_names"]):
+                    for pre in prefixes:
+                        if full.startswith(pre) and full[len(pre):] in known:
+                            pairs.append((i, full[len(pre):]))
+                            break
+        else:
+            ids = [i for pg in sd["param_groups"] for i in pg["params"]]
+            if len(ids) != len(own):
+                raise ValueError("optimizer state without parameter names has %d entries, the backbone has %d parameters" % (len(ids), len(own)))
+            pairs = list(zip(ids, own))
+        t, restored = 0, 0
         self.m.zero_()
         self.v.zero_()
-        for i, n in zip(ids, names):
+        for i, n in pairs:
             st = sd["state"].get(i)
-            if st is None:
+            if st is None or f.groups[n] is None:
                 continue
+            if tuple(st["exp_avg"].shape) != f.shapes[n]:
+                continue        # a different architecture under the same name: keep the fresh state
             f.view(self.m, n).copy_(st["exp_avg"])
             f.view(self.v, n).copy_(st["exp_avg_sq"])
             t = max(t, int(float(st["step"])))
+            restored += 1
         self.t = t
+        self.last_epoch = t      # (overwritten by load_scheduler_state_dict when the checkpoint carries the scheduler)
+        return restored
 
     def scheduler_state_dict(self):
         """the fields of torch.optim.lr_scheduler.CosineAnnealingLR.state_dict() (MAIN:457: T_max = end_iter, eta_min = 0)"""
-        return {"T_max": self.total_steps, "eta_min": 0, "base_lrs": [self.lr0, self.lr0], "last_epoch": self.t, "verbose": False,
-                "_step_count": self.t + 1, "_get_lr_called_within_step": False, "_last_lr": [self.lr_at(self.t)] * 2}
+        return {"T_max": self.total_steps, "eta_min": 0, "base_lrs": [self.lr0, self.lr0], "last_epoch": self.last_epoch, "verbose": False,
+                "_step_count": self.last_epoch + 1, "_get_lr_called_within_step": False, "_last_lr": [self.lr_at(self.last_epoch)] * 2}
 
     def load_scheduler_state_dict(self, sd):
         self.total_steps = sd.get("T_max", self.total_steps)
-        self.t = int(sd.get("last_epoch", self.t))
+        self.last_epoch = int(sd.get("last_epoch", self.last_epoch))
 
     def step(self):
         from . import ops
@@ -264,12 +318,13 @@ class FlatAdamW:
             ops.sqnorm(f.grad[:n], self.sqn)
             sq = self.sqn
         ops.adamw_flat(f.data[:n], f.grad[:n], self.m[:n], self.v[:n], self.seg_start, self.seg_wd, self.hyper, sq, float(self.max_norm or 0.0), gs)
+        self.last_epoch += 1     # scheduler.step() of MAIN:832
 
 
 class DataParallelTrainer:
     """fwd -> loss -> bwd (+ overlapped bucketed all-reduce) -> clip + AdamW, on the HIP engine."""
 
-    def __init__(self, module, lr=6e-5, weight_decay=0.05, max_norm=5.0, total_steps=None, bucket_bytes=256 << 20, feature_dtype=None):
+    def __init__(self, module, lr=6e-5, weight_decay=0.05, max_norm=5.0, total_steps=None, bucket_bytes=64 << 20, feature_dtype=None):
         self.module = module
         self.engine = module._engine()
         self.flat = FlatParams(module, unused=module._unused_params)
@@ -277,6 +332,23 @@ class DataParallelTrainer:
         self.reducer = GradReducer(self.flat, bucket_bytes)
         self.opt = FlatAdamW(self.flat, lr=lr, weight_decay=weight_decay, max_norm=max_norm, total_steps=total_steps, world_size=self.world)
         self.feature_dtype = feature_dtype
+        self.sync_replicas()
+
+    def sync_replicas(self, optimizer_state=False):
+        """rank 0's parameters (and, after a resume, optimizer state and counters) to every rank -- what DistributedDataParallel
+        does at construction (MAIN:508-518): replicas that were seeded or loaded differently would otherwise sum unrelated
+        gradients silently."""
+        if self.world <= 1:
+            return
+        dist.broadcast(self.flat.data, src=0)
+        if optimizer_state:
+            dist.broadcast(self.opt.m, src=0)
+            dist.broadcast(self.opt.v, src=0)
+            cnt = torch.tensor([self.opt.t, self.opt.last_epoch, self.opt.total_steps or 0], dtype=torch.int64, device=self.flat.data.device)
+            dist.broadcast(cnt, src=0)
+            self.opt.t, self.opt.last_epoch = int(cnt[0]), int(cnt[1])
+            self.opt.total_steps = int(cnt[2]) or None
+        self.engine._key = None
 
     # ---- encoder checkpoint in the reference's dict format (MAIN:823-829 save, MAIN:483-499 resume) -------------------------
     def checkpoint(self, epoch=0, iteration=None, losses=()):
@@ -306,12 +378,14 @@ class DataParallelTrainer:
         if "scheduler" in ckpt:
             self.opt.load_scheduler_state_dict(ckpt["scheduler"])
         self.engine._key = None
+        self.sync_replicas(optimizer_state=True)
         losses = ckpt.get("loss_pretrain", [])
         return ckpt.get("epoch", 0), ckpt.get("iteration", self.opt.t), (losses.tolist() if hasattr(losses, "tolist") else list(losses))
 
     def step(self, img, loss_and_grads):
         """loss_and_grads(feats) -> (loss, [dfeat or None] * 4).  Returns the (local) loss tensor."""
         self.flat.grad.zero_()     # one memset per step: the engine accumulates bias / LayerNorm gradients (engine._colsum)
+        self.reducer.begin_step()
         feats, ctx = self.engine.forward(img, training=True, need_grad=True, feature_dtype=self.feature_dtype)
         loss, dfeats = loss_and_grads(feats)
         self.engine.backward(ctx, dfeats, self.flat.G, on_block_done=self.reducer.on_block_done)

@@ -1,5 +1,7 @@
 """CPU: checkpoint / resume in the reference's formats (main_pretrain.py:483-499 resume, :823-829 save) and the parameter
 groups of LayerDecayOptimizerConstructor_ViT (mmcv_custom/layer_decay_optimizer_constructor_vit.py:33-67)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -47,7 +49,7 @@ def test_optimizer_state_round_trips_with_torch_adamw():
     g = torch.Generator().manual_seed(1)
     opt.m.copy_(torch.randn(opt.m.shape, generator=g))
     opt.v.copy_(torch.rand(opt.v.shape, generator=g))
-    opt.t = 7
+    opt.t = opt.last_epoch = 7
     sd = opt.state_dict(net)
     ref = torch_adamw_like_reference(net)
     ref.load_state_dict(sd)                                   # torch validates group sizes / ids
@@ -75,7 +77,7 @@ def test_optimizer_state_round_trips_with_torch_adamw():
 def test_trainer_checkpoint_in_reference_format(tmp_path):
     net = small()
     tr = DataParallelTrainer(net, total_steps=50)
-    tr.opt.t = 3
+    tr.opt.t = tr.opt.last_epoch = 3
     tr.opt.m.fill_(0.25)
     tr.opt.v.fill_(0.5)
     path = tmp_path / "Iter_3_vit_l_rvsa_pretrn_model_encoder.pth"
@@ -106,3 +108,47 @@ def test_trainer_checkpoint_in_reference_format(tmp_path):
     assert not any(net3.load_state_dict(ck["state_dict"] if "decoder.not_ours.weight" not in ck["state_dict"] else
                                         {k: v for k, v in ck["state_dict"].items() if k != "decoder.not_ours.weight"}, strict=True))
     assert torch.equal(net3.pos_embed, net.pos_embed)
+
+
+def test_resume_from_a_whole_model_reference_checkpoint():
+    """the reference's *_encoder.pth holds optimizer.state_dict() of the WHOLE pretrain model -- encoder + three decoders, names
+    prefixed `encoder.` / `semsegdecoder.` ... (MAIN:826-829) -- written after optimizer.step() but BEFORE scheduler.step()
+    (MAIN:788, 823, 832): Adam step = iteration, scheduler last_epoch = iteration - 1.  The backbone's entries are found by
+    name, the decoders' skipped, and the two counters stay apart."""
+    net = small()
+
+    class Whole(torch.nn.Module):
+        def __init__(self, enc):
+            super().__init__()
+            self.encoder = enc
+            self.semsegdecoder = torch.nn.Conv2d(8, 4, 3)       # stands for the mm* decoders: parameters this build does not own
+            self.rotdetdecoder = torch.nn.Linear(16, 5)
+    whole = Whole(net)
+    # the reference's constructor: groups in first-seen order of named_parameters(), `param_names` stored per group
+    groups = {}
+    for n, p in whole.named_parameters():
+        nd = p.dim() == 1 or n.endswith(".bias") or "pos_embed" in n
+        g = groups.setdefault("no_decay" if nd else "decay", {"params": [], "param_names": [], "weight_decay": 0.0 if nd else 0.05, "lr_scale": 1.0})
+        g["params"].append(p)
+        g["param_names"].append(n)
+    ref = torch.optim.AdamW(list(groups.values()), lr=6e-5, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(ref, 100, eta_min=0)
+    gen = torch.Generator().manual_seed(3)
+    for it in range(1, 4):                                        # three iterations of MAIN's loop
+        for p in whole.parameters():
+            p.grad = torch.randn(p.shape, generator=gen) * 1e-2
+        ref.step()
+        if it == 3:                                               # checkpoint of iteration 3: saved before the scheduler steps
+            ck = {"epoch": 0, "iteration": it, "state_dict": {k: v.clone() for k, v in net.state_dict().items()},
+                  "optimizer": ref.state_dict(), "scheduler": sched.state_dict(), "loss_pretrain": np.array([1.0])}
+        sched.step()
+    assert len(ck["optimizer"]["state"]) > len(list(net.parameters()))           # really the whole model's optimizer
+    tr = DataParallelTrainer(small(), total_steps=100)
+    tr.load_checkpoint(ck)
+    assert tr.opt.t == 3 and tr.opt.last_epoch == 2                               # Adam step 3, scheduler epoch 2
+    P = dict(whole.encoder.named_parameters())
+    for n in ("blocks.2.attn.qkv.weight", "pos_embed", "fpn1.0.bias", "blocks.4.attn.sampling_angles.2.weight"):
+        st = ref.state[P[n]]
+        assert torch.equal(tr.flat.view(tr.opt.m, n), st["exp_avg"]) and torch.equal(tr.flat.view(tr.opt.v, n), st["exp_avg_sq"])
+    # the next step uses the learning rate the reference's resumed loop would use (its scheduler is still at epoch 2)
+    assert tr.opt.hyper_values()[0] == pytest.approx(0.5 * 6e-5 * (1 + math.cos(math.pi * 2 / 100)))

@@ -59,8 +59,8 @@ def test_small_model_forward_and_all_gradients_vs_reference(golden, precision, t
             errs[n] = rel_err(p.grad.cpu(), g["g_" + n])
         else:
             errs[n] = _check_summary(p.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], gt, 1024, n)
-    top = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
-    print("worst param-grad rel errs (%s): %s" % (precision, ", ".join("%s=%.2e" % kv for kv in top)))
+    for n, v in errs.items():
+        record_parity("small_%s_vs_fp32_maxabs" % precision, n, v)
     # the RVSA sampling heads' gradients go through d(bilinear)/d(coord) = DIFFERENCES of neighbouring K/V rows: rounding K/V to
     # bf16 is amplified there (same numbers with the f32-math VALU kernels on bf16 data), so they get their own bf16 bound
     for n, e in errs.items():
@@ -248,7 +248,6 @@ def test_vit_l_headline_model_vs_reference(golden, precision):
             if k.endswith("_vs_fp32_maxabs"):
                 assert v < (1e-3 if k[0] == "f" and k[1].isdigit() else 5e-3), (k, v)
     else:
-        # measured (profiles/r02_parity_errors.json): see the table; the bounds are ~2x the measured values
         for k, v in errs.items():
             if k.endswith("_vs_bf16ref_l2"):
                 assert v < VITL_BF16_L2[_bf16_class(k)], (k, v)
@@ -264,8 +263,16 @@ def _bf16_class(k):
     return "grad"
 
 
-VITL_BF16_L2 = {"fwd": 0.5, "grad": 0.5, "sampling": 1.0}        # placeholders until the first measured run
-VITL_BF16_MAXABS = {"fwd": 0.5, "grad": 0.5, "sampling": 1.0}
+# bf16-mode bounds of the ViT-L test, each ~2x the measured value (profiles/r02_parity_errors.json, group vit_l_b2_bf16):
+#   forward maps   measured 6.4e-3 .. 7.9e-3 relative L2 vs the reference's bf16-autocast run (5.3e-3 .. 6.5e-3 vs its fp32 run; the
+#                  reference's own bf16 run is 7.1e-3 away from its fp32 run)
+#   gradients      measured <= 9.7e-2 (typically 6e-2 .. 8e-2: 24 blocks of bf16 rounding; the reference's own bf16 input gradient
+#                  is 8.0e-2 away from its fp32 one, ours 6.4e-2)
+#   sampling heads measured <= 0.22: d(bilinear)/d(position) is a DIFFERENCE of neighbouring K / V rows, which bf16 rounding of K / V
+#                  hits hardest (the reference's own bf16 run moves these gradients by up to 0.58 on the small model, group
+#                  small_reference_bf16_vs_fp32_l2)
+VITL_BF16_L2 = {"fwd": 2e-2, "grad": 0.15, "sampling": 0.45}
+VITL_BF16_MAXABS = {"fwd": 2e-2, "grad": 0.15, "sampling": 0.45}
 
 
 def test_small_model_bf16_gradients_vs_reference_bf16_autocast(golden):
@@ -294,7 +301,9 @@ def test_small_model_bf16_gradients_vs_reference_bf16_autocast(golden):
         assert v < SMALL_BF16_L2["sampling" if "sampling" in n else "grad"], (n, v, ref_noise[n])
 
 
-SMALL_BF16_L2 = {"grad": 0.5, "sampling": 1.0}      # placeholders until the first measured run
+# measured (profiles/r02_parity_errors.json, group small_bf16_vs_bf16ref_l2): <= 4.3e-2 on the 97 ordinary gradients, <= 0.30 on the
+# sampling heads, where the reference's own bf16 run is up to 0.58 away from its fp32 run (group small_reference_bf16_vs_fp32_l2)
+SMALL_BF16_L2 = {"grad": 0.09, "sampling": 0.6}
 
 
 def test_uint8_input_through_fused_preprocessor_equals_preprocessed_f32_input():

@@ -55,10 +55,10 @@ def test_cosine_schedule_and_bias_correction():
     net = small()
     flat = FlatParams(net, unused=net._unused_params)
     opt = FlatAdamW.__new__(FlatAdamW)
-    opt.lr0, opt.betas, opt.eps, opt.total_steps, opt.t = 6e-5, (0.9, 0.999), 1e-8, 100, 0
+    opt.lr0, opt.betas, opt.eps, opt.total_steps, opt.t, opt.last_epoch = 6e-5, (0.9, 0.999), 1e-8, 100, 0, 0
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=6e-5), T_max=100)
     for t in range(1, 6):
-        opt.t = t
+        opt.t, opt.last_epoch = t, t - 1          # the t-th Adam step runs with the learning rate of scheduler epoch t - 1
         hv = opt.hyper_values()
         assert hv[0] == pytest.approx(sched.get_last_lr()[0], rel=1e-9)
         assert hv[4] == pytest.approx(1 - 0.9 ** t) and hv[5] == pytest.approx(1 - 0.999 ** t)
@@ -88,11 +88,23 @@ def _worker(rank, world, port, q):
         dist.all_reduce(ref)                                   # the single-tensor reference
         red = GradReducer(flat, bucket_bytes=1 << 20)
         assert red.world == world and len(red.buckets) > 2
-        order = [6] + list(range(5, -1, -1)) + [-1]             # the engine's completion order
+        order = [6] + list(range(5, -1, -1)) + [-1]             # the engine's completion order, one group at a time
         for gid in order:
             red.on_block_done(gid)
         red.finish()
         ok = torch.equal(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        ok = ok and red.collectives == len(red.buckets)
+        # ... and in bursts, as the engine reports them when the weight gradients of several blocks are launched together
+        flat.grad.copy_(local)
+        red.begin_step()
+        for gid in (6, 5, 4, 3):
+            red.on_block_done(gid)          # (all at once after the burst's launch)
+        n_after_burst = red.collectives
+        for gid in (2, 1, 0, -1):
+            red.on_block_done(gid)
+        red.finish()
+        ok = ok and torch.equal(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        ok = ok and n_after_burst >= 1 and red.start == flat.reduced
         q.put((rank, bool(ok), red.bytes_reduced == flat.reduced * 4))
     finally:
         dist.destroy_process_group()
@@ -110,3 +122,38 @@ def test_bucketed_allreduce_equals_single_allreduce_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True, True), (1, True, True)]
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mtp_amd.parallel import DataParallelTrainer
+        torch.manual_seed(1000 + rank)                          # every rank initialises DIFFERENTLY ...
+        net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
+        tr = DataParallelTrainer(net, total_steps=20)           # ... the trainer broadcasts rank 0's replica (DDP does, MAIN:508-518)
+        a = tr.flat.data.clone()
+        dist.broadcast(a, src=0)
+        same_params = torch.equal(a, tr.flat.data)
+        # resume: only rank 0 "read the checkpoint"; optimizer state and both counters must follow
+        if rank == 0:
+            tr.opt.m.fill_(0.5); tr.opt.v.fill_(0.25); tr.opt.t, tr.opt.last_epoch = 9, 8
+        tr.sync_replicas(optimizer_state=True)
+        ok = same_params and float(tr.opt.m.mean()) == 0.5 and float(tr.opt.v.mean()) == 0.25 and (tr.opt.t, tr.opt.last_epoch) == (9, 8)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_synchronises_replicas_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
