@@ -293,9 +293,18 @@ def main():
             out["host_input"] = host_input
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model)
-        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST line of stdout: RCCL prints a version banner through C stdio, which would otherwise be
+        # flushed at process exit, after Python's print
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

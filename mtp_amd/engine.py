@@ -387,9 +387,10 @@ class BackboneEngine:
     # ------------------------------------------------------------------ whole backward
     def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None):
         """dfeats: 4 NCHW cotangents (or None).  G: name -> f32 gradient buffer (overwritten; parameters that receive no
-        gradient -- `norm.*`, blocks after the last tap -- are left untouched).  on_block_done(i) is called after the
-        gradients of block i (and, for i == -1, of patch-embed / pos-embed) are complete on the current stream --
-        the hook mtp_amd.parallel uses to launch bucketed RCCL all-reduces on a side stream."""
+        gradient -- `norm.*`, blocks after the last tap -- are left untouched).  on_block_done(i) is called once the gradients
+        of block i AND of every block after it (and, for i == -1, of patch-embed / pos-embed) are complete on the current stream:
+        once per burst of blocks whose weight gradients were launched together (ops.WgradQueue), with the lowest block index of
+        the burst -- the hook mtp_amd.parallel uses to launch RCCL all-reduces of contiguous gradient slices on a side stream."""
         B, Cin, H, W, Hp, Wp = ctx["geom"]
         C, N, T = self.C, Hp * Wp, B * Hp * Wp
         P = self.P
@@ -444,8 +445,7 @@ class BackboneEngine:
             if i == 0 or wq.should_flush():
                 wq.flush()
                 if on_block_done is not None:
-                    for j in waiting:
-                        on_block_done(j)
+                    on_block_done(waiting[-1])     # the lowest block of the burst: its group end covers the whole burst
                 waiting = []
         # ---- patch embed / pos embed
         ops.gemm_tn(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1), colsum=G["patch_embed.proj.bias"])
