@@ -38,7 +38,11 @@ typedef enum {
     MTP_EPI_BIAS = 0,      /* C = acc + bias                          (bias may be NULL)                   */
     MTP_EPI_BIAS_GELU = 1, /* aux = acc + bias (pre-activation u);  C = gelu(u)            nn.GELU erf   */
     MTP_EPI_BIAS_RES = 2,  /* C(f32) = res[row % res_mod] + rowscale[row / rows_per_sample] * (acc + bias) */
-    MTP_EPI_DGELU = 3      /* C = acc * gelu'(aux)                                                         */
+    MTP_EPI_DGELU = 3,     /* C = acc * gelu'(aux)                                                         */
+    /* the pair the training engine uses for fc1 / its backward (VIT:55-62): the forward stores gelu'(u) instead of u -- the erf
+     * and the exponential are shared with gelu(u), and the backward epilogue is one multiplication instead of another erf */
+    MTP_EPI_BIAS_GELU_DG = 4, /* u = acc + bias;  aux = gelu'(u);  C = gelu(u)                              */
+    MTP_EPI_MUL = 5           /* C = acc * aux                                                            */
 } mtp_epilogue;
 
 typedef struct {
@@ -56,7 +60,8 @@ typedef struct {
     int64_t res_ld, res_mod;
     const float* rowscale; /* EPI_BIAS_RES: per-sample drop-path factor or NULL                           */
     int64_t rows_per_sample;
-    void* aux;          /* EPI_BIAS_GELU: u out;  EPI_DGELU: u in;  (M, N), ld aux_ld, dtype out_dtype.
+    void* aux;          /* EPI_BIAS_GELU: u out;  EPI_DGELU: u in;  EPI_BIAS_GELU_DG: gelu'(u) out;  EPI_MUL: factor in;
+                         * (M, N), ld aux_ld, dtype out_dtype.
                          * TN with split_k > 1: optional f32 workspace (split_k * M * N) for the partial tiles,
                          * summed into C by the callee (deterministic); NULL = f32 atomicAdd into zeroed C  */
     int64_t aux_ld;

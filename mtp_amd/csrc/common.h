@@ -109,6 +109,13 @@ __device__ __forceinline__ float gelu_f(float x) {
     float e;
     return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, e));
 }
+// gelu(x) and gelu'(x) together: one erf, one exponential
+__device__ __forceinline__ void gelu_pair_f(float x, float& g, float& dg) {
+    float e;
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+    g = x * cdf;
+    dg = cdf + x * 0.39894228040143267794f * e;
+}
 __device__ __forceinline__ float dgelu_f(float x) {
     float e;
     const float er = erf_as(x * 0.70710678118654752440f, e);

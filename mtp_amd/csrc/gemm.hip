@@ -647,7 +647,7 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     if (rc) return rc;
     if (a->K % E) return MTP_ERR_ARG;
     if (EPI == MTP_EPI_BIAS_RES && (!a->res || (a->res_ld % 4))) return MTP_ERR_ARG;
-    if ((EPI == MTP_EPI_BIAS_GELU || EPI == MTP_EPI_DGELU) && (!a->aux || (a->aux_ld % 4))) return MTP_ERR_ARG;
+    if ((EPI == MTP_EPI_BIAS_GELU || EPI == MTP_EPI_DGELU || EPI == MTP_EPI_BIAS_GELU_DG || EPI == MTP_EPI_MUL) && (!a->aux || (a->aux_ld % 4))) return MTP_ERR_ARG;
     if (a->bias && a->bias_mod > 0 && (a->bias_mod % 4)) return MTP_ERR_ARG;
     // 256 x 256 8-wave pipelined kernel (gemm_p8.hip; bf16, whole K-tile pairs): variant bits 8-9 = 1 one workgroup per tile,
     // 2 persistent workgroups; falls through to the 128-wide kernels when the problem does not fit it
@@ -778,6 +778,8 @@ int dispatch_epi(const mtp_gemm_args* a, hipStream_t s) {
         case MTP_EPI_BIAS: return launch_nt<T, Tout, MTP_EPI_BIAS>(a, s);
         case MTP_EPI_BIAS_GELU: return launch_nt<T, Tout, MTP_EPI_BIAS_GELU>(a, s);
         case MTP_EPI_DGELU: return launch_nt<T, Tout, MTP_EPI_DGELU>(a, s);
+        case MTP_EPI_BIAS_GELU_DG: return launch_nt<T, Tout, MTP_EPI_BIAS_GELU_DG>(a, s);
+        case MTP_EPI_MUL: return launch_nt<T, Tout, MTP_EPI_MUL>(a, s);
         default: return MTP_ERR_UNSUPPORTED;
     }
 }

@@ -79,7 +79,7 @@ __device__ __forceinline__ void epilogue(const KArgs& p, f32x4_t (&acc)[4][MF], 
         const int n = ncol0 + ni * 16 + g * 4;
         nok[ni] = n < p.N;
         nn[ni] = nok[ni] ? n : 0;
-        const float* bp = (EPI != MTP_EPI_DGELU && p.bias) ? p.bias + (p.bias_mod > 0 ? nn[ni] % p.bias_mod : nn[ni]) : reinterpret_cast<const float*>(&g_zero16);
+        const float* bp = (EPI != MTP_EPI_DGELU && EPI != MTP_EPI_MUL && p.bias) ? p.bias + (p.bias_mod > 0 ? nn[ni] % p.bias_mod : nn[ni]) : reinterpret_cast<const float*>(&g_zero16);
         const uint4 b = ldg16(bp);
         bias[ni] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
     }
@@ -108,7 +108,7 @@ __device__ __forceinline__ void epilogue(const KArgs& p, f32x4_t (&acc)[4][MF], 
                 side[ni] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
             }
             if (rsp) rs = *rsp;
-        } else if (EPI == MTP_EPI_DGELU) {
+        } else if (EPI == MTP_EPI_DGELU || EPI == MTP_EPI_MUL) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) side[ni] = load4(reinterpret_cast<const Tout*>(p.aux) + (int64_t)mc * p.aux_ld + nn[ni]);
         }
@@ -119,8 +119,14 @@ __device__ __forceinline__ void epilogue(const KArgs& p, f32x4_t (&acc)[4][MF], 
             if (EPI == MTP_EPI_BIAS_GELU) {
                 if (ok) store4(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + nn[ni], v);
                 v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+            } else if (EPI == MTP_EPI_BIAS_GELU_DG) {
+                float4 d;
+                gelu_pair_f(v.x, v.x, d.x); gelu_pair_f(v.y, v.y, d.y); gelu_pair_f(v.z, v.z, d.z); gelu_pair_f(v.w, v.w, d.w);
+                if (ok) store4(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + nn[ni], d);
             } else if (EPI == MTP_EPI_DGELU) {
                 v = make_float4(v.x * dgelu_f(side[ni].x), v.y * dgelu_f(side[ni].y), v.z * dgelu_f(side[ni].z), v.w * dgelu_f(side[ni].w));
+            } else if (EPI == MTP_EPI_MUL) {
+                v = make_float4(v.x * side[ni].x, v.y * side[ni].y, v.z * side[ni].z, v.w * side[ni].w);
             } else if (EPI == MTP_EPI_BIAS_RES) {
                 v = make_float4(side[ni].x + rs * v.x, side[ni].y + rs * v.y, side[ni].z + rs * v.z, side[ni].w + rs * v.w);
             }

@@ -139,7 +139,7 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
 #pragma unroll
     for (int q = 0; q < NV / 4; ++q) {
         const int nb = nc + 4 * q;
-        const float* bp = (EPI != MTP_EPI_DGELU && p.bias) ? p.bias + (p.bias_mod > 0 ? nb % p.bias_mod : nb) : reinterpret_cast<const float*>(&g_zero16);
+        const float* bp = (EPI != MTP_EPI_DGELU && EPI != MTP_EPI_MUL && p.bias) ? p.bias + (p.bias_mod > 0 ? nb % p.bias_mod : nb) : reinterpret_cast<const float*>(&g_zero16);
         const float4 b = ld4f(bp);
         bias[4 * q + 0] = b.x; bias[4 * q + 1] = b.y; bias[4 * q + 2] = b.z; bias[4 * q + 3] = b.w;
     }
@@ -158,7 +158,7 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
             const int mb = mrow0 + h * RSTRIDE + bt * 8 * RSTEP + rsub;     // first row of this lane in the batch; rows mb + it * RSTEP
             // side inputs of the whole batch first (unconditional loads on clamped rows), so that they are all in flight together
             float4 side[(EPI == MTP_EPI_BIAS_RES) ? 8 : 1];
-            uint4 sideb[(EPI == MTP_EPI_DGELU) ? 8 : 1];
+            uint4 sideb[(EPI == MTP_EPI_DGELU || EPI == MTP_EPI_MUL) ? 8 : 1];
             float rsv[(EPI == MTP_EPI_BIAS_RES) ? 8 : 1];
             if constexpr (EPI == MTP_EPI_BIAS_RES) {
                 // row -> sample and row % res_mod advance incrementally: one division per batch, not per row
@@ -176,7 +176,7 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
                         if (p.res_mod > 0) while (rrow >= p.res_mod) rrow -= p.res_mod;
                     }
                 }
-            } else if constexpr (EPI == MTP_EPI_DGELU) {
+            } else if constexpr (EPI == MTP_EPI_DGELU || EPI == MTP_EPI_MUL) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     int m = mb + it * RSTEP;
@@ -204,12 +204,24 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
                     if (ok) store8(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, v);
 #pragma unroll
                     for (int e = 0; e < NV; ++e) v[e] = gelu_f(v[e]);
+                } else if constexpr (EPI == MTP_EPI_BIAS_GELU_DG) {
+                    float d[NV];
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) gelu_pair_f(v[e], v[e], d[e]);
+                    if (ok) store8(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, d);
                 } else if constexpr (EPI == MTP_EPI_DGELU) {
                     const uint32_t w[4] = {sideb[it].x, sideb[it].y, sideb[it].z, sideb[it].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[2 * e] *= dgelu_f(bf16_bits_to_f32(w[e] & 0xffffu));
                         v[2 * e + 1] *= dgelu_f(bf16_bits_to_f32(w[e] >> 16));
+                    }
+                } else if constexpr (EPI == MTP_EPI_MUL) {
+                    const uint32_t w[4] = {sideb[it].x, sideb[it].y, sideb[it].z, sideb[it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] *= bf16_bits_to_f32(w[e] & 0xffffu);
+                        v[2 * e + 1] *= bf16_bits_to_f32(w[e] >> 16);
                     }
                 } else if constexpr (EPI == MTP_EPI_BIAS_RES) {
                     v[0] = side[it].x + rsv[it] * v[0]; v[1] = side[it].y + rsv[it] * v[1];

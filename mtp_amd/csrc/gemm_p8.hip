@@ -277,6 +277,8 @@ int dispatch_p8(const KArgs& k, int epi, int flags, hipStream_t s) {
         case MTP_EPI_BIAS: return launch_p8<Tout, MTP_EPI_BIAS>(k, flags, s);
         case MTP_EPI_BIAS_GELU: return launch_p8<Tout, MTP_EPI_BIAS_GELU>(k, flags, s);
         case MTP_EPI_DGELU: return launch_p8<Tout, MTP_EPI_DGELU>(k, flags, s);
+        case MTP_EPI_BIAS_GELU_DG: return launch_p8<Tout, MTP_EPI_BIAS_GELU_DG>(k, flags, s);
+        case MTP_EPI_MUL: return launch_p8<Tout, MTP_EPI_MUL>(k, flags, s);
         default: return MTP_ERR_UNSUPPORTED;
     }
 }
@@ -288,7 +290,7 @@ int mtp_nt_p8_fits(const KArgs& k, int out_dtype, int epi) {
     if (k.K < 128 || (k.K % 128) || (k.M % 8) || (k.N % 8) || k.M < 8 || k.N < 8) return 0;
     if ((uint64_t)k.lda * 2 * 8 + (uint64_t)k.K * 2 >= (1ull << 31) || (uint64_t)k.ldb * 2 * 8 + (uint64_t)k.K * 2 >= (1ull << 31)) return 0;
     if (epi == MTP_EPI_BIAS_RES) return out_dtype == MTP_F32;
-    if (out_dtype == MTP_BF16) return epi == MTP_EPI_BIAS || epi == MTP_EPI_BIAS_GELU || epi == MTP_EPI_DGELU;
+    if (out_dtype == MTP_BF16) return epi == MTP_EPI_BIAS || epi == MTP_EPI_BIAS_GELU || epi == MTP_EPI_DGELU || epi == MTP_EPI_BIAS_GELU_DG || epi == MTP_EPI_MUL;
     return out_dtype == MTP_F32 && epi == MTP_EPI_BIAS;
 }
 

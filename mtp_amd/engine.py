@@ -144,18 +144,15 @@ class BackboneEngine:
         return self._zero_rel[key]
 
     def _drop_scales(self, B, training):
-        """VIT:31-42, 619: per-sample factor floor(keep + U[0,1)) / keep for each residual branch; None when inactive."""
-        out = []
-        for i in range(self.depth):
-            r = float(self.m.drop_path_rates[i])
-            if not training or r == 0.0 or not self.m.blocks[i].training:   # (a frozen stage is put in eval(): no drop-path there)
-                out.append((None, None))
-            else:
-                keep = 1.0 - r
-                u = torch.rand(2, B, device=self.dev, dtype=F32)
-                s = torch.floor(keep + u) / keep
-                out.append((s[0].contiguous(), s[1].contiguous()))
-        return out
+        """VIT:31-42, 619: per-sample factor floor(keep + U[0,1)) / keep for each residual branch; None when inactive.
+        One RNG launch for the whole network (the per-block torch.rand / floor / div were ~100 tiny launches per step)."""
+        rates = [float(self.m.drop_path_rates[i]) for i in range(self.depth)]
+        live = [training and r > 0.0 and self.m.blocks[i].training for i, r in enumerate(rates)]   # (a frozen stage is in eval(): no drop-path)
+        if not any(live):
+            return [(None, None)] * self.depth
+        keep = torch.tensor([1.0 - r for r in rates], dtype=F32).to(self.dev, non_blocking=True).view(self.depth, 1, 1)
+        s = torch.floor(keep + torch.rand(self.depth, 2, B, device=self.dev, dtype=F32)) / keep
+        return [(s[i, 0], s[i, 1]) if live[i] else (None, None) for i in range(self.depth)]
 
     # ------------------------------------------------------------------ block forward
     def _block_fwd(self, i, x, B, Hp, Wp, dps, save):
@@ -184,8 +181,8 @@ class BackboneEngine:
                          rowscale=dps[0], rows_per_sample=N)
         mean2, rstd2 = self._e(T, dtype=F32), self._e(T, dtype=F32)
         ln2 = ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], self._e(T, C), mean2, rstd2)
-        u = self._e(T, 4 * C)
-        h = ops.gemm_nt(ln2, b.w1, self._e(T, 4 * C), epi=ops.EPI_BIAS_GELU, bias=P[pre + "mlp.fc1.bias"], aux=u)
+        u = self._e(T, 4 * C)     # gelu'(fc1 pre-activation): all the MLP backward needs of it (one multiplication in the dgrad epilogue)
+        h = ops.gemm_nt(ln2, b.w1, self._e(T, 4 * C), epi=ops.EPI_BIAS_GELU_DG, bias=P[pre + "mlp.fc1.bias"], aux=u)
         x2 = ops.gemm_nt(h, b.w2, self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=P[pre + "mlp.fc2.bias"], res=x1,
                          rowscale=dps[1], rows_per_sample=N)
         if save:
@@ -204,7 +201,7 @@ class BackboneEngine:
         # (weight gradients: queued, launched together with those of the neighbouring blocks -- ops.WgradQueue)
         wq = self._wq
         wq.add(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], G[pre + "mlp.fc2.bias"])
-        du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_DGELU, aux=s["u"])
+        du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_MUL, aux=s["u"])
         wq.add(du, s["ln2"], G[pre + "mlp.fc1.weight"], G[pre + "mlp.fc1.bias"])
         dln2 = ops.gemm_nt(du, b.w1T, self._e(T, C))
         del du

@@ -7,7 +7,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, MTP_BF16, MTP_F32, GemmArgs, check  # noqa: F401
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_DG, EPI_BIAS_RES, EPI_DGELU, EPI_MUL, MTP_BF16, MTP_F32, GemmArgs,  # noqa: F401
+                   check)
 
 _DT = {torch.float32: MTP_F32, torch.bfloat16: MTP_BF16}
 _NT_VARIANT = int(__import__("os").environ.get("MTP_NT_VARIANT", "0"))   # whole-model A/B of the NT GEMM kernel choices (mtp_hip.h: variant)

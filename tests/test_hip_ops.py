@@ -75,6 +75,13 @@ def test_gemm_nt_epilogues(ops, dtype):
     uu = rnd(M, N, dtype=dtype, seed=5)
     out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N, dtype=dtype), epi=ops.EPI_DGELU, aux=dev(uu, dtype))
     assert rel_err(out.float().cpu(), (a @ w.t()) * O.dgelu(uu)) < TOL[dtype]
+    # the pair the engine uses for fc1 and its backward: forward stores gelu'(u), backward multiplies by it
+    dg = e(M, N, dtype=dtype)
+    h2 = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU_DG, bias=dev(b), aux=dg)
+    assert rel_err(h2.float().cpu(), O.gelu(ref)) < TOL[dtype] and rel_err(dg.float().cpu(), O.dgelu(ref)) < TOL[dtype]
+    fac = rnd(M, N, dtype=dtype, seed=7)
+    out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N, dtype=dtype), epi=ops.EPI_MUL, aux=dev(fac, dtype))
+    assert rel_err(out.float().cpu(), (a @ w.t()) * fac) < TOL[dtype]
     # bias_mod (ConvTranspose2d bias repeated per tap), f32 out from ACT in
     b4 = rnd(N // 4, seed=6)
     out = ops.gemm_nt(dev(a, dtype), dev(w, dtype), e(M, N), bias=dev(b4), bias_mod=N // 4)
@@ -144,7 +151,10 @@ def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
         r = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=v)
         d = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_DGELU, aux=uu, variant=v)
         f = ops.gemm_nt(a, w, e(M, N), bias=b, variant=v)
-        return u, h, r, d, f
+        dg = e(M, N, dtype=dtype)
+        h2 = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU_DG, bias=b, aux=dg, variant=v)
+        mu = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_MUL, aux=uu, variant=v)
+        return u, h, r, d, f, dg, h2, mu
     ref = run(1024)
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
     for v in (512, 768):
