@@ -133,7 +133,9 @@ class BackboneEngine:
             # the kernels index rel_h[hq - hk + Hp - 1] / rel_w[wq - wk + Wp - 1] with the RUNTIME grid: a table sized for another
             # input size would be read (and, in the backward, written) out of bounds.  The reference fails here too
             # (calc_rel_pos_spatial's reshape / index error, VIT:142-193).
-            if h.shape[0] != 2 * Hp - 1 or w.shape[0] != 2 * Wp - 1:
+            # (A LARGER table is fine and means what it means in the reference: rows [0, 2 Hp - 2] are used -- the tables are sized from
+            #  patch_shape[0] for both axes, VIT:81-84, so every non-square input has a taller rel_pos_w than it needs.)
+            if h.shape[0] < 2 * Hp - 1 or w.shape[0] < 2 * Wp - 1:
                 raise ValueError("%sattn.full_attn_rel_pos_h/w have %d / %d rows, a %d x %d token grid needs %d / %d (resize them like "
                                  "init_weights does, or build the model for this input size)" % (pre, h.shape[0], w.shape[0], Hp, Wp, 2 * Hp - 1, 2 * Wp - 1))
             return h, w
