@@ -47,8 +47,11 @@ def test_small_model_forward_and_all_gradients_vs_reference(golden, precision, t
         loss = loss + (f * recipe.loss_weights(f.shape, 200 + i).cuda()).sum()
     assert rel_err(feats[2].cpu(), g["f2"]) < tol and rel_err(feats[3].cpu(), g["f3"]) < tol
     loss.backward()
-    # gradients: fp32 mode 5e-3; bf16 mode: bf16 rounding of activations/weights through 6 blocks gives O(10 %) noise on
-    # individual gradient entries (the reference itself moves by 5e-3 in the forward under bf16 autocast)
+    # gradients: fp32 mode 5e-3 (measured: <= 4.4e-6 on all 123 tensors, profiles/r02_parity_errors.json group small_fp32_vs_fp32_maxabs).
+    # bf16 mode, WORST SINGLE ENTRY relative to the tensor's largest (a max-abs metric: one unlucky element decides): measured <= 0.23
+    # on the ordinary gradients and <= 0.42 on the sampling heads (group small_bf16_vs_fp32_maxabs) -- the same tensors are within
+    # 4.3e-2 / 0.30 relative L2 of the reference's own bf16-autocast gradients (test_small_model_bf16_gradients_vs_reference_bf16_autocast,
+    # which is the meaningful bf16 bound); the reference's bf16 run itself is 6e-2 / 0.58 away from its fp32 run.
     gt = 5 * tol if precision == "fp32" else 0.35
     _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], gt, 2048, "dimg")
     errs = {}
