@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--host-input", action="store_true", help="additionally time the step fed from HOST uint8 batches (pinned staging, side-stream H2D, "
                                                               "fused preprocess): reported as `host_input`, never as `value`")
+    ap.add_argument("--heads", default="mean", choices=["mean", "standin3"],
+                    help="what consumes the four feature maps: `mean` = sum_i mean(f_i) (the headline line); `standin3` = three labelled stand-in task "
+                         "heads (BASELINE configs[1]: 'ViT-B/16 + 3 MTP decoder heads'; the real decoders live in un-vendored mmseg / mmdet / mmrotate)")
     ap.add_argument("--image-size", type=int, default=224, help="224 = the headline metric; 448 = what MTP actually pretrains at (use --batch 16)")
     args = ap.parse_args()
 
@@ -166,11 +169,29 @@ def main():
     B = args.batch
     img = torch.randn(B, 3, args.image_size, args.image_size, device="cuda")
 
-    def loss_and_grads(feats):
-        # stand-in for the three task decoders: loss = sum_i mean(f_i), d loss / d f_i = 1 / numel(f_i), written out by hand
-        # (one f32-accumulating reduction + one fill per map, every step) instead of through autograd's f32 copies of the maps
-        loss = sum(f.sum(dtype=torch.float32) / f.numel() for f in feats)
-        return loss, [torch.full_like(f, 1.0 / f.numel()) for f in feats]
+    if args.heads == "standin3":
+        # Three STAND-IN task heads (semantic segmentation / instance segmentation / rotated detection of models.py:112-179, 329-335,
+        # which call mmseg / mmdet / mmrotate decoders that are not vendored): head t scores every pixel of every map with its own
+        # 1x1 projection w[t][i] (C -> 1) and averages -- three consumers of the four maps with their own parameters and a
+        # per-channel cotangent, nothing more.  Labelled as stand-ins in `config`.
+        gh = torch.Generator(device="cuda").manual_seed(7)
+        C_ = net.embed_dim
+        head_w = [[torch.randn(C_, device="cuda", generator=gh) / C_ ** 0.5 for _ in range(4)] for _ in range(3)]
+
+        def loss_and_grads(feats):
+            loss, grads = 0.0, []
+            for i, f in enumerate(feats):
+                wsum = head_w[0][i] + head_w[1][i] + head_w[2][i]
+                pix = f.shape[0] * f.shape[2] * f.shape[3]
+                loss = loss + (f.sum(dim=(0, 2, 3), dtype=torch.float32) * wsum).sum() / pix
+                grads.append((wsum / pix).to(f.dtype).view(1, -1, 1, 1).expand_as(f).contiguous())
+            return loss, grads
+    else:
+        def loss_and_grads(feats):
+            # stand-in for the three task decoders: loss = sum_i mean(f_i), d loss / d f_i = 1 / numel(f_i), written out by hand
+            # (one f32-accumulating reduction + one fill per map, every step) instead of through autograd's f32 copies of the maps
+            loss = sum(f.sum(dtype=torch.float32) / f.numel() for f in feats)
+            return loss, [torch.full_like(f, 1.0 / f.numel()) for f in feats]
 
     timer = GemmTimer(ops)
     if not args.no_gemm_timer:
@@ -262,14 +283,16 @@ def main():
             d = fams[dom]
             ach = d["flops"] / d["seconds"] / 1e12
             traffic = None   # HBM bytes per launch of the dominant family, from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs)
+            traffic_src = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
-                traffic = (pmc[dom + "_kernel"]["hbm_bytes_per_launch"]
-                           if args.model == "vit_l" and args.precision == "bf16" and B == 64 and args.image_size == 224 else None)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))
+                if args.model == "vit_l" and args.precision == "bf16" and B == 64 and args.image_size == 224:
+                    traffic = pmc[dom + "_kernel"]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/r02_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload at commit %s)" % pmc.get("_commit", "?")
             except Exception:
                 traffic = None
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
-                        unit="TFLOP/s", frac=round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4), traffic=traffic,
+                        unit="TFLOP/s", frac=round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 4), traffic=traffic, traffic_source=traffic_src,
                         flops_per_launch=round(d["flops"] / d["launches"]),
                         avg_launch_us=round(d["seconds"] / d["launches"] * 1e6, 1), launches_per_step=d["launches"] // args.steps,
                         families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / args.steps * 1e3, 2))
@@ -282,8 +305,11 @@ def main():
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "%s + RVSA backbone fwd+bwd + grad all-reduce + clip + AdamW, %dx%d, batch %d per GPU%s"
                                    % ("ViT-L" if args.model == "vit_l" else "ViT-B", args.image_size, args.image_size, B,
-                                      " (BASELINE configs[2]/[3])" if args.image_size == 224 else " (not the headline configuration)"),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss)},
+                                      (" (BASELINE configs[2]/[3])" if args.model == "vit_l" and B == 64 else " (BASELINE configs[1])" if args.model == "vit_b" and B == 32 else "")
+                                      if args.image_size == 224 else " (not the headline configuration)"),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss),
+                       "heads": ("3 stand-in task heads (per-map 1x1 projection + mean each; the mm* decoders are not vendored)" if args.heads == "standin3"
+                                 else "sum_i mean(f_i)")},
             "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if args.image_size == 224 else None,
             "roofline": roof,
         }
