@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 bk[dt][kk] = ld8x2(dKt + o, dKt + o + 8);
                 bv[dt][kk] = ld8x2(dVt + o, dVt + o + 8);
             }
-        for (int ti = t_lo + wave; ti <= t_hi; ti += 4) {
+        for (int ti = t_lo + wave; ti <= t_hi && dense_scatter != 2; ti += 4) {
             const int tok = 16 * ti + fr, tyy = tok / g.Wp, txx = tok - tyy * g.Wp;
             const float X = (float)(txx + g.pad_l), Y = (float)(tyy + g.pad_t);
             const float live = tok < N ? 1.f : 0.f;
@@ -584,7 +584,7 @@ int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, 
                              float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     const RvsaGeom g = make_geom(Hp, Wp, heads);
-    static const int dense = []() { const char* e = getenv("MTP_RVSA_SCATTER"); return (e && e[0] == 'c') ? 0 : 1; }();   // "corner": per-(key, corner) atomics (A/B)
+    static const int dense = []() { const char* e = getenv("MTP_RVSA_SCATTER"); return (e && e[0] == 'c') ? 0 : (e && e[0] == 'n') ? 2 : 1; }();   // "corner": per-(key, corner) atomics (A/B); "none": ablation, no scatter at all
     hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, dense);
     return mtp_launch_status();
