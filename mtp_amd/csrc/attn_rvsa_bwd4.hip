@@ -31,8 +31,8 @@ __device__ __forceinline__ Sample make_sample(const RvsaGeom& g, const float* __
     s.rely = (float)(a - 3) * stepy;
     s.rx = s.relx * sx;
     s.ry = s.rely * sy;
-    s.cs = cosf(ang);
-    s.sn = sinf(ang);
+    s.cs = __cosf(ang);      // v_cos / v_sin (abs error ~1e-6 on |ang| < pi): this kernel and the forward share the expression
+    s.sn = __sinf(ang);
     const float gx = cenx + (s.rx * s.cs - s.ry * s.sn) + offx;
     const float gy = ceny + (s.ry * s.cs + s.rx * s.sn) + offy;
     float ix = (gx + 1.0f) * 0.5f * (float)(g.We - 1), iy = (gy + 1.0f) * 0.5f * (float)(g.He - 1);
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv, float* __restrict__ dkv, float* __restrict__ dsamp,
                                                             float* __restrict__ rel_part, float* __restrict__ tab_part,
                                                             const float* __restrict__ rel_h, const float* __restrict__ rel_w, const float* __restrict__ bias_table,
-                                                            RvsaGeom g, float scale, int dense_scatter) {
+                                                            RvsaGeom g, float scale, int dense_scatter_) {
+    const int dense_scatter = dense_scatter_ & 15, stop_after = dense_scatter_ >> 4;   // stop_after: phase-timing ablation (tools/ab_rvsa.py)
     __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
     __shared__ __attribute__((aligned(16))) char R2[2 * 64 * TP];
@@ -167,64 +168,8 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     }
     if (tid < 8) vsum[tid] = 0.f;
     for (int i = tid; i < 26 * 64; i += 256) dQR[i] = 0.f;
-    {   // ---- gather: thread = (key = lane, 16-channel quarter = wave)
-        const int d0 = 16 * wave;
-        float ks[16], vs[16];
-#pragma unroll
-        for (int d = 0; d < 16; ++d) { ks[d] = 0.f; vs[d] = 0.f; }
-        Sample s;
-        s.fx = 0.f; s.fy = 0.f; s.x0 = -100; s.y0 = -100; s.rx = 0.f; s.ry = 0.f; s.cs = 1.f; s.sn = 0.f; s.relx = 0.f; s.rely = 0.f;
-        if (lane < 49) {
-            s = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, lane / 7, lane % 7);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float w;
-                const int tok = neighbour(g, s.x0, s.y0, s.fx, s.fy, k, w);
-                const int tc = tok >= 0 ? tok : 0;
-                w = tok >= 0 ? w : 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float t[8];
-                    load8(base + C + (int64_t)tc * ld + d0 + 8 * i, t);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ks[8 * i + e] += w * t[e];
-                    load8(base + 2 * C + (int64_t)tc * ld + d0 + 8 * i, t);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) vs[8 * i + e] += w * t[e];
-                }
-            }
-        }
-        if (wave == 0) {
-            smp[0 * 64 + lane] = s.fx; smp[1 * 64 + lane] = s.fy; smp[2 * 64 + lane] = __int_as_float(s.x0); smp[3 * 64 + lane] = __int_as_float(s.y0);
-            smp[4 * 64 + lane] = s.rx; smp[5 * 64 + lane] = s.ry; smp[6 * 64 + lane] = s.cs; smp[7 * 64 + lane] = s.sn;
-            smp[8 * 64 + lane] = s.relx; smp[9 * 64 + lane] = s.rely;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<uint4*>(Ks + swz(lane, 2 * wave + i)) = pack_bf16x8(ks[8 * i], ks[8 * i + 1], ks[8 * i + 2], ks[8 * i + 3], ks[8 * i + 4], ks[8 * i + 5], ks[8 * i + 6], ks[8 * i + 7]);
-            *reinterpret_cast<uint4*>(Vs + swz(lane, 2 * wave + i)) = pack_bf16x8(vs[8 * i], vs[8 * i + 1], vs[8 * i + 2], vs[8 * i + 3], vs[8 * i + 4], vs[8 * i + 5], vs[8 * i + 6], vs[8 * i + 7]);
-        }
-#pragma unroll
-        for (int d = 0; d < 16; ++d) *reinterpret_cast<uint16_t*>(Kt + (d0 + d) * TP + lane * 2) = (uint16_t)f32_to_bf16_bits(ks[d]);
-    }
-    if (wave == 0) {   // ---- lane = query: delta = dO . O, lse
-        float dl = 0.f, ls = 0.f;
-        const int tok = lane < 49 ? query_token(g, lane, wi, wj) : -1;
-        const int tc = tok >= 0 ? tok : 0;
-#pragma unroll
-        for (int i = 0; i < HD / 8; ++i) {
-            float a[8], c[8];
-            load8(dob + (int64_t)tc * C + 8 * i, a);
-            load8(o + ((int64_t)b * N + tc) * C + h * HD + 8 * i, c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dl += a[e] * c[e];
-        }
-        dl = tok >= 0 ? dl : 0.f;
-        if (lane < 49) ls = lse[(int64_t)blockIdx.x * 49 + lane];
-        delta[lane] = dl;
-        lses[lane] = ls;
-    }
-    // ---- this wave's query tile: Q / dO fragments and QR = tables x Q^T
+    // ---- this wave's query tile: Q / dO fragments and QR = tables x Q^T  (first: these loads depend on nothing, so they are in
+    // flight while wave 0 computes the sample positions and all waves gather)
     const int qt = wave;
     const int nA = 16 * qt + fr;
     const int qtokA = nA < 49 ? query_token(g, nA, wi, wj) : -1;
@@ -244,7 +189,81 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         for (int rr = 0; rr < 4; ++rr)
             if (4 * gq + rr < 13) QR[(t * 13 + 4 * gq + rr) * 64 + nA] = acc[rr];
     }
+    // ---- sample positions: wave 0, lane = key
+    if (wave == 0) {
+        Sample s;
+        s.fx = 0.f; s.fy = 0.f; s.x0 = -100; s.y0 = -100; s.rx = 0.f; s.ry = 0.f; s.cs = 1.f; s.sn = 0.f; s.relx = 0.f; s.rely = 0.f;
+        if (lane < 49) s = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, lane / 7, lane % 7);
+        smp[0 * 64 + lane] = s.fx; smp[1 * 64 + lane] = s.fy; smp[2 * 64 + lane] = __int_as_float(s.x0); smp[3 * 64 + lane] = __int_as_float(s.y0);
+        smp[4 * 64 + lane] = s.rx; smp[5 * 64 + lane] = s.ry; smp[6 * 64 + lane] = s.cs; smp[7 * 64 + lane] = s.sn;
+        smp[8 * 64 + lane] = s.relx; smp[9 * 64 + lane] = s.rely;
+    }
     __syncthreads();
+    // ---- gather: lane = (key of a group of 8, 16-B chunk of the 64-channel row) -- one wave instruction reads 8 WHOLE 128-B rows --
+    // and delta = dO . O per query in the same lane arrangement.  ALL loads of the phase (2 key groups x 4 neighbours x {K, V} + 2 query
+    // groups x {dO, O}) are issued before the first one is used: the phase is a chain of HBM round trips (the qkv rows of a
+    // window are cold), and issued group by group they cost one latency each (phase timing, MTP_RVSA_STOP).
+    {
+        const int kl = lane >> 3, ch = lane & 7;
+        uint4 kq[2][4], vq[2][4], da[2], oc[2];
+        float wq[2][4];
+        int qtok[2];
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int key = (wave + 4 * gi) * 8 + kl;      // 8 groups = 64 key rows; keys >= 49 come out as zero rows
+            const float fx = smp[0 * 64 + key], fy = smp[1 * 64 + key];
+            const int x0 = __float_as_int(smp[2 * 64 + key]), y0 = __float_as_int(smp[3 * 64 + key]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float w;
+                const int tok = neighbour(g, x0, y0, fx, fy, k, w);      // (keys >= 49: x0 = -100 -> outside -> weight 0)
+                const int tc = tok >= 0 ? tok : 0;
+                wq[gi][k] = tok >= 0 ? w : 0.f;
+                kq[gi][k] = ldg16(base + C + (int64_t)tc * ld + 8 * ch);
+                vq[gi][k] = ldg16(base + 2 * C + (int64_t)tc * ld + 8 * ch);
+            }
+            const int n = (wave + 4 * gi) * 8 + kl;
+            qtok[gi] = n < 49 ? query_token(g, n, wi, wj) : -1;
+            const int tc = qtok[gi] >= 0 ? qtok[gi] : 0;
+            da[gi] = ldg16(dob + (int64_t)tc * C + 8 * ch);
+            oc[gi] = ldg16(o + ((int64_t)b * N + tc) * C + h * HD + 8 * ch);
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int key = (wave + 4 * gi) * 8 + kl;
+            float ks[8], vs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ks[e] = 0.f; vs[e] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t kw[4] = {kq[gi][k].x, kq[gi][k].y, kq[gi][k].z, kq[gi][k].w}, vw[4] = {vq[gi][k].x, vq[gi][k].y, vq[gi][k].z, vq[gi][k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ks[2 * e] += wq[gi][k] * bf16_bits_to_f32(kw[e] & 0xffffu); ks[2 * e + 1] += wq[gi][k] * bf16_bits_to_f32(kw[e] >> 16);
+                    vs[2 * e] += wq[gi][k] * bf16_bits_to_f32(vw[e] & 0xffffu); vs[2 * e + 1] += wq[gi][k] * bf16_bits_to_f32(vw[e] >> 16);
+                }
+            }
+            *reinterpret_cast<uint4*>(Ks + swz(key, ch)) = pack_bf16x8(ks[0], ks[1], ks[2], ks[3], ks[4], ks[5], ks[6], ks[7]);
+            *reinterpret_cast<uint4*>(Vs + swz(key, ch)) = pack_bf16x8(vs[0], vs[1], vs[2], vs[3], vs[4], vs[5], vs[6], vs[7]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *reinterpret_cast<uint16_t*>(Kt + (8 * ch + e) * TP + key * 2) = (uint16_t)f32_to_bf16_bits(ks[e]);
+            // delta = dO . O of query n = key index, lse
+            const uint32_t aw[4] = {da[gi].x, da[gi].y, da[gi].z, da[gi].w}, cw[4] = {oc[gi].x, oc[gi].y, oc[gi].z, oc[gi].w};
+            float dl = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dl += bf16_bits_to_f32(aw[e] & 0xffffu) * bf16_bits_to_f32(cw[e] & 0xffffu) + bf16_bits_to_f32(aw[e] >> 16) * bf16_bits_to_f32(cw[e] >> 16);
+            dl += __shfl_xor(dl, 1, 64);
+            dl += __shfl_xor(dl, 2, 64);
+            dl += __shfl_xor(dl, 4, 64);
+            if (ch == 0) {
+                delta[key] = qtok[gi] >= 0 ? dl : 0.f;
+                lses[key] = key < 49 ? lse[(int64_t)blockIdx.x * 49 + key] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    if (stop_after == 1) return;
 
     // ================= phase A: wave = query tile; lane (query; 4 keys) -> dQ, dQR, P^T / dS^T images ===============
     {
@@ -319,6 +338,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
             }
         }
         __syncthreads();   // dQR / P^T / dS^T complete
+        if (stop_after == 2) return;
         float e[8], f[8];
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
@@ -340,6 +360,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         }
     }
     __syncthreads();   // K^T no longer needed: R2 becomes Q^T | dO^T
+    if (stop_after == 3) return;
     {   // ---- thread = (query = lane, 16-channel quarter = wave)
         const int tok = lane < 49 ? query_token(g, lane, wi, wj) : -1;
 #pragma unroll
@@ -357,6 +378,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         }
     }
     __syncthreads();
+    if (stop_after == 4) return;
     {   // ---- table gradients: wave = d tile
         float* rp = rel_part + (int64_t)blockIdx.x * 26 * HD;
         const int dt = wave;
@@ -390,6 +412,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
             tab_part[((int64_t)bw * 169 + tid) * H + h] = acc / scale;   // (169, heads) as the parameter
         }
     }
+    if (stop_after == 5) return;
     // ================= phase B: wave = key tile; lane (key; 4 queries) -> dK_sel^T, dV_sel^T, scatter, coordinate gradients ==
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
     {
@@ -420,10 +443,18 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 dv2[dt] = mma(pfb[kk], dotf, dv2[dt]);
             }
         }
+        __syncthreads();   // every wave holds its P^T / dS^T fragments and is past its last read of Q^T | dO^T
+        // dK_sel / dV_sel rows (bf16, the [key][16-B chunk] image of K_sel / V_sel) over P^T | dS^T: the coordinate gradients
+        // below read them chunk-wise next to the neighbour rows
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int o = swz(16 * kt + fr, 2 * dt + (gq >> 1)) + 8 * (gq & 1);
+            *reinterpret_cast<uint2*>(Ks + o) = make_uint2(pack_bf16x2(dks[dt][0], dks[dt][1]), pack_bf16x2(dks[dt][2], dks[dt][3]));
+            *reinterpret_cast<uint2*>(Vs + o) = make_uint2(pack_bf16x2(dvs[dt][0], dvs[dt][1]), pack_bf16x2(dvs[dt][2], dvs[dt][3]));
+        }
         if (dense_scatter) {
-            // dK_sel^T / dV_sel^T -> bf16 [d][key] images over Q^T | dO^T (every wave is past its last read of them); the
-            // scatter itself runs after the coordinate gradients, see the end of the kernel
-            __syncthreads();
+            // dK_sel^T / dV_sel^T -> bf16 [d][key] images over Q^T | dO^T; the scatter itself runs after the coordinate
+            // gradients, see the end of the kernel
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int o = (16 * dt + fr) * TP + (16 * kt + 4 * gq) * 2;
@@ -451,38 +482,62 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 }
             }
         }
-        const float fx = smp[0 * 64 + kc], fy = smp[1 * 64 + kc];
-        const int x0 = __float_as_int(smp[2 * 64 + kc]), y0 = __float_as_int(smp[3 * 64 + kc]);
-        float dix = 0.f, diy = 0.f;
+    }
+    __syncthreads();   // dK_sel / dV_sel rows complete
+    if (stop_after == 6) return;
+    {   // ---- coordinate gradients: lane = (key of a group of 8, 16-B chunk): d(K_sel, V_sel)/d(ix, iy) needs the four neighbour rows
+        // (all neighbour loads of the wave's two key groups issued before the first use, as in the gather)
+        const int kl = lane >> 3, ch = lane & 7;
+        uint4 kq[2][4], vq[2][4];
+        bool live[2][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float w;
-            const int tok = key < 49 ? neighbour(g, x0, y0, fx, fy, k, w) : -1;
-            const int tc = tok >= 0 ? tok : 0;
-            const bf16_t* krow = base + C + (int64_t)tc * ld + 4 * gq;
-            const bf16_t* vrow = base + 2 * C + (int64_t)tc * ld + 4 * gq;
-            float dot = 0.f;
+        for (int gi = 0; gi < 2; ++gi) {
+            const int key = (wave + 4 * gi) * 8 + kl, kc = key < 48 ? key : 48;      // keys 0 .. 63 (49 real)
+            const float fx = smp[0 * 64 + kc], fy = smp[1 * 64 + kc];
+            const int x0 = __float_as_int(smp[2 * 64 + kc]), y0 = __float_as_int(smp[3 * 64 + kc]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const float4 kv = load4(krow + 16 * dt), vv = load4(vrow + 16 * dt);
-                dot += dks[dt][0] * kv.x + dks[dt][1] * kv.y + dks[dt][2] * kv.z + dks[dt][3] * kv.w
-                     + dvs[dt][0] * vv.x + dvs[dt][1] * vv.y + dvs[dt][2] * vv.z + dvs[dt][3] * vv.w;
+            for (int k = 0; k < 4; ++k) {
+                float w;
+                const int tok = key < 49 ? neighbour(g, x0, y0, fx, fy, k, w) : -1;
+                const int tc = tok >= 0 ? tok : 0;
+                live[gi][k] = tok >= 0;
+                kq[gi][k] = ldg16(base + C + (int64_t)tc * ld + 8 * ch);
+                vq[gi][k] = ldg16(base + 2 * C + (int64_t)tc * ld + 8 * ch);
             }
-            dot = tok >= 0 ? dot : 0.f;
-            dot += __shfl_xor(dot, 16, 64);
-            dot += __shfl_xor(dot, 32, 64);
-            const int dx = k & 1, dy = k >> 1;
-            dix += dot * (dy ? fy : 1.0f - fy) * (dx ? 1.0f : -1.0f);
-            diy += dot * (dx ? fx : 1.0f - fx) * (dy ? 1.0f : -1.0f);
         }
-        if (gq == 0 && key < 49) {
-            const float rx = smp[4 * 64 + kc], ry = smp[5 * 64 + kc], cs = smp[6 * 64 + kc], sn = smp[7 * 64 + kc];
-            const float dgx = dix * 0.5f * (float)(g.We - 1), dgy = diy * 0.5f * (float)(g.He - 1);
-            v0 = dgx * g.inv_div_x;
-            v1 = dgy * g.inv_div_y;
-            v2 = (dgx * cs + dgy * sn) * smp[8 * 64 + kc];
-            v3 = (-dgx * sn + dgy * cs) * smp[9 * 64 + kc];
-            v4 = dgx * (-rx * sn - ry * cs) + dgy * (-ry * sn + rx * cs);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int key = (wave + 4 * gi) * 8 + kl, kc = key < 48 ? key : 48;
+            const float fx = smp[0 * 64 + kc], fy = smp[1 * 64 + kc];
+            float dk[8], dv[8];
+            load8(reinterpret_cast<const bf16_t*>(Ks + swz(key, ch)), dk);
+            load8(reinterpret_cast<const bf16_t*>(Vs + swz(key, ch)), dv);
+            float dix = 0.f, diy = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t kw[4] = {kq[gi][k].x, kq[gi][k].y, kq[gi][k].z, kq[gi][k].w}, vw[4] = {vq[gi][k].x, vq[gi][k].y, vq[gi][k].z, vq[gi][k].w};
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dot += dk[2 * e] * bf16_bits_to_f32(kw[e] & 0xffffu) + dk[2 * e + 1] * bf16_bits_to_f32(kw[e] >> 16)
+                         + dv[2 * e] * bf16_bits_to_f32(vw[e] & 0xffffu) + dv[2 * e + 1] * bf16_bits_to_f32(vw[e] >> 16);
+                dot = live[gi][k] ? dot : 0.f;
+                dot += __shfl_xor(dot, 1, 64);
+                dot += __shfl_xor(dot, 2, 64);
+                dot += __shfl_xor(dot, 4, 64);
+                const int dx = k & 1, dy = k >> 1;
+                dix += dot * (dy ? fy : 1.0f - fy) * (dx ? 1.0f : -1.0f);
+                diy += dot * (dx ? fx : 1.0f - fx) * (dy ? 1.0f : -1.0f);
+            }
+            if (ch == 0 && key < 49) {
+                const float rx = smp[4 * 64 + kc], ry = smp[5 * 64 + kc], cs = smp[6 * 64 + kc], sn = smp[7 * 64 + kc];
+                const float dgx = dix * 0.5f * (float)(g.We - 1), dgy = diy * 0.5f * (float)(g.He - 1);
+                v0 += dgx * g.inv_div_x;
+                v1 += dgy * g.inv_div_y;
+                v2 += (dgx * cs + dgy * sn) * smp[8 * 64 + kc];
+                v3 += (-dgx * sn + dgy * cs) * smp[9 * 64 + kc];
+                v4 += dgx * (-rx * sn - ry * cs) + dgy * (-ry * sn + rx * cs);
+            }
         }
     }
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
@@ -584,7 +639,11 @@ int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, 
                              float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     const RvsaGeom g = make_geom(Hp, Wp, heads);
-    static const int dense = []() { const char* e = getenv("MTP_RVSA_SCATTER"); return (e && e[0] == 'c') ? 0 : (e && e[0] == 'n') ? 2 : 1; }();   // "corner": per-(key, corner) atomics (A/B); "none": ablation, no scatter at all
+    static const int dense = []() {
+        const char* e = getenv("MTP_RVSA_SCATTER");   // "corner": per-(key, corner) atomics (A/B); "none": ablation, no scatter at all
+        const char* st = getenv("MTP_RVSA_STOP");     // phase-timing ablation: return after phase 1..6
+        return ((e && e[0] == 'c') ? 0 : (e && e[0] == 'n') ? 2 : 1) | ((st ? atoi(st) : 0) << 4);
+    }();
     hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, dense);
     return mtp_launch_status();

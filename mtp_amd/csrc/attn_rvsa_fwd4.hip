@@ -29,8 +29,8 @@ __device__ __forceinline__ Sample make_sample(const RvsaGeom& g, const float* __
     s.rely = (float)(a - 3) * stepy;
     s.rx = s.relx * sx;
     s.ry = s.rely * sy;
-    s.cs = cosf(ang);
-    s.sn = sinf(ang);
+    s.cs = __cosf(ang);      // v_cos / v_sin (abs error ~1e-6 on |ang| < pi): shared with the backward kernel
+    s.sn = __sinf(ang);
     const float gx = cenx + (s.rx * s.cs - s.ry * s.sn) + offx;
     const float gy = ceny + (s.ry * s.cs + s.rx * s.sn) + offy;
     float ix = (gx + 1.0f) * 0.5f * (float)(g.We - 1), iy = (gy + 1.0f) * 0.5f * (float)(g.He - 1);
@@ -146,38 +146,7 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
     const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
 
     if (tid < 169) tab[tid] = bias_table[tid * H + h];
-    {   // ---- gather: thread = (key = lane, 16-channel quarter = wave)
-        const int d0 = 16 * wave;
-        float ks[16], vs[16];
-#pragma unroll
-        for (int d = 0; d < 16; ++d) { ks[d] = 0.f; vs[d] = 0.f; }
-        if (lane < 49) {
-            const Sample s = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, lane / 7, lane % 7);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float w;
-                const int tok = neighbour(g, s.x0, s.y0, s.fx, s.fy, k, w);
-                const int tc = tok >= 0 ? tok : 0;
-                w = tok >= 0 ? w : 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float t[8];
-                    load8(base + C + (int64_t)tc * ld + d0 + 8 * i, t);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ks[8 * i + e] += w * t[e];
-                    load8(base + 2 * C + (int64_t)tc * ld + d0 + 8 * i, t);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) vs[8 * i + e] += w * t[e];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<uint4*>(Ks + swz(lane, 2 * wave + i)) = pack_bf16x8(ks[8 * i], ks[8 * i + 1], ks[8 * i + 2], ks[8 * i + 3], ks[8 * i + 4], ks[8 * i + 5], ks[8 * i + 6], ks[8 * i + 7]);
-#pragma unroll
-        for (int d = 0; d < 16; ++d) *reinterpret_cast<uint16_t*>(Vt + (d0 + d) * TP + lane * 2) = (uint16_t)f32_to_bf16_bits(vs[d]);
-    }
-    // ---- this wave's query tile
+    // ---- this wave's query tile first: these loads depend on nothing, so they fly under the sample computation and the gather
     const int qt = wave;
     const int n = 16 * qt + fr;
     const int qtok = n < 49 ? query_token(g, n, wi, wj) : -1;
@@ -193,6 +162,46 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
             if (4 * gq + rr < 13) QR[(t * 13 + 4 * gq + rr) * 64 + n] = acc[rr];
+    }
+    {   // ---- gather: lane = (key of a group of 8, 16-B chunk of the 64-channel row): a wave instruction reads 8 WHOLE 128-B rows
+        // (with lane = key it touched 49 cache lines for 16 B each); all 16 loads of the wave's two key groups are issued before
+        // the first use.  Every lane computes the sample position of its own key (8 lanes share one: no barrier needed).
+        const int kl = lane >> 3, ch = lane & 7;
+        uint4 kq[2][4], vq[2][4];
+        float wq[2][4];
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int key = (wave + 4 * gi) * 8 + kl, kc = key < 48 ? key : 48;      // 8 groups = 64 key rows; keys >= 49 are zero rows
+            const Sample sm = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, kc / 7, kc % 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float w;
+                const int tok = key < 49 ? neighbour(g, sm.x0, sm.y0, sm.fx, sm.fy, k, w) : -1;
+                const int tc = tok >= 0 ? tok : 0;
+                wq[gi][k] = tok >= 0 ? w : 0.f;
+                kq[gi][k] = ldg16(base + C + (int64_t)tc * ld + 8 * ch);
+                vq[gi][k] = ldg16(base + 2 * C + (int64_t)tc * ld + 8 * ch);
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int key = (wave + 4 * gi) * 8 + kl;
+            float ks[8], vs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ks[e] = 0.f; vs[e] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t kw[4] = {kq[gi][k].x, kq[gi][k].y, kq[gi][k].z, kq[gi][k].w}, vw[4] = {vq[gi][k].x, vq[gi][k].y, vq[gi][k].z, vq[gi][k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ks[2 * e] += wq[gi][k] * bf16_bits_to_f32(kw[e] & 0xffffu); ks[2 * e + 1] += wq[gi][k] * bf16_bits_to_f32(kw[e] >> 16);
+                    vs[2 * e] += wq[gi][k] * bf16_bits_to_f32(vw[e] & 0xffffu); vs[2 * e + 1] += wq[gi][k] * bf16_bits_to_f32(vw[e] >> 16);
+                }
+            }
+            *reinterpret_cast<uint4*>(Ks + swz(key, ch)) = pack_bf16x8(ks[0], ks[1], ks[2], ks[3], ks[4], ks[5], ks[6], ks[7]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *reinterpret_cast<uint16_t*>(Vt + (8 * ch + e) * TP + key * 2) = (uint16_t)f32_to_bf16_bits(vs[e]);
+        }
     }
     __syncthreads();
     f32x4_t s[4];
