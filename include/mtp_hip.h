@@ -199,7 +199,8 @@ int mtp_rvsa_attn_fwd(const void* qkv, const float* samp, void* o, float* lse, i
 /* dqkv (T,3C) ACT: q part written directly; k/v parts are scattered through the bilinear weights with f32 atomics into
  * dkv_f32 (T, 2C) (zeroed by the callee) and then converted into dqkv by the callee.  dsamp (B*nh*nw, 5*heads) f32.
  * rel_part (B*nh*nw*heads, 26*hd) f32 = per-workgroup partials of [drel_h (13,hd) | drel_w (13,hd)];
- * tab_part (B*nh*nw, 169, heads) f32 = per-window partials of the bias-table gradient, laid out like the parameter. */
+ * tab_part (B*nh*nw, heads, 169) f32 = per-(window, head) partials of the bias-table gradient (the parameter is (169, heads):
+ * the caller sums over the windows and transposes). */
 int mtp_rvsa_attn_bwd(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse,
                       void* dqkv, float* dkv_f32, float* dsamp, float* rel_part, float* tab_part, int dtype,
                       const float* rel_h, const float* rel_w, const float* bias_table,

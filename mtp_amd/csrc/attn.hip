@@ -739,7 +739,7 @@ __global__ __launch_bounds__(64) void rvsa_attn_bwd_kernel(const T* __restrict__
             rp[r * HD + lane] = ah;
             rp[(13 + r) * HD + lane] = aw;
         }
-        for (int i = lane; i < 169; i += 64) tab_part[((int64_t)bw * 169 + i) * H + h] = dtab[i];   // (169, heads) as the parameter
+        for (int i = lane; i < 169; i += 64) tab_part[((int64_t)bw * H + h) * 169 + i] = dtab[i];   // (window, head, 169): contiguous per workgroup
     }
 
     // ---- phase K (lane = key): d(K_sel), d(V_sel), then scatter through the bilinear footprint + coordinate gradients

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
                     if (4 * gq + rr < 13) rp[(t * 13 + 4 * gq + rr) * HD + 16 * dt + fr] = acc[rr];
             }
         }
-        for (int i = lane; i < 169; i += 64) tab_part[((int64_t)bw * 169 + i) * H + h] = dtab[i];   // (169, heads) as the parameter
+        for (int i = lane; i < 169; i += 64) tab_part[((int64_t)bw * H + h) * 169 + i] = dtab[i];   // (window, head, 169): contiguous per workgroup
     }
     // ================= phase B: lane (key; 4 queries) -> dK_sel^T, dV_sel^T, scatter, coordinate gradients ================
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;

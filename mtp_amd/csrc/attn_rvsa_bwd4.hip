@@ -68,15 +68,21 @@ __device__ __forceinline__ uint4 ld8x2(const char* p0, const char* p1) {   // tw
 }
 // 8 f32 table values (row r, elements e0..e0+7) -> bf16 operand; zero when the row is out of range
 __device__ __forceinline__ uint4 table_frag(const float* __restrict__ tab, int r, int rows, int e0) {
-    if (r >= rows) return make_uint4(0, 0, 0, 0);
-    const float4 a = *reinterpret_cast<const float4*>(tab + r * HD + e0), b = *reinterpret_cast<const float4*>(tab + r * HD + e0 + 4);
-    return pack_bf16x8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+    // unconditional loads on a clamped row, masked afterwards: a branch around the loads makes hipcc wait for them inside it
+    const int rc = r < rows ? r : rows - 1;
+    const float m = r < rows ? 1.0f : 0.0f;
+    const float4 a = *reinterpret_cast<const float4*>(tab + rc * HD + e0), b = *reinterpret_cast<const float4*>(tab + rc * HD + e0 + 4);
+    return pack_bf16x8(m * a.x, m * a.y, m * a.z, m * a.w, m * b.x, m * b.y, m * b.z, m * b.w);
 }
 // transposed table operand: lane (d, g) -> tab[8g+e][d], e = 0..7
 __device__ __forceinline__ uint4 table_frag_t(const float* __restrict__ tab, int d, int rows, int r0) {
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (r0 + e) < rows ? tab[(r0 + e) * HD + d] : 0.f;
+    for (int e = 0; e < 8; ++e) {      // unconditional loads on clamped rows (see table_frag)
+        const int r = r0 + e;
+        const float t = tab[(r < rows ? r : rows - 1) * HD + d];
+        v[e] = r < rows ? t : 0.f;
+    }
     return pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 }
 
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     __shared__ float lses[64];
     __shared__ float delta[64];
     __shared__ __attribute__((aligned(16))) float smp[SMP_F * 64];
-    __shared__ float vsum[8];
+    __shared__ float vsum[4 * 8];
     char* Kt = R2;
     char* Qt = R2;
     char* dOt = R2 + 64 * TP;
@@ -166,10 +172,9 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     if (tid < 176) {
         tab[tid] = tid < 169 ? bias_table[tid * H + h] : 0.f;
     }
-    if (tid < 8) vsum[tid] = 0.f;
     for (int i = tid; i < 26 * 64; i += 256) dQR[i] = 0.f;
     // ---- this wave's query tile: Q / dO fragments and QR = tables x Q^T  (first: these loads depend on nothing, so they are in
-    // flight while wave 0 computes the sample positions and all waves gather)
+    // flight together with the gather's)
     const int qt = wave;
     const int nA = 16 * qt + fr;
     const int qtokA = nA < 49 ? query_token(g, nA, wi, wj) : -1;
@@ -179,30 +184,12 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         qf[ks] = row_frag(base, ld, qtokA, ks * 32 + gq * 8);
         dof[ks] = row_frag(dob, C, qtokA, ks * 32 + gq * 8);
     }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const float* tb = t ? rel_w : rel_h;
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mma(table_frag(tb, fr, 13, gq * 8), qf[0], acc);
-        acc = mma(table_frag(tb, fr, 13, 32 + gq * 8), qf[1], acc);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-            if (4 * gq + rr < 13) QR[(t * 13 + 4 * gq + rr) * 64 + nA] = acc[rr];
-    }
-    // ---- sample positions: wave 0, lane = key
-    if (wave == 0) {
-        Sample s;
-        s.fx = 0.f; s.fy = 0.f; s.x0 = -100; s.y0 = -100; s.rx = 0.f; s.ry = 0.f; s.cs = 1.f; s.sn = 0.f; s.relx = 0.f; s.rely = 0.f;
-        if (lane < 49) s = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, lane / 7, lane % 7);
-        smp[0 * 64 + lane] = s.fx; smp[1 * 64 + lane] = s.fy; smp[2 * 64 + lane] = __int_as_float(s.x0); smp[3 * 64 + lane] = __int_as_float(s.y0);
-        smp[4 * 64 + lane] = s.rx; smp[5 * 64 + lane] = s.ry; smp[6 * 64 + lane] = s.cs; smp[7 * 64 + lane] = s.sn;
-        smp[8 * 64 + lane] = s.relx; smp[9 * 64 + lane] = s.rely;
-    }
-    __syncthreads();
     // ---- gather: lane = (key of a group of 8, 16-B chunk of the 64-channel row) -- one wave instruction reads 8 WHOLE 128-B rows --
-    // and delta = dO . O per query in the same lane arrangement.  ALL loads of the phase (2 key groups x 4 neighbours x {K, V} + 2 query
-    // groups x {dO, O}) are issued before the first one is used: the phase is a chain of HBM round trips (the qkv rows of a
-    // window are cold), and issued group by group they cost one latency each (phase timing, MTP_RVSA_STOP).
+    // and delta = dO . O per query in the same lane arrangement.  Every lane computes the sample position of its own two keys (8
+    // lanes share one; no wave-0-only phase, no barrier before the gather) and the chunk-0 lanes publish it in `smp` for the later
+    // phases.  ALL loads of the phase (2 key groups x 4 neighbours x {K, V} + 2 query groups x {dO, O}) are issued before the
+    // first one is used: the phase is a chain of HBM round trips (the qkv rows of a window are cold), and issued group by group
+    // they cost one latency each (phase timing, MTP_RVSA_STOP).
     {
         const int kl = lane >> 3, ch = lane & 7;
         uint4 kq[2][4], vq[2][4], da[2], oc[2];
@@ -210,9 +197,16 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         int qtok[2];
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-            const int key = (wave + 4 * gi) * 8 + kl;      // 8 groups = 64 key rows; keys >= 49 come out as zero rows
-            const float fx = smp[0 * 64 + key], fy = smp[1 * 64 + key];
-            const int x0 = __float_as_int(smp[2 * 64 + key]), y0 = __float_as_int(smp[3 * 64 + key]);
+            const int key = (wave + 4 * gi) * 8 + kl, kc = key < 48 ? key : 48;      // 8 groups = 64 key rows; keys >= 49 are zero rows
+            Sample sm = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, kc / 7, kc % 7);   // (unconditional: no branch around its loads)
+            if (key >= 49) { sm.x0 = -100; sm.y0 = -100; sm.fx = 0.f; sm.fy = 0.f; }
+            if (ch == 0) {
+                smp[0 * 64 + key] = sm.fx; smp[1 * 64 + key] = sm.fy; smp[2 * 64 + key] = __int_as_float(sm.x0); smp[3 * 64 + key] = __int_as_float(sm.y0);
+                smp[4 * 64 + key] = sm.rx; smp[5 * 64 + key] = sm.ry; smp[6 * 64 + key] = sm.cs; smp[7 * 64 + key] = sm.sn;
+                smp[8 * 64 + key] = sm.relx; smp[9 * 64 + key] = sm.rely;
+            }
+            const float fx = sm.fx, fy = sm.fy;
+            const int x0 = sm.x0, y0 = sm.y0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float w;
@@ -227,6 +221,17 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
             const int tc = qtok[gi] >= 0 ? qtok[gi] : 0;
             da[gi] = ldg16(dob + (int64_t)tc * C + 8 * ch);
             oc[gi] = ldg16(o + ((int64_t)b * N + tc) * C + h * HD + 8 * ch);
+        }
+        // QR = tables x Q^T of this wave's query tile, while the gather's loads are in flight
+    #pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* tb = t ? rel_w : rel_h;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = mma(table_frag(tb, fr, 13, gq * 8), qf[0], acc);
+            acc = mma(table_frag(tb, fr, 13, 32 + gq * 8), qf[1], acc);
+    #pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (4 * gq + rr < 13) QR[(t * 13 + 4 * gq + rr) * 64 + nA] = acc[rr];
         }
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
@@ -409,7 +414,8 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 const float v = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(Vs + key * 128 + ((nn * 2) ^ ((key & 7) << 4))));
                 acc += ok ? v : 0.f;
             }
-            tab_part[((int64_t)bw * 169 + tid) * H + h] = acc / scale;   // (169, heads) as the parameter
+            tab_part[((int64_t)bw * H + h) * 169 + tid] = acc / scale;   // (window, head, 169): 676 contiguous bytes per workgroup
+                                                                       // (laid out like the parameter, (169, heads), it was 169 four-byte stores 64 B apart)
         }
     }
     if (stop_after == 5) return;
@@ -541,13 +547,15 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         }
     }
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
-    if (lane == 0) {
-        atomicAdd(&vsum[0], v0); atomicAdd(&vsum[1], v1); atomicAdd(&vsum[2], v2); atomicAdd(&vsum[3], v3); atomicAdd(&vsum[4], v4);
+    if (lane == 0) {   // per-wave partials, summed in a fixed order: LDS atomics here made dsamp differ by an ulp from run to run,
+                       // and downstream bf16 roundings turned that into 1e-4 gradient differences (tools/race_finder.py)
+        vsum[8 * wave + 0] = v0; vsum[8 * wave + 1] = v1; vsum[8 * wave + 2] = v2; vsum[8 * wave + 3] = v3; vsum[8 * wave + 4] = v4;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 5) {
         float* dp = dsamp + (int64_t)bw * 5 * H;
-        dp[2 * h] = vsum[0]; dp[2 * h + 1] = vsum[1]; dp[2 * H + 2 * h] = vsum[2]; dp[2 * H + 2 * h + 1] = vsum[3]; dp[4 * H + h] = vsum[4];
+        const float sum = (vsum[tid] + vsum[8 + tid]) + (vsum[16 + tid] + vsum[24 + tid]);
+        dp[tid < 2 ? 2 * h + tid : tid < 4 ? 2 * H + 2 * h + (tid - 2) : 4 * H + h] = sum;
     }
     if (dense_scatter) {
         // ================= scatter of dK_sel / dV_sel through the bilinear weights, as a product on the matrix cores =========
@@ -555,6 +563,8 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         // corner weights, summed per TOKEN before they leave the workgroup.  The memory side retires ~31 G 64-byte f32 atomics/s
         // (measured) and the per-(key, corner) scatter issued 49 x 4 x 8 of them per workgroup: it was the
         // kernel's floor.  Neighbouring keys share corners, so per token it is ~81 x 8 for near-identity sampling.
+        // (Tried in round 2: packed-bf16 atomics, global_atomic_pk_add_bf16, straight into dqkv -- half the requests, no f32 scratch, no
+        //  conversion pass -- measured SLOWER end to end: 287 vs 276 us per call.)
         // wave = token tiles w, w+4, ... of 16 tokens inside the row range the samples can touch.
         const char* dKt = R2;
         const char* dVt = R2 + 64 * TP;
@@ -644,6 +654,8 @@ int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, 
         const char* st = getenv("MTP_RVSA_STOP");     // phase-timing ablation: return after phase 1..6
         return ((e && e[0] == 'c') ? 0 : (e && e[0] == 'n') ? 2 : 1) | ((st ? atoi(st) : 0) << 4);
     }();
+
+
     hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, dense);
     return mtp_launch_status();

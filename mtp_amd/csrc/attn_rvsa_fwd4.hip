@@ -66,15 +66,21 @@ __device__ __forceinline__ uint4 ld8x2(const char* p0, const char* p1) {   // tw
 }
 // 8 f32 table values (row r, elements e0..e0+7) -> bf16 operand; zero when the row is out of range
 __device__ __forceinline__ uint4 table_frag(const float* __restrict__ tab, int r, int rows, int e0) {
-    if (r >= rows) return make_uint4(0, 0, 0, 0);
-    const float4 a = *reinterpret_cast<const float4*>(tab + r * HD + e0), b = *reinterpret_cast<const float4*>(tab + r * HD + e0 + 4);
-    return pack_bf16x8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+    // unconditional loads on a clamped row, masked afterwards: a branch around the loads makes hipcc wait for them inside it
+    const int rc = r < rows ? r : rows - 1;
+    const float m = r < rows ? 1.0f : 0.0f;
+    const float4 a = *reinterpret_cast<const float4*>(tab + rc * HD + e0), b = *reinterpret_cast<const float4*>(tab + rc * HD + e0 + 4);
+    return pack_bf16x8(m * a.x, m * a.y, m * a.z, m * a.w, m * b.x, m * b.y, m * b.z, m * b.w);
 }
 // transposed table operand: lane (d, g) -> tab[8g+e][d], e = 0..7
 __device__ __forceinline__ uint4 table_frag_t(const float* __restrict__ tab, int d, int rows, int r0) {
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (r0 + e) < rows ? tab[(r0 + e) * HD + d] : 0.f;
+    for (int e = 0; e < 8; ++e) {      // unconditional loads on clamped rows (see table_frag)
+        const int r = r0 + e;
+        const float t = tab[(r < rows ? r : rows - 1) * HD + d];
+        v[e] = r < rows ? t : 0.f;
+    }
     return pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 }
 
@@ -153,16 +159,6 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
     uint4 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = row_frag(base, ld, qtok, ks * 32 + gq * 8);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const float* tb = t ? rel_w : rel_h;
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mma(table_frag(tb, fr, 13, gq * 8), qf[0], acc);
-        acc = mma(table_frag(tb, fr, 13, 32 + gq * 8), qf[1], acc);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-            if (4 * gq + rr < 13) QR[(t * 13 + 4 * gq + rr) * 64 + n] = acc[rr];
-    }
     {   // ---- gather: lane = (key of a group of 8, 16-B chunk of the 64-channel row): a wave instruction reads 8 WHOLE 128-B rows
         // (with lane = key it touched 49 cache lines for 16 B each); all 16 loads of the wave's two key groups are issued before
         // the first use.  Every lane computes the sample position of its own key (8 lanes share one: no barrier needed).
@@ -182,6 +178,17 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
                 kq[gi][k] = ldg16(base + C + (int64_t)tc * ld + 8 * ch);
                 vq[gi][k] = ldg16(base + 2 * C + (int64_t)tc * ld + 8 * ch);
             }
+        }
+        // QR = tables x Q^T of this wave's query tile, while the gather's loads are in flight
+    #pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* tb = t ? rel_w : rel_h;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = mma(table_frag(tb, fr, 13, gq * 8), qf[0], acc);
+            acc = mma(table_frag(tb, fr, 13, 32 + gq * 8), qf[1], acc);
+    #pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (4 * gq + rr < 13) QR[(t * 13 + 4 * gq + rr) * 64 + n] = acc[rr];
         }
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {

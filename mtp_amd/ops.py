@@ -454,11 +454,15 @@ def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, dre
     dev = qkv.device
     dkv = torch.empty(T, 2 * Cc, device=dev, dtype=torch.float32)
     rel_part = torch.empty(nblk, 26 * hd, device=dev, dtype=torch.float32)
-    tab_part = torch.empty(B * nh * nw, heads * 169, device=dev, dtype=torch.float32)
+    tab_part = torch.empty(B * nh * nw, heads * 169, device=dev, dtype=torch.float32)     # (window, head, 169): contiguous per workgroup
     check(lib().mtp_rvsa_attn_bwd(_p(qkv), _f32(samp), _p(o), _p(dout), _f32(lse), _p(dqkv), _p(dkv), _f32(dsamp), _p(rel_part), _p(tab_part),
                                   _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table), B, Hp, Wp, heads, hd, scale, _s()), "mtp_rvsa_attn_bwd")
     _reduce_pair(rel_part, 13 * hd, drel_h, drel_w, accumulate)   # per-workgroup partials -> the parameters, no staging copies
-    reduce_rows(tab_part, dtable, accumulate)
+    tsum = reduce_rows(tab_part, torch.empty(heads * 169, device=dev, dtype=torch.float32))   # sum over the windows -> (heads, 169)
+    if accumulate:
+        dtable.add_(tsum.view(heads, 169).t())       # the parameter is (169, heads)
+    else:
+        dtable.copy_(tsum.view(heads, 169).t())
     return dqkv
 
 
