@@ -862,7 +862,9 @@ extern "C" int mtp_full_attn_bwd(const void* qkv, const void* o, const void* dou
     if (!qkv || !o || !dout || !lse || !dqkv || !rel_h || !rel_w || !drel_part || B <= 0 || heads <= 0) return MTP_ERR_ARG;
     if (hd != HD) return MTP_ERR_UNSUPPORTED;
     if (dtype == MTP_BF16 && mtp_use_mfma_attn()) {
-        const int rc = mtp_full_bwd_mfma_launch(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_part, B, Hp, Wp, heads, scale, (hipStream_t)stream);
+        int rc = mtp_full_bwd_mfma_launch(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_part, B, Hp, Wp, heads, scale, (hipStream_t)stream);
+        if (rc != MTP_ERR_UNSUPPORTED) return rc;
+        rc = mtp_full_bwd_flash_launch(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_part, workspace, B, Hp, Wp, heads, scale, (hipStream_t)stream);
         if (rc != MTP_ERR_UNSUPPORTED) return rc;
     }
     const int N = (int)(Hp * Wp);

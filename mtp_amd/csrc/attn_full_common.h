@@ -1,0 +1,61 @@
+// helpers shared by the full-attention MFMA kernels (attn_full_mfma.hip: <= 256 tokens and the flash forward;
+// attn_full_flash_bwd.hip: the flash backward beyond 256 tokens).  Internal linkage: every translation unit gets its own copy.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+
+__device__ __attribute__((aligned(16))) const uint4 g_zero16f = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint4 ld16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 ld8x2(const char* p0, const char* p1) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p0), b = *reinterpret_cast<const uint2*>(p1);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ uint4 row_frag(const bf16_t* __restrict__ rows, int64_t ld, int tok, bool ok, int e0) {
+    return ldg16(ok ? reinterpret_cast<const char*>(rows + (int64_t)tok * ld + e0) : reinterpret_cast<const char*>(&g_zero16f));
+}
+__device__ __forceinline__ uint4 table_frag(const float* __restrict__ tab, int r, int rows, int e0) {
+    if (r >= rows) return make_uint4(0, 0, 0, 0);
+    const float4 a = *reinterpret_cast<const float4*>(tab + r * HD + e0), b = *reinterpret_cast<const float4*>(tab + r * HD + e0 + 4);
+    return pack_bf16x8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+__device__ __forceinline__ uint4 table_frag_t(const float* __restrict__ tab, int d, int rows, int r0) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (r0 + e) < rows ? tab[(r0 + e) * HD + d] : 0.f;
+    return pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+
+struct FGeom {
+    int N, Hp, Wp, heads, NT, NP, NP2, KK, TPV, RH, RW;
+};
+
+// K (or any 64-wide row block of qkv) -> swizzled row-major LDS image, rows >= N zeroed, up to `rows` rows
+__device__ __forceinline__ void stage_rows_swz(const bf16_t* __restrict__ src, int64_t ld, int N, int rows, char* img, int tid) {
+    for (int idx = tid; idx < rows * 8; idx += 256) {
+        const int row = idx >> 3, c = idx & 7;
+        *reinterpret_cast<uint4*>(img + swz(row, c)) = row_frag(src, ld, row, row < N, 8 * c);
+    }
+}
+// 64-wide rows -> transposed image img[d][row] (pitch TPV bytes), columns >= N zeroed, up to `cols` columns
+__device__ __forceinline__ void stage_rows_t(const bf16_t* __restrict__ src, int64_t ld, int N, int cols, int TPV, char* img, int tid) {
+    for (int idx = tid; idx < cols * 8; idx += 256) {
+        const int row = idx >> 3, c = idx & 7;
+        const uint4 v = row_frag(src, ld, row, row < N, 8 * c);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<uint16_t*>(img + (8 * c + 2 * e) * TPV + row * 2) = (uint16_t)(w[e] & 0xffffu);
+            *reinterpret_cast<uint16_t*>(img + (8 * c + 2 * e + 1) * TPV + row * 2) = (uint16_t)(w[e] >> 16);
+        }
+    }
+}
+
+}  // namespace

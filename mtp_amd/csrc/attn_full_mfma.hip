@@ -8,62 +8,9 @@
 //   kernel A (lane: query, 4 keys)  : dQ^T = K^T.dS^T + Rh^T.dQRh + Rw^T.dQRw,  d(rel_pos_h/w) partials
 //   kernel B (lane: key, 4 queries) : dK^T = Q^T.dS,  dV^T = dO^T.P
 #include "attn_mfma.h"
-#include "common.h"
+#include "attn_full_common.h"
 
 namespace {
-
-constexpr int HD = 64;
-
-__device__ __attribute__((aligned(16))) const uint4 g_zero16f = {0u, 0u, 0u, 0u};
-
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-__device__ __forceinline__ f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ uint4 ld16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
-__device__ __forceinline__ uint4 ld8x2(const char* p0, const char* p1) {
-    const uint2 a = *reinterpret_cast<const uint2*>(p0), b = *reinterpret_cast<const uint2*>(p1);
-    return make_uint4(a.x, a.y, b.x, b.y);
-}
-__device__ __forceinline__ uint4 row_frag(const bf16_t* __restrict__ rows, int64_t ld, int tok, bool ok, int e0) {
-    return ldg16(ok ? reinterpret_cast<const char*>(rows + (int64_t)tok * ld + e0) : reinterpret_cast<const char*>(&g_zero16f));
-}
-__device__ __forceinline__ uint4 table_frag(const float* __restrict__ tab, int r, int rows, int e0) {
-    if (r >= rows) return make_uint4(0, 0, 0, 0);
-    const float4 a = *reinterpret_cast<const float4*>(tab + r * HD + e0), b = *reinterpret_cast<const float4*>(tab + r * HD + e0 + 4);
-    return pack_bf16x8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
-}
-__device__ __forceinline__ uint4 table_frag_t(const float* __restrict__ tab, int d, int rows, int r0) {
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (r0 + e) < rows ? tab[(r0 + e) * HD + d] : 0.f;
-    return pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-}
-
-struct FGeom {
-    int N, Hp, Wp, heads, NT, NP, NP2, KK, TPV, RH, RW;
-};
-
-// K (or any 64-wide row block of qkv) -> swizzled row-major LDS image, rows >= N zeroed, up to `rows` rows
-__device__ __forceinline__ void stage_rows_swz(const bf16_t* __restrict__ src, int64_t ld, int N, int rows, char* img, int tid) {
-    for (int idx = tid; idx < rows * 8; idx += 256) {
-        const int row = idx >> 3, c = idx & 7;
-        *reinterpret_cast<uint4*>(img + swz(row, c)) = row_frag(src, ld, row, row < N, 8 * c);
-    }
-}
-// 64-wide rows -> transposed image img[d][row] (pitch TPV bytes), columns >= N zeroed, up to `cols` columns
-__device__ __forceinline__ void stage_rows_t(const bf16_t* __restrict__ src, int64_t ld, int N, int cols, int TPV, char* img, int tid) {
-    for (int idx = tid; idx < cols * 8; idx += 256) {
-        const int row = idx >> 3, c = idx & 7;
-        const uint4 v = row_frag(src, ld, row, row < N, 8 * c);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            *reinterpret_cast<uint16_t*>(img + (8 * c + 2 * e) * TPV + row * 2) = (uint16_t)(w[e] & 0xffffu);
-            *reinterpret_cast<uint16_t*>(img + (8 * c + 2 * e + 1) * TPV + row * 2) = (uint16_t)(w[e] >> 16);
-        }
-    }
-}
 
 // ===================================================================================================================
 // forward.  dynamic LDS: Ks[16NT*128] | Vt[64*TPV] | QR[4 waves][64][16] f32 | kpos[NP2] u32
@@ -187,12 +134,14 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const bf16_t* __rest
 // ===================================================================================================================
 // forward beyond 256 tokens (448^2 pretraining inputs: 784): flash-style.  Workgroup = 64 queries of one (image, head)
 // (wave = one 16-query tile), loop over blocks of 256 keys with an online softmax; per block the same S^T = K.Q^T /
-// in-lane softmax / O^T = V^T.P^T scheme as above.  Table rows up to 64 per axis (Hp, Wp <= 32).
-// dynamic LDS: Ks[256*128] | Vt[64*FTPV] | QR[4 waves][128][16] f32 | kpos[256] u32
+// in-lane softmax / O^T = V^T.P^T scheme as above.  RT = 16-row tiles per table: 4 (Hp, Wp <= 32) or 8 (<= 64: the 1024^2
+// detection fine-tunes, 4096 tokens).
+// dynamic LDS: Ks[256*128] | Vt[64*FTPV] | QR[4 waves][32 RT][16] f32 | kpos[256] u32
 // ===================================================================================================================
 constexpr int FKB = 256;
 constexpr int FTPV = FKB * 2 + 8;
 
+template <int RT>
 __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                                  const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                                  int N, int Hp, int Wp, int heads, float scale) {
@@ -200,13 +149,13 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
     char* Ks = sm;
     char* Vt = Ks + FKB * 128;
     float* QRall = reinterpret_cast<float*>(Vt + 64 * FTPV);
-    uint32_t* kpos = reinterpret_cast<uint32_t*>(QRall + 4 * 128 * 16);
+    uint32_t* kpos = reinterpret_cast<uint32_t*>(QRall + 4 * 32 * RT * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, gq = lane >> 4;
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
     const int C = heads * HD, RH = 2 * Hp - 1, RW = 2 * Wp - 1;
     const int64_t ld = 3 * (int64_t)C;
     const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
-    float* QR = QRall + wave * 128 * 16;
+    float* QR = QRall + wave * 32 * RT * 16;
     const int n = 16 * (blockIdx.y * 4 + wave) + fr;
     const bool nv = n < N;
     const int nc = nv ? n : N - 1;
@@ -214,7 +163,7 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = row_frag(base, ld, nc, nv, ks * 32 + gq * 8);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {   // q.Rh / q.Rw for every table row: one MFMA tile row each, exchanged through LDS
+    for (int rt = 0; rt < RT; ++rt) {   // q.Rh / q.Rw for every table row: one MFMA tile row each, exchanged through LDS
         f32x4_t ah = {0.f, 0.f, 0.f, 0.f}, aw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -224,7 +173,7 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             QR[(16 * rt + 4 * gq + rr) * 16 + fr] = ah[rr];
-            QR[(64 + 16 * rt + 4 * gq + rr) * 16 + fr] = aw[rr];
+            QR[(16 * RT + 16 * rt + 4 * gq + rr) * 16 + fr] = aw[rr];
         }
     }
     const int hq = nc / Wp + Hp - 1, wq = nc % Wp + Wp - 1;
@@ -260,7 +209,7 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
             for (int r = 0; r < 4; ++r) {
                 const int kl = 16 * kt + 4 * gq + r;
                 const uint32_t kp = kpos[kl];
-                float v = scale * (s[kt][r] + QR[(hq - (int)(kp & 0xffu)) * 16 + fr] + QR[(64 + wq - (int)(kp >> 8)) * 16 + fr]);
+                float v = scale * (s[kt][r] + QR[(hq - (int)(kp & 0xffu)) * 16 + fr] + QR[(16 * RT + wq - (int)(kp >> 8)) * 16 + fr]);
                 v = kb0 + kl < N ? v : -INFINITY;
                 s[kt][r] = v;
                 bm = fmaxf(bm, v);
@@ -693,11 +642,17 @@ int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* 
     FGeom g;
     if (!make_fgeom(Hp, Wp, heads, g)) {
         const int64_t N = Hp * Wp;
-        if (N <= 256 || Hp > 32 || Wp > 32 || getenv("MTP_NO_FLASH_ATTN")) return MTP_ERR_UNSUPPORTED;
-        const size_t lds = (size_t)FKB * 128 + (size_t)64 * FTPV + 4 * 128 * 16 * 4 + FKB * 4;   // flash-style forward, 64 queries per workgroup
-        (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(full_fwd_flash_mfma_kernel, dim3((unsigned)(B * heads), (unsigned)((N + 63) / 64)), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse,
-                           rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
+        if (N <= 256 || Hp > 64 || Wp > 64 || getenv("MTP_NO_FLASH_ATTN")) return MTP_ERR_UNSUPPORTED;
+        const bool big = Hp > 32 || Wp > 32;          // tables of up to 127 rows: 8 row tiles each
+        const size_t lds = (size_t)FKB * 128 + (size_t)64 * FTPV + (size_t)4 * 32 * (big ? 8 : 4) * 16 * 4 + FKB * 4;   // flash-style forward, 64 queries per workgroup
+        const dim3 grid((unsigned)(B * heads), (unsigned)((N + 63) / 64));
+        if (big) {
+            (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(full_fwd_flash_mfma_kernel<8>, grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
+        } else {
+            (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(full_fwd_flash_mfma_kernel<4>, grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
+        }
         return mtp_launch_status();
     }
     const size_t lds = (size_t)g.NT * 16 * 128 + (size_t)64 * g.TPV + 4 * 64 * 16 * 4 + (size_t)g.NP2 * 4;

@@ -12,6 +12,9 @@ int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* 
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
 int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
                              float* drel_part, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
+// beyond 256 tokens (attn_full_flash_bwd.hip); workspace as mtp_full_attn_bwd_workspace_floats
+int mtp_full_bwd_flash_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
+                              float* drel_part, float* workspace, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
 
 // MTP_ATTN_VALU=1 forces the f32-VALU reference kernels also for bf16 I/O (A/B and debugging)
 static inline bool mtp_use_mfma_attn() {

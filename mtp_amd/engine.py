@@ -10,6 +10,8 @@ Data layout: tokens (T, C) row-major, T = B*Hp*Wp; residua
 everything consumed by a GEMM ("ACT": LN outputs, qkv, attention output, MLP hidden, and their gradients) in
 `act_dtype` (bf16 = throughput mode, f32 = parity mode); parameters / parameter gradients / LN statistics f32.
 """
+import os
+
 import torch
 
 from . import ops
@@ -110,6 +112,15 @@ class BackboneEngine:
         self._wimg = ops.WeightImages(entries, act)
 
     # ------------------------------------------------------------------ helpers
+    def _wgrad_stream(self):
+        """MTP_WGRAD_STREAM=1: grouped weight-gradient launches go to a side stream (ops.WgradQueue)"""
+        if os.environ.get("MTP_WGRAD_STREAM", "0") != "1":
+            return None
+        st = getattr(self, "_wstream", None)
+        if st is None or st.device != self.dev:
+            st = self._wstream = torch.cuda.Stream(device=self.dev)
+        return st
+
     def _e(self, *shape, dtype=None):
         return torch.empty(*shape, device=self.dev, dtype=dtype or self.act)
 
@@ -430,8 +441,9 @@ class BackboneEngine:
         dx = tapgrad[last]
         # ACT copy of the output gradient of the last block, scaled by its mlp drop-path factor
         dx_act = self._scaled_copy(dx, dps[last][1], N)
-        self._wq = wq = ops.WgradQueue()
+        self._wq = wq = ops.WgradQueue(stream=self._wgrad_stream())
         waiting = []     # blocks whose weight gradients are still queued: on_block_done fires once they have been launched
+        pending = None   # side-stream mode: the burst launched last (reported once the NEXT burst has been launched, after a wait)
         for i in range(last, -1, -1):
             s = saved[i]
             if ctx["ckpt"]:
@@ -443,9 +455,18 @@ class BackboneEngine:
             waiting.append(i)
             if i == 0 or wq.should_flush():
                 wq.flush()
-                if on_block_done is not None:
-                    on_block_done(waiting[-1])     # the lowest block of the burst: its group end covers the whole burst
+                if wq.stream is None:
+                    if on_block_done is not None:
+                        on_block_done(waiting[-1])     # the lowest block of the burst: its group end covers the whole burst
+                else:
+                    wq.wait(keep=1)
+                    if pending is not None and on_block_done is not None:
+                        on_block_done(pending)
+                    pending = waiting[-1]
                 waiting = []
+        wq.wait()
+        if pending is not None and on_block_done is not None:
+            on_block_done(pending)
         # ---- patch embed / pos embed
         ops.gemm_tn(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1), colsum=G["patch_embed.proj.bias"])
         if "pos_embed" in G:

@@ -472,6 +472,32 @@ def test_full_attention_fwd_bwd(ops, dtype, Hp, Wp):                            
     assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype]
 
 
+@pytest.mark.parametrize("Hp,Wp,B", [(64, 64, 1), (40, 25, 2), (33, 40, 1), (20, 50, 2), (40, 8, 2), (26, 10, 2)])
+def test_full_attention_flash_large_grids(ops, Hp, Wp, B):
+    """bf16 flash forward + flash MFMA backward (attn_full_flash_bwd.hip) beyond 256 tokens: 64 x 64 = the 1024^2 detection
+    fine-tunes (4096 tokens, 127-row tables), non-square grids whose key blocks start mid-row, Wp = 10 (the narrowest grid the
+    flash backward takes) and Wp = 8 (falls through to the three-pass f32-math kernels) -- vs the oracle's autograd"""
+    dtype = torch.bfloat16
+    heads, hd = 2, 64
+    C, N = heads * hd, Hp * Wp
+    T = B * N
+    qkv = _attn_inputs(T, C, dtype, seed=5)
+    rh, rw = 0.3 * rnd(2 * Hp - 1, hd, seed=1), 0.3 * rnd(2 * Wp - 1, hd, seed=2)
+    o, lse = e(T, C, dtype=dtype), e(B * heads * N)
+    ops.full_attn_fwd(dev(qkv, dtype), o, lse, dev(rh), dev(rw), B, Hp, Wp, heads, hd ** -0.5)
+    q = qkv.clone().requires_grad_(True)
+    rhr, rwr = rh.clone().requires_grad_(True), rw.clone().requires_grad_(True)
+    oref, lref = O.full_attn_fwd(q, B, Hp, Wp, heads, rhr, rwr)
+    assert rel_err(o.float().cpu(), oref) < TOL[dtype] and rel_err(lse.cpu().reshape(lref.shape), lref) < 5e-3
+    do = rnd(T, C, dtype=dtype, seed=3)
+    gq, gh, gw = torch.autograd.grad(oref, (q, rhr, rwr), do)
+    dqkv, drh, drw = e(T, 3 * C, dtype=dtype), e(*rh.shape), e(*rw.shape)
+    ops.full_attn_bwd(dev(qkv, dtype), o, dev(do, dtype), lse, dqkv, dev(rh), dev(rw), drh, drw, B, Hp, Wp, heads, hd ** -0.5)
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        assert rel_err(dqkv[:, sl].float().cpu(), gq[:, sl]) < TOL[dtype], name
+    assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Hp,Wp", [(14, 14), (16, 12)])
 def test_rvsa_pool_and_small_linear(ops, dtype, Hp, Wp):
