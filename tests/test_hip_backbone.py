@@ -448,3 +448,41 @@ def test_448_pretraining_resolution_forward_and_gradients_vs_oracle():
             assert q.grad is None, n
         else:
             assert rel_err(q.grad.cpu(), p[n].grad) < 5e-3, n
+
+
+@pytest.mark.parametrize("size", [448, 1024])
+def test_large_inputs_bf16_flash_attention_path_vs_oracle(size):
+    """bf16 mode at 448^2 (784 tokens per image: MTP's pretraining resolution) and 1024^2 (4096 tokens: the detection fine-tunes'
+    RVSA_MTP_branches(img_size=1024)): the full-attention blocks run the flash forward and the flash MFMA backward
+    (attn_full_flash_bwd.hip).  Relative L2 against the fp32 oracle; bounds as for the ViT-L bf16 run (the bf16 rounding of one
+    forward / backward: forward 2e-2, gradients 0.15, RVSA sampling heads 0.6), measured values go to the parity table."""
+    kw = dict(img_size=size, embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True, out_indices=[0, 1, 2, 3])
+    depth = 4
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(precision="bf16", feature_dtype=torch.float32, **kw)
+    sd = recipe.make_params({k: v.shape for k, v in net.state_dict().items() if v.dtype.is_floating_point}, seed=31)
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().train()
+    img = recipe.make_input(1, size, size, seed=9)
+    x = img.cuda().requires_grad_(True)
+    feats = net(x)
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in net.state_dict().items()}
+    xr = img.clone().requires_grad_(True)
+    ref = O.backbone_forward(xr, p, depth, 2, 2, kw["out_indices"])
+    ws = [recipe.loss_weights(f.shape, 700 + i) for i, f in enumerate(ref)]
+    group = "large_input_%d_bf16_vs_fp32_l2" % size
+    for i, (a, b) in enumerate(zip(feats, ref)):
+        v = _l2(a.detach().float().cpu().numpy(), b.detach().numpy())
+        record_parity(group, "f%d" % i, v)
+        assert v < 2e-2, (i, v)
+    sum((f * w.cuda()).sum() for f, w in zip(feats, ws)).backward()
+    sum((f * w).sum() for f, w in zip(ref, ws)).backward()
+    v = _l2(x.grad.cpu().numpy(), xr.grad.numpy())
+    record_parity(group, "dimg", v)
+    assert v < 0.15
+    for n, q in net.named_parameters():
+        if p[n].grad is None:
+            assert q.grad is None, n
+            continue
+        v = _l2(q.grad.cpu().numpy(), p[n].grad.numpy())
+        record_parity(group, n, v)
+        assert v < (0.6 if "sampling" in n else 0.15), (n, v)
