@@ -486,3 +486,16 @@ def test_large_inputs_bf16_flash_attention_path_vs_oracle(size):
         v = _l2(q.grad.cpu().numpy(), p[n].grad.numpy())
         record_parity(group, n, v)
         assert v < (0.6 if "sampling" in n else 0.15), (n, v)
+
+
+def test_window_partition_reverse_on_device_bit_exact(golden):
+    """VIT:113-140 (dead code in the reference's forward, kept in the module surface): the same view / permute on device tensors,
+    bit for bit against fixture f1, and partition -> reverse is the identity on a bf16 activation-sized tensor"""
+    from mtp_amd.backbone import window_partition, window_reverse
+    g = golden("f1_index.npz")
+    x = torch.from_numpy(g["wp_in"]).cuda()
+    w = window_partition(x, 7)
+    assert w.is_cuda and np.array_equal(w.cpu().numpy(), g["wp_out"])
+    assert np.array_equal(window_reverse(w, 7, 14, 21).cpu().numpy(), g["wr_out"])
+    a = torch.randn(4, 28, 28, 256, device="cuda").to(torch.bfloat16)
+    assert torch.equal(window_reverse(window_partition(a, 7), 7, 28, 28), a)
