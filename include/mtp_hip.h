@@ -171,6 +171,44 @@ int mtp_copy_segments_f32(const float* const* src, float* const* dst, const int6
 /* dst (rows, C) ACT = scale[row / rows_per_sample] * src (rows, C) f32   (scale may be NULL = plain cast) */
 int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, const float* scale, int64_t rows_per_sample, int64_t rows, int64_t C, mtp_stream_t stream);
 
+/* ---- InternImage layers around the DCNv3 core (csrc/conv.hip) ------------------------------------- */
+/* Conv2d(kernel 3, stride s, padding 1) as im2col + mtp_gemm_nt (StemLayer intern_image.py:239-276, DownsampleLayer :279-300):
+ * cols (N*Ho*Wo, Kp) ACT with column (kh*3 + kw)*Cin + c, zero for padding taps and for columns 9*Cin .. Kp (Kp: the caller's
+ * multiple of 8).  The source is addressed by ELEMENT strides (sN, sH, sW, sC): NCHW images and channels-last maps both fit. */
+int mtp_im2col3x3(const void* x, int x_dtype, int64_t sN, int64_t sH, int64_t sW, int64_t sC, void* cols, int cols_dtype,
+                  int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t stride, int64_t Kp, mtp_stream_t stream);
+/* dx (f32, element strides) = / += the transposed gather of dcols (N*Ho*Wo, Kp) */
+int mtp_col2im3x3(const void* dcols, int cols_dtype, float* dx, int64_t sN, int64_t sH, int64_t sW, int64_t sC,
+                  int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t stride, int64_t Kp, int accumulate, mtp_stream_t stream);
+/* (Cout, Cin, 3, 3) f32 weight -> w2 (Cout, Kp) and / or w2t (Kp, Cout) in the im2col column order; and the gradient back */
+int mtp_conv3x3_pack(const float* w, void* w2, void* w2t, int dtype, int64_t Cout, int64_t Cin, int64_t Kp, mtp_stream_t stream);
+int mtp_conv3x3_unpack_grad(const float* dw2, float* dw, int64_t Cout, int64_t Cin, int64_t Kp, mtp_stream_t stream);
+/* Linear weight (R, C) f32 -> wp (Rp, C) and / or wpt (C, Rp), zero rows / columns R .. Rp (mask head: 9 * groups rows) */
+int mtp_pack_rows_padded(const float* w, void* wp, void* wpt, int dtype, int64_t R, int64_t C, int64_t Rp, mtp_stream_t stream);
+/* dst (rows, ld) ACT: dst[r][c] = c < n ? src[r][c] : 0 -- an f32 gradient as the zero-padded contraction operand of a GEMM */
+int mtp_cast_pad_rows(const float* src, int64_t n, void* dst, int dst_dtype, int64_t ld, int64_t rows, mtp_stream_t stream);
+/* dst[r][0..n) = src[r][0..n) with separate row pitches (elements): compacts a GEMM output written with a padded pitch */
+int mtp_copy_rows(const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int dtype, int64_t n, int64_t rows, mtp_stream_t stream);
+/* depth-wise Conv2d(C, C, 3, 1, 1, groups=C) of DCNv3 (ops_dcnv3/modules/dcnv3.py:262-272), channels-last (N,H,W,C) ACT;
+ * w (C,1,3,3) f32, bias (C) f32.  bwd_dx: f32 output (= / +=).  bwd_dw: per-block partials (partial_rows, 10 C) f32 of
+ * [dweight (C, 9) | dbias (C)], to be summed by mtp_reduce_rows_f32. */
+int mtp_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int dtype, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream);
+int mtp_dwconv3x3_bwd_dx(const void* dy, int dtype, const float* w, float* dx, int accumulate, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream);
+int64_t mtp_dwconv3x3_bwd_dw_partial_rows(int64_t N, int64_t H, int64_t W);
+int mtp_dwconv3x3_bwd_dw(const void* dy, const void* x, int dtype, float* part, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream);
+/* softmax over the P <= 32 sampling points of each of G groups (dcnv3.py:341-342): logits (rows, ld >= G*P) -> prob (rows, G*P).
+ * bwd: dprob (rows, G*P) f32 -> dlogits (rows, ld) ACT, columns G*P .. ld zeroed. */
+int mtp_softmax_groups_fwd(const void* logits, int64_t ld, void* prob, int dtype, int64_t rows, int64_t G, int64_t P, mtp_stream_t stream);
+int mtp_softmax_groups_bwd(const void* prob, const float* dprob, void* dlogits, int64_t ld, int dtype, int64_t rows, int64_t G, int64_t P, mtp_stream_t stream);
+/* layer scale + drop path + residual (intern_image.py:424-426): out (rows, C) f32 = x + sample_scale[row / rows_per_sample] *
+ * gamma * z (z ACT; sample_scale may be NULL), out_act = the same in ACT (may be NULL).
+ * bwd: dz (ACT) = sample_scale * gamma * dout; part (partial_rows, C) f32 = per-block partials of dgamma. */
+int mtp_scale_residual_fwd(const float* x, const void* z, int dtype, const float* gamma, const float* sample_scale, int64_t rows_per_sample,
+                           float* out, void* out_act, int64_t rows, int64_t C, mtp_stream_t stream);
+int64_t mtp_scale_residual_bwd_partial_rows(int64_t rows);
+int mtp_scale_residual_bwd(const float* dout, const void* z, int dtype, const float* gamma, const float* sample_scale, int64_t rows_per_sample,
+                           void* dz, float* part, int64_t rows, int64_t C, mtp_stream_t stream);
+
 /* ---- attention --------------------------------------------------------------------------------------------- */
 /* Attention.forward core (VIT:97-108 + calc_rel_pos_spatial VIT:142-193): qkv (T,3C) ACT [q|k|v][head][hd] ->
  * o (T,C) ACT; lse (B, heads, N) f32.  logits = s*q.k + s*q.Rh[hq-hk+Hp-1] + s*q.Rw[wq-wk+Wp-1]. */

@@ -67,6 +67,22 @@ SIGNATURES = {
     "mtp_maxpool2_tokens_bwd": (i32, [p, p, i32, p, i32, i64, i64, i64, i64, p]),
     "mtp_axpy_f32": (i32, [p, p, f32, i64, p]),
     "mtp_scale_rows_cast": (i32, [p, p, i32, p, i64, i64, i64, p]),
+    "mtp_im2col3x3": (i32, [p, i32, i64, i64, i64, i64, p, i32, i64, i64, i64, i64, i64, i64, p]),
+    "mtp_col2im3x3": (i32, [p, i32, p, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, i32, p]),
+    "mtp_conv3x3_pack": (i32, [p, p, p, i32, i64, i64, i64, p]),
+    "mtp_conv3x3_unpack_grad": (i32, [p, p, i64, i64, i64, p]),
+    "mtp_pack_rows_padded": (i32, [p, p, p, i32, i64, i64, i64, p]),
+    "mtp_cast_pad_rows": (i32, [p, i64, p, i32, i64, i64, p]),
+    "mtp_copy_rows": (i32, [p, i64, p, i64, i32, i64, i64, p]),
+    "mtp_dwconv3x3_fwd": (i32, [p, p, p, p, i32, i64, i64, i64, i64, p]),
+    "mtp_dwconv3x3_bwd_dx": (i32, [p, i32, p, p, i32, i64, i64, i64, i64, p]),
+    "mtp_dwconv3x3_bwd_dw_partial_rows": (i64, [i64, i64, i64]),
+    "mtp_dwconv3x3_bwd_dw": (i32, [p, p, i32, p, i64, i64, i64, i64, p]),
+    "mtp_softmax_groups_fwd": (i32, [p, i64, p, i32, i64, i64, i64, p]),
+    "mtp_softmax_groups_bwd": (i32, [p, p, p, i64, i32, i64, i64, i64, p]),
+    "mtp_scale_residual_fwd": (i32, [p, p, i32, p, p, i64, p, p, i64, i64, p]),
+    "mtp_scale_residual_bwd_partial_rows": (i64, [i64]),
+    "mtp_scale_residual_bwd": (i32, [p, p, i32, p, p, i64, p, p, i64, i64, p]),
     "mtp_full_attn_fwd": (i32, [p, p, p, i32, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_full_attn_bwd_workspace_floats": (i64, [i64, i64, i64, i64]),
     "mtp_full_attn_bwd": (i32, [p, p, p, p, p, i32, p, p, p, p, i64, i64, i64, i64, i64, f32, p]),

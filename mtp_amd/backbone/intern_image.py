@@ -1,0 +1,226 @@
+"""InternImage backbone on the MI355X HIP operators behind the reference's class surface (BASELINE config 5).
+
+Mirrors Multi-Task_Pretrain/backbone/intern_image.py ("II"):
+  * class `InternImage(nn.Module)` with the constructor keywords of II:552-574, `forward(x)` -> list of NCHW maps taken before
+    each level's downsample (II:690-698), attributes `num_levels`, `depths`, `channels`, `num_features`, `out_indices`,
+    `out_channels`, `num_layers`, and `init_weights(pretrained)` with the reference's prefix-stripping rules (II:639-670);
+  * state-dict keys, shapes and order identical to the reference (`levels.0.blocks.0.dcn.dw_conv.1.1.weight`, ...), pinned by
+    fixture f12 (tests/test_hip_internimage.py);
+  * initialisation rules of II:672-686 + DCNv3._reset_parameters (ops_dcnv3/modules/dcnv3.py:308-316): Linear trunc_normal(.02)
+    / zero bias, LayerNorm 1 / 0, offset and mask heads zero, input / output projections xavier-uniform, layer scale
+    `layer_scale * ones`, convolutions with nn.Conv2d's default init.
+The configuration family MTP uses (models.py:92-104: norm 'LN', act 'GELU', layer_scale set, post_norm=True) is what the engine
+schedules; the InternImage-H/G options (dw_kernel_size, level2_post_norm, res_post_norm, center_feature_scale), pre-norm and
+`layer_scale=None` raise NotImplementedError instead of silently running something else.  `with_cp` (activation checkpointing)
+is accepted and ignored: it changes memory, not results.
+All compute runs in libmtp_hip.so (mtp_amd/engine_intern.py); there is no CPU / eager fallback.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ..registry import BACKBONES, MODELS
+
+
+def _trunc_normal_(t, std):
+    return nn.init.trunc_normal_(t, std=std, a=-2.0, b=2.0)      # timm's default cut-offs (II:14)
+
+
+class _Holder(nn.Module):
+    """parameter container node: the module tree only exists to reproduce the reference's state-dict names"""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("mtp_amd.InternImage sub-modules are parameter holders: call the backbone (the HIP engine schedules the kernels)")
+
+
+def _put(root, dotted, tensor):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Holder())
+        node = node._modules[p]
+    node.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+class _InternFn(torch.autograd.Function):
+    """One autograd node for the whole backbone: forward / backward are the engine's explicit kernel schedules."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng = module._engine()
+        need = any(ctx.needs_input_grad)
+        feats, ectx = eng.forward(x, training=module.training, need_grad=need, feature_dtype=module._feature_dtype())
+        ctx.module, ctx.ectx, ctx.x_grad = module, ectx, x.requires_grad
+        ctx.names = [n for n, _ in module.named_parameters()]
+        return tuple(feats)
+
+    @staticmethod
+    def backward(ctx, *dfeats):
+        if ctx.ectx is None:
+            raise RuntimeError("backward through a forward that ran without saved activations")
+        module = ctx.module
+        P = dict(module.named_parameters())
+        G = {n: torch.zeros_like(P[n], dtype=torch.float32) for n in ctx.names}
+        dimg = module._engine().backward(ctx.ectx, list(dfeats), G, need_input_grad=ctx.x_grad)
+        ctx.ectx = None
+        return (None, dimg) + tuple(G[n] for n in ctx.names)
+
+
+class InternImage(nn.Module):
+    def __init__(self, core_op="DCNv3", channels=64, depths=[3, 4, 18, 5], groups=[3, 6, 12, 24], mlp_ratio=4., drop_rate=0.,
+                 drop_path_rate=0.2, drop_path_type="linear", act_layer="GELU", norm_layer="LN", layer_scale=None, offset_scale=1.0,
+                 post_norm=False, with_cp=False, dw_kernel_size=None, level2_post_norm=False, level2_post_norm_block_ids=None,
+                 res_post_norm=False, center_feature_scale=False, out_indices=(0, 1, 2, 3), init_cfg=None,
+                 precision="bf16", feature_dtype=None):
+        super().__init__()
+        if core_op not in ("DCNv3", "DCNv3_pytorch"):
+            raise NotImplementedError("core_op %r" % (core_op,))
+        unsupported = dict(dw_kernel_size=dw_kernel_size, level2_post_norm=level2_post_norm, res_post_norm=res_post_norm,
+                           center_feature_scale=center_feature_scale)
+        for k, v in unsupported.items():
+            if v:
+                raise NotImplementedError("InternImage-H/G option %s is not built on the HIP path" % k)
+        if act_layer != "GELU" or norm_layer != "LN" or drop_rate != 0.0:
+            raise NotImplementedError("the HIP path schedules act_layer='GELU', norm_layer='LN', drop_rate=0 (what MTP uses, models.py:92-104)")
+        if not post_norm or layer_scale is None:
+            raise NotImplementedError("the HIP path schedules the layer_scale + post_norm branch (II:424-426) that InternImage-XL / MTP use")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.core_op = core_op
+        self.num_levels = len(depths)
+        self.depths = list(depths)
+        self.groups = list(groups)
+        self.channels = channels
+        self.num_features = int(channels * 2 ** (self.num_levels - 1))
+        self.post_norm = post_norm
+        self.mlp_ratio = mlp_ratio
+        self.init_cfg = init_cfg
+        self.out_indices = tuple(out_indices)
+        self.level2_post_norm_block_ids = level2_post_norm_block_ids
+        self.offset_scale = float(offset_scale)
+        self.layer_scale = float(layer_scale)
+        self.kernel_size = 3
+        self.with_cp = with_cp
+        self.precision = precision
+        self.feature_dtype = feature_dtype
+        for i, (c, g) in enumerate(zip([channels * 2 ** i for i in range(self.num_levels)], groups)):
+            if c % g or (c // g) % 4:
+                raise ValueError("level %d: channels %d must split into groups of a multiple of 4 channels (got %d groups)" % (i, c, g))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]        # II:602-607
+        if drop_path_type == "uniform":
+            dpr = [drop_path_rate] * len(dpr)
+        self.drop_path_rates = dpr
+        self._build_parameters()
+        self.num_layers = len(depths)
+        self.out_channels = [192, 384, 768, 1536]      # (II:637: hard-coded in the reference whatever `channels` is)
+        self._eng = None
+
+    # ------------------------------------------------------------------ parameters (reference names / shapes / order / init)
+    def _build_parameters(self):
+        ch, P = self.channels, self.kernel_size ** 2
+
+        def conv(cout, cin, k, groups=1, bias=True):
+            w = torch.empty(cout, cin // groups, k, k)
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+            b = None
+            if bias:
+                bound = 1.0 / math.sqrt((cin // groups) * k * k)
+                b = torch.empty(cout).uniform_(-bound, bound)
+            return w, b
+
+        def linear(r, c, kind):
+            w = torch.empty(r, c)
+            if kind == "zero":
+                w.zero_()
+            elif kind == "xavier":
+                nn.init.xavier_uniform_(w)
+            else:
+                _trunc_normal_(w, 0.02)
+            return w, torch.zeros(r)
+
+        def ln(pre, c):
+            _put(self, pre + ".weight", torch.ones(c))
+            _put(self, pre + ".bias", torch.zeros(c))
+
+        c2 = ch // 2
+        w, b = conv(c2, 3, 3)
+        _put(self, "patch_embed.conv1.weight", w)
+        _put(self, "patch_embed.conv1.bias", b)
+        ln("patch_embed.norm1.1", c2)
+        w, b = conv(ch, c2, 3)
+        _put(self, "patch_embed.conv2.weight", w)
+        _put(self, "patch_embed.conv2.bias", b)
+        ln("patch_embed.norm2.1", ch)
+        for i, (depth, G) in enumerate(zip(self.depths, self.groups)):
+            C = ch * 2 ** i
+            hid = int(C * self.mlp_ratio)
+            for j in range(depth):
+                p = "levels.%d.blocks.%d." % (i, j)
+                _put(self, p + "gamma1", self.layer_scale * torch.ones(C))
+                _put(self, p + "gamma2", self.layer_scale * torch.ones(C))
+                ln(p + "norm1.0", C)
+                w, b = conv(C, C, 3, groups=C)
+                _put(self, p + "dcn.dw_conv.0.weight", w)
+                _put(self, p + "dcn.dw_conv.0.bias", b)
+                ln(p + "dcn.dw_conv.1.1", C)
+                for name, rows, kind in (("offset", G * P * 2, "zero"), ("mask", G * P, "zero"), ("input_proj", C, "xavier"), ("output_proj", C, "xavier")):
+                    w, b = linear(rows, C, kind)
+                    _put(self, p + "dcn.%s.weight" % name, w)
+                    _put(self, p + "dcn.%s.bias" % name, b)
+                ln(p + "norm2.0", C)
+                w, b = linear(hid, C, "trunc")
+                _put(self, p + "mlp.fc1.weight", w)
+                _put(self, p + "mlp.fc1.bias", b)
+                w, b = linear(C, hid, "trunc")
+                _put(self, p + "mlp.fc2.weight", w)
+                _put(self, p + "mlp.fc2.bias", b)
+            if i < self.num_levels - 1:
+                p = "levels.%d.downsample." % i
+                w, _ = conv(2 * C, C, 3, bias=False)
+                _put(self, p + "conv.weight", w)
+                ln(p + "norm.1", 2 * C)
+
+    def init_weights(self, pretrained):
+        """II:639-670: checkpoint dict -> 'state_dict' / 'model' / itself, strip 'backbone.' and 'module.' prefixes, non-strict load"""
+        ckpt = torch.load(pretrained, map_location="cpu")
+        sd = ckpt.get("state_dict", ckpt.get("model", ckpt)) if isinstance(ckpt, dict) else ckpt
+        out = OrderedDict((k[9:] if k.startswith("backbone.") else k, v) for k, v in sd.items())
+        if out and next(iter(out)).startswith("module."):
+            out = OrderedDict((k[7:], v) for k, v in out.items())
+        return self.load_state_dict(out, strict=False)
+
+    # ------------------------------------------------------------------ execution
+    def _engine(self):
+        from ..engine_intern import InternEngine
+        act = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        if self._eng is None or self._eng.act != act:
+            self._eng = InternEngine(self, act)
+        return self._eng
+
+    def _feature_dtype(self):
+        if self.feature_dtype is not None:
+            return self.feature_dtype
+        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+
+    def forward(self, x):
+        """II:690-698: (N, 3, H, W) -> [ (N, C_i, H / 2^(i+2), W / 2^(i+2)) for i in out_indices ]"""
+        if not x.is_cuda:
+            raise RuntimeError("mtp_amd.InternImage runs on an MI355X (gfx950) device only: there is no CPU / eager PyTorch fallback.  "
+                               "Move the module and the input to 'cuda'.")
+        params = [p for _, p in self.named_parameters()]
+        return list(_InternFn.apply(self, x, *params))
+
+
+MODELS.register_module(module=InternImage, force=True)
+BACKBONES.register_module(module=InternImage, force=True)
+
+
+def internimage_xl(**kw):
+    """the backbone MTP builds for --backbone internimage_xl (models.py:92-104)"""
+    cfg = dict(core_op="DCNv3", channels=192, depths=[5, 5, 24, 5], groups=[12, 24, 48, 96], mlp_ratio=4., drop_path_rate=0.2, norm_layer="LN",
+               layer_scale=1e-5, offset_scale=2.0, post_norm=True, with_cp=True, out_indices=(0, 1, 2, 3))
+    cfg.update(kw)
+    return InternImage(**cfg)

@@ -1,0 +1,473 @@
+// The layers around the DCNv3 core in InternImage (reference Multi-Task_Pretrain/backbone/intern_image.py "II",
+// ops_dcnv3/modules/dcnv3.py "DCNM"), channels-last, gfx950.  All HBM-bound element / gather kernels; the contractions
+// themselves (3x3 convolutions as im2col + GEMM, the Linear layers) run on the MFMA GEMMs of gemm*.hip.
+//   im2col3x3 / col2im3x3    StemLayer II:239-276 and DownsampleLayer II:279-300: Conv2d(k=3, s=2, p=1)
+//   conv3x3_pack / _unpack   (Cout, Cin, 3, 3) f32 master weight <-> the GEMM's [Cout][(kh, kw, c)] images
+//   dwconv3x3 fwd / dx / dw  the depth-wise 3x3 of DCNM:262-272
+//   softmax_groups           softmax over the P sampling points of each group, DCNM:341-342
+//   scale_residual           x + drop_path(gamma * z), II:424-426 (layer scale + post-norm branch)
+//   pack_rows_padded         Linear weights whose row count is not a multiple of 8 (mask head, 9 * 12 = 108 rows)
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return bf16_bits_to_f32(p->bits); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cols[(n, ho, wo)][(kh * 3 + kw) * Cin + c] = x[n][ho * s + kh - 1][wo * s + kw - 1][c] (0 outside, 0 for columns >= 9 Cin).
+// The source is addressed through element strides, so the NCHW f32 image (stem) and channels-last maps both fit.
+template <typename Tx, typename Tc>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const Tx* __restrict__ x, int64_t sN, int64_t sH, int64_t sW, int64_t sC, Tc* __restrict__ cols,
+                                                       int H, int W, int Cin, int Ho, int Wo, int stride, int Kp, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % Kp);
+    const int64_t pix = idx / Kp;
+    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho);
+    const int64_t n = pix / ((int64_t)Wo * Ho);
+    float v = 0.f;
+    if (k < 9 * Cin) {
+        const int tap = k / Cin, c = k - tap * Cin, kh = tap / 3, kw = tap - 3 * kh;
+        const int h = ho * stride + kh - 1, w = wo * stride + kw - 1;
+        if (h >= 0 && h < H && w >= 0 && w < W) v = ld1(x + n * sN + h * sH + w * sW + c * sC);
+    }
+    Elem<Tc>::store(cols + idx, v);
+}
+
+// dx[n][h][w][c] (+)= sum over the taps (kh, kw) whose output position (ho, wo) exists: dcols[(n, ho, wo)][(kh * 3 + kw) * Cin + c]
+template <typename Tc>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const Tc* __restrict__ dcols, float* __restrict__ dx, int64_t sN, int64_t sH, int64_t sW, int64_t sC,
+                                                       int H, int W, int Cin, int Ho, int Wo, int stride, int Kp, int accumulate, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % Cin);
+    const int64_t pix = idx / Cin;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H);
+    const int64_t n = pix / ((int64_t)W * H);
+    float s = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hn = h + 1 - kh;
+        if (hn < 0 || hn % stride) continue;
+        const int ho = hn / stride;
+        if (ho >= Ho) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wn = w + 1 - kw;
+            if (wn < 0 || wn % stride) continue;
+            const int wo = wn / stride;
+            if (wo >= Wo) continue;
+            s += ld1(dcols + ((n * Ho + ho) * Wo + wo) * Kp + (kh * 3 + kw) * Cin + c);
+        }
+    }
+    float* p = dx + n * sN + h * sH + w * sW + c * sC;
+    *p = accumulate ? *p + s : s;
+}
+
+// w2[o][(kh * 3 + kw) * Cin + c] = w[o][c][kh][kw], zero beyond 9 Cin; w2t = its transpose [Kp][Cout]
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const float* __restrict__ w, T* __restrict__ w2, T* __restrict__ w2t, int Cout, int Cin, int Kp) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)Cout * Kp) return;
+    const int k = (int)(idx % Kp), o = (int)(idx / Kp);
+    float v = 0.f;
+    if (k < 9 * Cin) {
+        const int tap = k / Cin, c = k - tap * Cin;
+        v = w[((int64_t)o * Cin + c) * 9 + tap];
+    }
+    if (w2) Elem<T>::store(w2 + idx, v);
+    if (w2t) Elem<T>::store(w2t + (int64_t)k * Cout + o, v);
+}
+__global__ __launch_bounds__(256) void conv3x3_unpack_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int Cout, int Cin, int Kp) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)Cout * Cin * 9) return;
+    const int tap = (int)(idx % 9), c = (int)((idx / 9) % Cin), o = (int)(idx / (9 * (int64_t)Cin));
+    dw[idx] = dw2[(int64_t)o * Kp + tap * Cin + c];
+}
+
+// w (R, C) f32 -> wp [Rp][C] (rows >= R zero) and wpt [C][Rp] (columns >= R zero)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_rows_padded_kernel(const float* __restrict__ w, T* __restrict__ wp, T* __restrict__ wpt, int R, int C, int Rp) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)Rp * C) return;
+    const int c = (int)(idx % C), r = (int)(idx / C);
+    const float v = r < R ? w[(int64_t)r * C + c] : 0.f;
+    if (wp) Elem<T>::store(wp + idx, v);
+    if (wpt) Elem<T>::store(wpt + (int64_t)c * Rp + r, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// depth-wise 3x3, stride 1, padding 1, channels-last; thread = (pixel, 4 channels).  FLIP: the data gradient (the same sum with the
+// taps mirrored, no bias), written to an f32 map, optionally accumulating.
+template <typename T, typename To, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, To* __restrict__ y,
+                                                       int H, int W, int C, int accumulate, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = C >> 2;
+    const int c = 4 * (int)(idx % c4);
+    const int64_t pix = idx / c4;
+    const int wx = (int)(pix % W), h = (int)((pix / W) % H);
+    const int64_t n = pix / ((int64_t)W * H);
+    float4 acc = (bias && !FLIP) ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h + kh - 1;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ww = wx + kw - 1;
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const float4 v = load4(x + ((n * H + (ok ? hh : h)) * W + (ok ? ww : wx)) * C + c);      // unconditional load on a clamped address
+            const int tap = FLIP ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw;
+            const float m = ok ? 1.f : 0.f;
+            acc.x += m * v.x * w[(c + 0) * 9 + tap];
+            acc.y += m * v.y * w[(c + 1) * 9 + tap];
+            acc.z += m * v.z * w[(c + 2) * 9 + tap];
+            acc.w += m * v.w * w[(c + 3) * 9 + tap];
+        }
+    }
+    To* o = y + pix * C + c;
+    if (accumulate) {
+        const float4 p = load4(o);
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    store4(o, acc);
+}
+
+// weight / bias gradient partials: part[block][c * 9 + tap] = sum over the block's pixels of dy[pix][c] x[pix + tap][c],
+// part[block][9 C + c] = sum dy[pix][c].  Block = 256 threads = (64 channel quads) x (4 pixel lanes); reduced through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part,
+                                                          int H, int W, int C, int64_t pixels, int64_t pix_per_block) {
+    __shared__ float red[4][64][40];
+    const int cq = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = 4 * ((int)blockIdx.x * 64 + cq);
+    const bool cok = c < C;
+    const int cc = cok ? c : 0;
+    float acc[40];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) acc[i] = 0.f;
+    const int64_t p0 = (int64_t)blockIdx.y * pix_per_block;
+    int64_t p1 = p0 + pix_per_block;
+    p1 = p1 < pixels ? p1 : pixels;
+    for (int64_t pix = p0 + pl; pix < p1; pix += 4) {
+        const int wx = (int)(pix % W), h = (int)((pix / W) % H);
+        const float4 g = load4(dy + pix * C + cc);
+        acc[36] += g.x; acc[37] += g.y; acc[38] += g.z; acc[39] += g.w;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = wx + kw - 1;
+                const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                const float4 v = load4(x + (pix + (ok ? (int64_t)(kh - 1) * W + (kw - 1) : 0)) * C + cc);
+                const float m = ok ? 1.f : 0.f;
+                const int tap = kh * 3 + kw;
+                acc[tap] += m * g.x * v.x; acc[9 + tap] += m * g.y * v.y; acc[18 + tap] += m * g.z * v.z; acc[27 + tap] += m * g.w * v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 40; ++i) red[pl][cq][i] = acc[i];
+    __syncthreads();
+    if (pl == 0 && cok) {
+        float* out = part + (int64_t)blockIdx.y * (10 * (int64_t)C);
+#pragma unroll
+        for (int i = 0; i < 40; ++i) {
+            const float s = (red[0][cq][i] + red[1][cq][i]) + (red[2][cq][i] + red[3][cq][i]);
+            if (i < 36) out[(c + i / 9) * 9 + i % 9] = s;
+            else out[9 * (int64_t)C + c + (i - 36)] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// softmax over the P points of each (row, group): logits [rows][ld] -> probabilities [rows][G * P]; thread = (row, group)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_groups_fwd_kernel(const T* __restrict__ logits, int64_t ld, T* __restrict__ prob, int G, int P, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    const int64_t row = idx / G;
+    const T* in = logits + row * ld + g * P;
+    float v[32];
+    float m = -INFINITY;
+    for (int i = 0; i < P; ++i) {
+        v[i] = ld1(in + i);
+        m = fmaxf(m, v[i]);
+    }
+    float s = 0.f;
+    for (int i = 0; i < P; ++i) {
+        v[i] = __expf(v[i] - m);
+        s += v[i];
+    }
+    const float inv = 1.f / s;
+    T* out = prob + idx * P;
+    for (int i = 0; i < P; ++i) Elem<T>::store(out + i, v[i] * inv);
+}
+// dlogits[rows][ld] = p (dprob - sum p dprob); columns G * P .. ld are zeroed (they feed a GEMM as padded contraction columns)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_groups_bwd_kernel(const T* __restrict__ prob, const float* __restrict__ dprob, T* __restrict__ dlogits, int64_t ld,
+                                                                int G, int P, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    const int64_t row = idx / G;
+    const T* p = prob + idx * P;
+    const float* d = dprob + idx * P;
+    float pv[32], dot = 0.f;
+    for (int i = 0; i < P; ++i) {
+        pv[i] = ld1(p + i);
+        dot += pv[i] * d[i];
+    }
+    T* out = dlogits + row * ld + g * P;
+    for (int i = 0; i < P; ++i) Elem<T>::store(out + i, pv[i] * (d[i] - dot));
+    if (g == G - 1)
+        for (int i = G * P; i < ld; ++i) Elem<T>::store(dlogits + row * ld + i, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out32 = x32 + s[sample] * gamma * z  (+ an ACT-dtype copy for the next GEMM / depth-wise conv);  thread = 4 channels of a row
+template <typename T>
+__global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const float* __restrict__ x, const T* __restrict__ z, const float* __restrict__ gamma,
+                                                                const float* __restrict__ sample_scale, int rows_per_sample, float* __restrict__ out,
+                                                                T* __restrict__ out_act, int C, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = C >> 2;
+    const int c = 4 * (int)(idx % c4);
+    const int64_t row = idx / c4;
+    const float s = sample_scale ? sample_scale[row / rows_per_sample] : 1.f;
+    const float4 xv = *reinterpret_cast<const float4*>(x + row * C + c), zv = load4(z + row * C + c), gv = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 o = make_float4(xv.x + s * gv.x * zv.x, xv.y + s * gv.y * zv.y, xv.z + s * gv.z * zv.z, xv.w + s * gv.w * zv.w);
+    *reinterpret_cast<float4*>(out + row * C + c) = o;
+    if (out_act) store4(out_act + row * C + c, o);
+}
+// dz = s * gamma * dout (ACT dtype, the LayerNorm backward's input); dgamma partials: part[block][c] = sum_rows s * dout * z
+template <typename T>
+__global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ z, const float* __restrict__ gamma,
+                                                                const float* __restrict__ sample_scale, int rows_per_sample, T* __restrict__ dz,
+                                                                float* __restrict__ part, int C, int64_t rows, int64_t rows_per_block) {
+    __shared__ float4 red[4][64];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = 4 * ((int)blockIdx.x * 64 + cq);
+    const bool cok = c < C;
+    const int cc = cok ? c : 0;
+    const float4 gv = *reinterpret_cast<const float4*>(gamma + cc);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    for (int64_t row = r0 + rl; row < r1; row += 4) {
+        const float s = sample_scale ? sample_scale[row / rows_per_sample] : 1.f;
+        const float4 d = *reinterpret_cast<const float4*>(dout + row * C + cc), zv = load4(z + row * C + cc);
+        acc.x += s * d.x * zv.x; acc.y += s * d.y * zv.y; acc.z += s * d.z * zv.z; acc.w += s * d.w * zv.w;
+        if (cok) store4(dz + row * C + c, make_float4(s * gv.x * d.x, s * gv.y * d.y, s * gv.z * d.z, s * gv.w * d.w));
+    }
+    red[rl][cq] = acc;
+    __syncthreads();
+    if (rl == 0 && cok) {
+        const float4 a = red[0][cq], b = red[1][cq], e = red[2][cq], f = red[3][cq];
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + c) = make_float4((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y), (a.z + b.z) + (e.z + f.z), (a.w + b.w) + (e.w + f.w));
+    }
+}
+
+// dst[r][c] = c < n ? src[r][c] : 0   (f32 rows -> ACT rows of pitch ld >= n: the padded contraction operand of a GEMM)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_rows_kernel(const float* __restrict__ src, int64_t n, T* __restrict__ dst, int64_t ld, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t r = idx / ld, c = idx - r * ld;
+    Elem<T>::store(dst + idx, c < n ? src[r * n + c] : 0.f);
+}
+
+// dst[r][0..n) = src[r][0..n), both with their own row pitch (compacting a padded GEMM output)
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ src, int64_t src_ld, T* __restrict__ dst, int64_t dst_ld, int64_t n, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t r = idx / n, c = idx - r * n;
+    dst[r * dst_ld + c] = src[r * src_ld + c];
+}
+
+inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int mtp_im2col3x3(const void* x, int x_dtype, int64_t sN, int64_t sH, int64_t sW, int64_t sC, void* cols, int cols_dtype,
+                             int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t stride, int64_t Kp, mtp_stream_t stream) {
+    if (!x || !cols || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || stride < 1 || Kp < 9 * Cin) return MTP_ERR_ARG;
+    const int Ho = (int)((H - 1) / stride + 1), Wo = (int)((W - 1) / stride + 1);      // (H + 2 - 3) / s + 1
+    const int64_t total = N * Ho * Wo * Kp;
+    if (total / 256 > 0x7fffffff) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(blocks_for(total)), block(256);
+#define MTP_LAUNCH_I2C(TX, TC) hipLaunchKernelGGL((im2col3x3_kernel<TX, TC>), grid, block, 0, s, (const TX*)x, sN, sH, sW, sC, (TC*)cols, (int)H, (int)W, (int)Cin, Ho, Wo, (int)stride, (int)Kp, total)
+    if (x_dtype == MTP_F32 && cols_dtype == MTP_F32) MTP_LAUNCH_I2C(float, float);
+    else if (x_dtype == MTP_F32 && cols_dtype == MTP_BF16) MTP_LAUNCH_I2C(float, bf16_t);
+    else if (x_dtype == MTP_BF16 && cols_dtype == MTP_BF16) MTP_LAUNCH_I2C(bf16_t, bf16_t);
+    else return MTP_ERR_UNSUPPORTED;
+#undef MTP_LAUNCH_I2C
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_col2im3x3(const void* dcols, int cols_dtype, float* dx, int64_t sN, int64_t sH, int64_t sW, int64_t sC,
+                             int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t stride, int64_t Kp, int accumulate, mtp_stream_t stream) {
+    if (!dcols || !dx || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || stride < 1 || Kp < 9 * Cin) return MTP_ERR_ARG;
+    const int Ho = (int)((H - 1) / stride + 1), Wo = (int)((W - 1) / stride + 1);
+    const int64_t total = N * H * W * Cin;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(blocks_for(total)), block(256);
+    if (cols_dtype == MTP_BF16)
+        hipLaunchKernelGGL((col2im3x3_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)dcols, dx, sN, sH, sW, sC, (int)H, (int)W, (int)Cin, Ho, Wo, (int)stride, (int)Kp, accumulate, total);
+    else if (cols_dtype == MTP_F32)
+        hipLaunchKernelGGL((col2im3x3_kernel<float>), grid, block, 0, s, (const float*)dcols, dx, sN, sH, sW, sC, (int)H, (int)W, (int)Cin, Ho, Wo, (int)stride, (int)Kp, accumulate, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_conv3x3_pack(const float* w, void* w2, void* w2t, int dtype, int64_t Cout, int64_t Cin, int64_t Kp, mtp_stream_t stream) {
+    if (!w || (!w2 && !w2t) || Cout <= 0 || Cin <= 0 || Kp < 9 * Cin) return MTP_ERR_ARG;
+    const dim3 grid(blocks_for(Cout * Kp)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((conv3x3_pack_kernel<bf16_t>), grid, block, 0, s, w, (bf16_t*)w2, (bf16_t*)w2t, (int)Cout, (int)Cin, (int)Kp);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((conv3x3_pack_kernel<float>), grid, block, 0, s, w, (float*)w2, (float*)w2t, (int)Cout, (int)Cin, (int)Kp);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_conv3x3_unpack_grad(const float* dw2, float* dw, int64_t Cout, int64_t Cin, int64_t Kp, mtp_stream_t stream) {
+    if (!dw2 || !dw || Cout <= 0 || Cin <= 0 || Kp < 9 * Cin) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(conv3x3_unpack_kernel, dim3(blocks_for(Cout * Cin * 9)), dim3(256), 0, (hipStream_t)stream, dw2, dw, (int)Cout, (int)Cin, (int)Kp);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_pack_rows_padded(const float* w, void* wp, void* wpt, int dtype, int64_t R, int64_t C, int64_t Rp, mtp_stream_t stream) {
+    if (!w || (!wp && !wpt) || R <= 0 || C <= 0 || Rp < R) return MTP_ERR_ARG;
+    const dim3 grid(blocks_for(Rp * C)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((pack_rows_padded_kernel<bf16_t>), grid, block, 0, s, w, (bf16_t*)wp, (bf16_t*)wpt, (int)R, (int)C, (int)Rp);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((pack_rows_padded_kernel<float>), grid, block, 0, s, w, (float*)wp, (float*)wpt, (int)R, (int)C, (int)Rp);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int dtype, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4)) return MTP_ERR_ARG;
+    const int64_t total = N * H * W * (C / 4);
+    const dim3 grid(blocks_for(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, bf16_t, false>), grid, block, 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, (int)H, (int)W, (int)C, 0, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconv3x3_kernel<float, float, false>), grid, block, 0, s, (const float*)x, w, bias, (float*)y, (int)H, (int)W, (int)C, 0, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_dwconv3x3_bwd_dx(const void* dy, int dtype, const float* w, float* dx, int accumulate, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream) {
+    if (!dy || !w || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4)) return MTP_ERR_ARG;
+    const int64_t total = N * H * W * (C / 4);
+    const dim3 grid(blocks_for(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, float, true>), grid, block, 0, s, (const bf16_t*)dy, w, (const float*)nullptr, dx, (int)H, (int)W, (int)C, accumulate, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconv3x3_kernel<float, float, true>), grid, block, 0, s, (const float*)dy, w, (const float*)nullptr, dx, (int)H, (int)W, (int)C, accumulate, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int64_t mtp_dwconv3x3_bwd_dw_partial_rows(int64_t N, int64_t H, int64_t W) {
+    const int64_t pixels = N * H * W;
+    const int64_t nb = (pixels + 255) / 256;
+    return nb < 256 ? nb : 256;
+}
+
+/* part: (mtp_dwconv3x3_bwd_dw_partial_rows, 10 C) f32 = per-block partials of [dweight (C, 9) | dbias (C)] */
+extern "C" int mtp_dwconv3x3_bwd_dw(const void* dy, const void* x, int dtype, float* part, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream) {
+    if (!dy || !x || !part || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4)) return MTP_ERR_ARG;
+    const int64_t pixels = N * H * W, nb = mtp_dwconv3x3_bwd_dw_partial_rows(N, H, W);
+    const int64_t ppb = (pixels + nb - 1) / nb;
+    const dim3 grid((unsigned)((C / 4 + 63) / 64), (unsigned)nb), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconv3x3_dw_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)x, part, (int)H, (int)W, (int)C, pixels, ppb);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconv3x3_dw_kernel<float>), grid, block, 0, s, (const float*)dy, (const float*)x, part, (int)H, (int)W, (int)C, pixels, ppb);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_softmax_groups_fwd(const void* logits, int64_t ld, void* prob, int dtype, int64_t rows, int64_t G, int64_t P, mtp_stream_t stream) {
+    if (!logits || !prob || rows <= 0 || G <= 0 || P <= 0 || P > 32 || ld < G * P) return MTP_ERR_ARG;
+    const int64_t total = rows * G;
+    const dim3 grid(blocks_for(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((softmax_groups_fwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)logits, ld, (bf16_t*)prob, (int)G, (int)P, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((softmax_groups_fwd_kernel<float>), grid, block, 0, s, (const float*)logits, ld, (float*)prob, (int)G, (int)P, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_softmax_groups_bwd(const void* prob, const float* dprob, void* dlogits, int64_t ld, int dtype, int64_t rows, int64_t G, int64_t P, mtp_stream_t stream) {
+    if (!prob || !dprob || !dlogits || rows <= 0 || G <= 0 || P <= 0 || P > 32 || ld < G * P) return MTP_ERR_ARG;
+    const int64_t total = rows * G;
+    const dim3 grid(blocks_for(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((softmax_groups_bwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)prob, dprob, (bf16_t*)dlogits, ld, (int)G, (int)P, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((softmax_groups_bwd_kernel<float>), grid, block, 0, s, (const float*)prob, dprob, (float*)dlogits, ld, (int)G, (int)P, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_scale_residual_fwd(const float* x, const void* z, int dtype, const float* gamma, const float* sample_scale, int64_t rows_per_sample,
+                                      float* out, void* out_act, int64_t rows, int64_t C, mtp_stream_t stream) {
+    if (!x || !z || !gamma || !out || rows <= 0 || C <= 0 || (C % 4) || (sample_scale && rows_per_sample <= 0)) return MTP_ERR_ARG;
+    const int64_t total = rows * (C / 4);
+    const dim3 grid(blocks_for(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int rps = (int)(rows_per_sample > 0 ? rows_per_sample : 1);
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((scale_residual_fwd_kernel<bf16_t>), grid, block, 0, s, x, (const bf16_t*)z, gamma, sample_scale, rps, out, (bf16_t*)out_act, (int)C, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((scale_residual_fwd_kernel<float>), grid, block, 0, s, x, (const float*)z, gamma, sample_scale, rps, out, (float*)out_act, (int)C, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int64_t mtp_scale_residual_bwd_partial_rows(int64_t rows) {
+    const int64_t nb = (rows + 63) / 64;
+    return nb < 256 ? nb : 256;
+}
+
+/* part: (mtp_scale_residual_bwd_partial_rows(rows), C) f32 = per-block partials of dgamma */
+extern "C" int mtp_scale_residual_bwd(const float* dout, const void* z, int dtype, const float* gamma, const float* sample_scale, int64_t rows_per_sample,
+                                      void* dz, float* part, int64_t rows, int64_t C, mtp_stream_t stream) {
+    if (!dout || !z || !gamma || !dz || !part || rows <= 0 || C <= 0 || (C % 4) || (sample_scale && rows_per_sample <= 0)) return MTP_ERR_ARG;
+    const int64_t nb = mtp_scale_residual_bwd_partial_rows(rows);
+    const int64_t rpb = (rows + nb - 1) / nb;
+    const dim3 grid((unsigned)((C / 4 + 63) / 64), (unsigned)nb), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int rps = (int)(rows_per_sample > 0 ? rows_per_sample : 1);
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((scale_residual_bwd_kernel<bf16_t>), grid, block, 0, s, dout, (const bf16_t*)z, gamma, sample_scale, rps, (bf16_t*)dz, part, (int)C, rows, rpb);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((scale_residual_bwd_kernel<float>), grid, block, 0, s, dout, (const float*)z, gamma, sample_scale, rps, (float*)dz, part, (int)C, rows, rpb);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_cast_pad_rows(const float* src, int64_t n, void* dst, int dst_dtype, int64_t ld, int64_t rows, mtp_stream_t stream) {
+    if (!src || !dst || n <= 0 || ld < n || rows <= 0) return MTP_ERR_ARG;
+    const int64_t total = rows * ld;
+    const dim3 grid(blocks_for(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dst_dtype == MTP_BF16) hipLaunchKernelGGL((cast_pad_rows_kernel<bf16_t>), grid, block, 0, s, src, n, (bf16_t*)dst, ld, total);
+    else if (dst_dtype == MTP_F32) hipLaunchKernelGGL((cast_pad_rows_kernel<float>), grid, block, 0, s, src, n, (float*)dst, ld, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_copy_rows(const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int dtype, int64_t n, int64_t rows, mtp_stream_t stream) {
+    if (!src || !dst || n <= 0 || src_ld < n || dst_ld < n || rows <= 0) return MTP_ERR_ARG;
+    const int64_t total = rows * n;
+    const dim3 grid(blocks_for(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((copy_rows_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)src, src_ld, (bf16_t*)dst, dst_ld, n, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((copy_rows_kernel<float>), grid, block, 0, s, (const float*)src, src_ld, (float*)dst, dst_ld, n, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}

@@ -9,22 +9,22 @@
 namespace {
 
 constexpr int LN_THREADS = 256;   // 4 rows per block pass
-constexpr int MAXV = 4;           // float4 per lane kept in registers -> C <= 1024
+constexpr int MAXV = 8;           // float4 per lane kept in registers: kernels are instantiated for 4 (C <= 1024: the ViTs) and 8 (C <= 2048: InternImage-XL's 1536)
 
 // All row loads are UNCONDITIONAL on a clamped column (lanes past the row end re-read the last group and are masked in the
 // arithmetic / at the store): with `if (c4 < nv)` around them hipcc emitted an exec-masked block + s_waitcnt vmcnt(0) per load,
 // i.e. one HBM latency after the other (the backward ran at 3.4 TB/s with 8-10 serialised waits per row).
-template <typename Tx, typename Ty, bool GELU>
+template <typename Tx, typename Ty, bool GELU, int MV>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const Tx* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            Ty* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                            int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;   // float4 groups per row
-    int col[MAXV];
-    bool ok[MAXV];
-    float4 g[MAXV], bb[MAXV];
+    int col[MV];
+    bool ok[MV];
+    float4 g[MV], bb[MV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < MV; ++i) {
         const int c4 = lane + 64 * i;
         ok[i] = c4 < nv;
         col[i] = 4 * (ok[i] ? c4 : nv - 1);
@@ -33,16 +33,16 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const Tx* __restrict
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const Tx* xr = x + row * C;
-        float4 v[MAXV];
+        float4 v[MV];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) v[i] = load4(xr + col[i]);
+        for (int i = 0; i < MV; ++i) v[i] = load4(xr + col[i]);
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) s += ok[i] ? (v[i].x + v[i].y + v[i].z + v[i].w) : 0.f;
+        for (int i = 0; i < MV; ++i) s += ok[i] ? (v[i].x + v[i].y + v[i].z + v[i].w) : 0.f;
         const float mu = wave_sum(s) / (float)C;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < MV; ++i) {
             const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
             q += ok[i] ? (a * a + b * b + c * c + d * d) : 0.f;
         }
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const Tx* __restrict
         }
         Ty* yr = y + row * C;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < MV; ++i) {
             float4 o = make_float4((v[i].x - mu) * rs * g[i].x + bb[i].x, (v[i].y - mu) * rs * g[i].y + bb[i].y,
                                    (v[i].z - mu) * rs * g[i].z + bb[i].z, (v[i].w - mu) * rs * g[i].w + bb[i].w);
             if (GELU) o = make_float4(gelu_f(o.x), gelu_f(o.y), gelu_f(o.z), gelu_f(o.w));
@@ -62,20 +62,20 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const Tx* __restrict
     }
 }
 
-template <typename Tact, typename Tx, typename Tdx, bool GELU>
+template <typename Tact, typename Tx, typename Tdx, bool GELU, int MV>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restrict__ dy, const Tx* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dres, const float* __restrict__ extra, Tdx* __restrict__ dx,
                                                            Tact* __restrict__ dx_copy, const float* __restrict__ copy_scale, int rows_per_sample,
                                                            float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int64_t part_ld, int64_t rows, int C) {
-    __shared__ float4 red[2][3][64 * MAXV];   // waves 1..3 -> wave 0
+    __shared__ float4 red[2][3][64 * MV];   // waves 1..3 -> wave 0
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
-    float4 gacc[MAXV], bacc[MAXV], g[MAXV], bt[MAXV];
-    int col[MAXV];
-    bool ok[MAXV];
+    float4 gacc[MV], bacc[MV], g[MV], bt[MV];
+    int col[MV];
+    bool ok[MV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < MV; ++i) {
         gacc[i] = make_float4(0, 0, 0, 0);
         bacc[i] = make_float4(0, 0, 0, 0);
         const int c4 = lane + 64 * i;
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         // ---- every load of the row first (the uniform `if (dres)` blocks contain loads only, no uses)
-        float4 xv[MAXV], dv[MAXV], rr[MAXV], ee[MAXV];
+        float4 xv[MV], dv[MV], rr[MV], ee[MV];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < MV; ++i) {
             xv[i] = load4(x + row * C + col[i]);
             dv[i] = load4(dy + row * C + col[i]);
             rr[i] = zero4;
@@ -97,18 +97,18 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
         }
         if (dres) {
 #pragma unroll
-            for (int i = 0; i < MAXV; ++i) rr[i] = *reinterpret_cast<const float4*>(dres + row * C + col[i]);
+            for (int i = 0; i < MV; ++i) rr[i] = *reinterpret_cast<const float4*>(dres + row * C + col[i]);
         }
         if (extra) {
 #pragma unroll
-            for (int i = 0; i < MAXV; ++i) ee[i] = *reinterpret_cast<const float4*>(extra + row * C + col[i]);
+            for (int i = 0; i < MV; ++i) ee[i] = *reinterpret_cast<const float4*>(extra + row * C + col[i]);
         }
         const float mu = mean[row], rs = rstd[row];
         const float cs = (dx_copy && copy_scale) ? copy_scale[(uint32_t)row / (uint32_t)rows_per_sample] : 1.0f;   // (64-bit division is ~150 instructions)
-        float4 xh[MAXV], d[MAXV];
+        float4 xh[MV], d[MV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < MV; ++i) {
             if (!ok[i]) dv[i] = zero4;   // select on the loaded VALUE: masked lanes add nothing below
             xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
             if (GELU) {   // y = gelu(z), z = xhat*gamma+beta
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
         }
         const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < MV; ++i) {
             const float4 o = make_float4((d[i].x - xh[i].x * c1 - c2) * rs + rr[i].x + ee[i].x, (d[i].y - xh[i].y * c1 - c2) * rs + rr[i].y + ee[i].y,
                                          (d[i].z - xh[i].z * c1 - c2) * rs + rr[i].z + ee[i].z, (d[i].w - xh[i].w * c1 - c2) * rs + rr[i].w + ee[i].w);
             if (ok[i]) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
     // block-level reduction of the parameter-gradient partials (waves 1..3 -> LDS -> wave 0)
     if (wave > 0) {
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < MV; ++i) {
             red[0][wave - 1][lane + 64 * i] = gacc[i];
             red[1][wave - 1][lane + 64 * i] = bacc[i];
         }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < MV; ++i) {
             if (ok[i]) {
                 float4 a = gacc[i], b = bacc[i];
 #pragma unroll
@@ -215,10 +215,15 @@ int ln_grid(int64_t rows) {
 template <typename Tx, typename Ty>
 int launch_ln_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t rows, int64_t C, float eps, int gelu, hipStream_t s) {
     dim3 grid(ln_grid(rows)), block(LN_THREADS);
-    if (gelu)
-        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, true>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
+    if (C > 1024) {
+        if (gelu)
+            hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, true, 8>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
+        else
+            hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, false, 8>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
+    } else if (gelu)
+        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, true, 4>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
     else
-        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, false>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
+        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, false, 4>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
     return mtp_launch_status();
 }
 
@@ -227,11 +232,18 @@ int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float*
                   const float* dres, const float* extra, void* dx, void* dx_copy, const float* copy_scale, int64_t rps,
                   float* dgp, float* dbp, int64_t part_ld, int64_t rows, int64_t C, hipStream_t s) {
     dim3 grid((unsigned)mtp_layernorm_bwd_partial_rows(rows)), block(LN_THREADS);
-    if (gelu)
-        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
+    if (C > 1024) {
+        if (gelu)
+            hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true, 8>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
+        else
+            hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false, 8>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
+    } else if (gelu)
+        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true, 4>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
                            (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
     else
-        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
+        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false, 4>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
                            (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
     return mtp_launch_status();
 }

@@ -1,0 +1,331 @@
+"""Explicit forward / backward kernel schedule of the InternImage backbone on the HIP operators.
+
+Reference: Multi-Task_Pretrain/backbone/intern_image.py ("II") -- StemLayer II:239-276, DownsampleLayer II:279-300, MLPLayer
+II:303-333, InternImageLayer II:336-433 (the layer_scale + post_norm branch II:424-426), InternImageBlock II:436-524,
+InternImage.forward II:690-698 -- and ops_dcnv3/modules/dcnv3.py ("DCNM") DCNv3.forward :318-356.
+
+Everything is channels-last, `rows = N * H * W` rows of C channels:
+  * 3x3 convolutions (stem, downsample) = mtp_im2col3x3 + the MFMA NT GEMM; their gradients = TN GEMM (+ unpack) and NT GEMM + col2im;
+  * Linear layers = NT GEMMs with fused bias / GELU (+ gelu') / residual epilogues, weight gradients = TN GEMMs with the bias
+    gradient as a by-product;
+  * depth-wise 3x3, softmax over the 9 points, layer-scale residual: csrc/conv.hip; LayerNorm (+GELU): csrc/layernorm.hip;
+  * the DCNv3 core: csrc/dcnv3.hip through mtp_amd.ops_dcnv3 (the reference's own extension interface).
+The residual stream is f32; every GEMM operand is the ACT dtype (bf16, or f32 in parity mode).  No torch compute ops: torch
+allocates buffers and draws the drop-path masks.
+"""
+import torch
+
+from . import ops
+from .ops_dcnv3 import functions as dcn
+
+F32 = torch.float32
+
+
+class _Lin:
+    __slots__ = ("name", "R", "C", "Rp", "w", "wt", "padded", "bias")
+
+
+class InternEngine:
+    def __init__(self, module, act_dtype=torch.bfloat16):
+        self.m = module
+        self.act = act_dtype
+        self._key = None
+        self._ptrs = None
+        self._lin = {}
+        self._conv = {}
+        self._wimg = None
+        self._padded = []
+
+    # ------------------------------------------------------------------ parameters -> GEMM-side images
+    def params(self):
+        return dict(self.m.named_parameters())
+
+    def prepare_weights(self):
+        P = self.params()
+        key = (self.act,) + tuple((p.data_ptr(), p._version) for p in P.values())
+        if key == self._key:
+            return
+        ptrs = (self.act,) + tuple(p.data_ptr() for p in P.values())
+        if ptrs != self._ptrs:
+            self._build(P)
+            self._ptrs = ptrs
+        if self._wimg is not None:
+            self._wimg.refresh()
+        for L in self._padded:
+            ops.pack_rows_padded(P[L.name].detach(), L.w, L.wt)
+            L.bias[:L.R].copy_(P[L.name[:-len("weight")] + "bias"].detach())      # (device-to-device copy of R floats)
+        for name, (w2, w2t) in self._conv.items():
+            ops.conv3x3_pack(P[name].detach().contiguous(), w2, w2t)
+        self._key = key
+
+    def _build(self, P):
+        dev = next(iter(P.values())).device
+        act = self.act
+        entries, self._lin, self._conv, self._padded = [], {}, {}, []
+        for name, p in P.items():
+            if p.dim() == 2:       # Linear (R, C)
+                L = _Lin()
+                L.name, (L.R, L.C) = name, p.shape
+                L.Rp = ops.pad8(L.R)
+                L.padded = L.Rp != L.R
+                w2d = p.detach()
+                L.bias = None
+                if L.padded:
+                    # rows not a multiple of 8 (mask head at 12 groups: 108 rows): the GEMM runs on zero-padded images -- Rp output
+                    # columns forward (the extra logits are 0 and never read), a 16-byte row pitch for the transposed image and a
+                    # contraction over Rp in the data gradient
+                    L.w = torch.zeros(L.Rp, L.C, device=dev, dtype=act)
+                    L.wt = torch.zeros(L.C, L.Rp, device=dev, dtype=act)
+                    L.bias = torch.zeros(L.Rp, device=dev, dtype=F32)
+                    self._padded.append(L)
+                else:
+                    L.wt = torch.empty(L.C, L.R, device=dev, dtype=act)
+                    L.w = w2d if act == F32 else torch.empty(L.R, L.C, device=dev, dtype=act)
+                    entries.append((w2d, None if act == F32 else L.w, L.wt, False))
+                self._lin[name] = L
+            elif p.dim() == 4 and p.shape[1] > 1:     # dense 3x3 convolution (Cout, Cin, 3, 3)
+                Cout, Cin = p.shape[:2]
+                Kp = ops.pad8(9 * Cin)
+                self._conv[name] = (torch.empty(Cout, Kp, device=dev, dtype=act), torch.empty(Kp, Cout, device=dev, dtype=act))
+        self._wimg = ops.WeightImages(entries, act) if entries else None
+
+    # ------------------------------------------------------------------ helpers
+    def _e(self, *shape, dtype=None):
+        return torch.empty(*shape, device=self.dev, dtype=dtype or self.act)
+
+    def _linear(self, x, wname, bias, padded_out=False, **kw):
+        """x @ W^T + b.  Padded weights: the GEMM writes Rp columns; the result is compacted to R columns unless the caller reads
+        it through its pitch (padded_out)."""
+        L = self._lin[wname]
+        if not L.padded:
+            return ops.gemm_nt(x, L.w, self._e(x.shape[0], L.R), bias=bias, **kw)
+        out = ops.gemm_nt(x, L.w, self._e(x.shape[0], L.Rp), bias=L.bias, **kw)
+        return out if padded_out else ops.copy_rows(out, self._e(x.shape[0], L.R), L.R)
+
+    def _wgrad(self, dy, x, wname, G):
+        """dW = dy^T x and db = column sums of dy into G.  Padded layers: dy has Rp columns (the last ones zero); the TN GEMM needs its
+        M to be a multiple of 8, so it produces Rp rows and the first R are copied out."""
+        L = self._lin[wname]
+        bname = wname[:-len("weight")] + "bias"
+        if not L.padded:
+            ops.gemm_tn(dy, x, G[wname], colsum=G[bname])
+            return
+        tw, tb = self._e(L.Rp, L.C, dtype=F32), torch.zeros(L.Rp, device=self.dev, dtype=F32)
+        ops.gemm_tn(dy, x, tw, colsum=tb)
+        ops.copy_segments([tw.view(-1)[:L.R * L.C], tb[:L.R]], [G[wname].view(-1), G[bname]])
+
+    def _ln(self, x, P, key, out_dtype=None, gelu=False):
+        rows = x.shape[0]
+        y = self._e(rows, x.shape[1], dtype=out_dtype)
+        mean, rstd = self._e(rows, dtype=F32), self._e(rows, dtype=F32)
+        ops.layernorm_fwd(x, P[key + ".weight"], P[key + ".bias"], y, mean, rstd, eps=1e-6, gelu=gelu)
+        return y, mean, rstd
+
+    def _ln_bwd(self, dy, x, mean, rstd, P, G, key, gelu=False):
+        dx = self._e(*x.shape, dtype=x.dtype)
+        ops.layernorm_bwd(dy, x, mean, rstd, P[key + ".weight"], dx, G[key + ".weight"], G[key + ".bias"],
+                          beta=P[key + ".bias"] if gelu else None, gelu=gelu, accumulate=True)
+        return dx
+
+    def _to_act(self, t):
+        return t if t.dtype == self.act else ops.cast(t, self._e(*t.shape))
+
+    def _conv_fwd(self, x, strides, name, bias, N, H, W, Cin, stride):
+        w2, _ = self._conv[name]
+        Ho, Wo = ops.conv_out(H, stride), ops.conv_out(W, stride)
+        cols = ops.im2col3x3(x, strides, self._e(N * Ho * Wo, w2.shape[1]), N, H, W, Cin, stride)
+        y = ops.gemm_nt(cols, w2, self._e(N * Ho * Wo, w2.shape[0]), bias=bias)
+        return y, cols, Ho, Wo
+
+    def _conv_bwd(self, dy, cols, name, G, bias_name, dx, strides, N, H, W, Cin, stride, accumulate=False):
+        """dy (rows, Cout) ACT.  Weight (+ bias) gradient into G; dx (f32, strided) = / += data gradient when dx is not None"""
+        w2, w2t = self._conv[name]
+        dw2 = self._e(*w2.shape, dtype=F32)
+        ops.gemm_tn(dy, cols, dw2, colsum=(G[bias_name] if bias_name else None))
+        ops.conv3x3_unpack_grad(dw2, G[name])
+        if dx is not None:
+            dcols = ops.gemm_nt(dy, w2t, self._e(dy.shape[0], w2.shape[1]))
+            ops.col2im3x3(dcols, dx, strides, N, H, W, Cin, stride, accumulate=accumulate)
+
+    def _drop_scales(self, n_layers, N, training):
+        rates = self.m.drop_path_rates
+        if not training or not any(r > 0 for r in rates):
+            return None
+        keep = 1.0 - torch.tensor(rates, device=self.dev, dtype=F32).repeat_interleave(2).unsqueeze(1)     # (2 * layers, 1)
+        u = torch.rand(2 * n_layers, N, device=self.dev)
+        return ((u < keep).to(F32) / keep).contiguous()
+
+    # ------------------------------------------------------------------ one InternImageLayer
+    def _layer_fwd(self, pre, x32, xa, N, H, W, C, G, scales, save):
+        P = self.P
+        rows = N * H * W
+        K = self.m.kernel_size
+        Pn = K * K
+        d = pre + "dcn."
+        xp = self._linear(xa, d + "input_proj.weight", P[d + "input_proj.bias"])
+        x1c = ops.dwconv3x3_fwd(xa, P[d + "dw_conv.0.weight"], P[d + "dw_conv.0.bias"], self._e(rows, C), N, H, W)
+        x1, m0, r0 = self._ln(x1c, P, d + "dw_conv.1.1", gelu=True)
+        off = self._linear(x1, d + "offset.weight", P[d + "offset.bias"])
+        Lm = self._lin[d + "mask.weight"]
+        logits = self._linear(x1, d + "mask.weight", P[d + "mask.bias"], padded_out=True)
+        mask = ops.softmax_groups_fwd(logits, self._e(rows, G * Pn), G, Pn)
+        pad = K // 2
+        y = dcn.dcnv3_forward(xp.view(N, H, W, C), off.view(N, H, W, -1), mask.view(N, H, W, -1), K, K, 1, 1, pad, pad, 1, 1, G, C // G,
+                              self.m.offset_scale, 256).view(rows, C)
+        h = self._linear(y, d + "output_proj.weight", P[d + "output_proj.bias"])
+        z1, m1, r1 = self._ln(h, P, pre + "norm1.0")
+        s1 = scales[0] if scales is not None else None
+        x32b, xab = self._e(rows, C, dtype=F32), self._e(rows, C)
+        ops.scale_residual_fwd(x32, z1, P[pre + "gamma1"], x32b, xab, s1, H * W)
+        # MLPLayer: fc1 -> GELU -> fc2 (dropout p = 0); fc1 stores gelu'(u) next to gelu(u) for the backward
+        L1 = self._lin[pre + "mlp.fc1.weight"]
+        u = self._e(rows, L1.R)
+        ug = self._e(rows, L1.R) if save else None
+        ops.gemm_nt(xab, L1.w, u, epi=(ops.EPI_BIAS_GELU_DG if save else ops.EPI_BIAS_GELU), bias=P[pre + "mlp.fc1.bias"], aux=ug)
+        v = self._linear(u, pre + "mlp.fc2.weight", P[pre + "mlp.fc2.bias"])
+        z2, m2, r2 = self._ln(v, P, pre + "norm2.0")
+        s2 = scales[1] if scales is not None else None
+        x32c, xac = self._e(rows, C, dtype=F32), self._e(rows, C)
+        ops.scale_residual_fwd(x32b, z2, P[pre + "gamma2"], x32c, xac, s2, H * W)
+        ctx = None
+        if save:
+            ctx = dict(xa=xa, xp=xp, x1c=x1c, m0=m0, r0=r0, x1=x1, off=off, mask=mask, y=y, h=h, m1=m1, r1=r1, z1=z1, xab=xab, u=u, ug=ug, v=v,
+                       m2=m2, r2=r2, z2=z2, s1=s1, s2=s2)
+        return x32c, xac, ctx
+
+    def _layer_bwd(self, pre, c, dx32, N, H, W, C, G, Gd):
+        """dx32 (rows, C) f32: gradient of the layer's output; returns the gradient of its input (f32, new buffer or in place)"""
+        P = self.P
+        rows = N * H * W
+        K = self.m.kernel_size
+        Pn = K * K
+        d = pre + "dcn."
+        # ---- x3 = x2 + s2 * gamma2 * LN2(fc2(gelu(fc1(x2))))
+        dz2 = ops.scale_residual_bwd(dx32, c["z2"], P[pre + "gamma2"], self._e(rows, C), Gd[pre + "gamma2"], c["s2"], H * W, accumulate=True)
+        dv = self._ln_bwd(dz2, c["v"], c["m2"], c["r2"], P, Gd, pre + "norm2.0")
+        L1, L2 = self._lin[pre + "mlp.fc1.weight"], self._lin[pre + "mlp.fc2.weight"]
+        ops.gemm_tn(dv, c["u"], Gd[pre + "mlp.fc2.weight"], colsum=Gd[pre + "mlp.fc2.bias"])
+        du = ops.gemm_nt(dv, L2.wt, self._e(rows, L1.R), epi=ops.EPI_MUL, aux=c["ug"])
+        ops.gemm_tn(du, c["xab"], Gd[pre + "mlp.fc1.weight"], colsum=Gd[pre + "mlp.fc1.bias"])
+        dx2 = ops.gemm_nt(du, L1.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx32)      # + the residual path
+        # ---- x2 = x + s1 * gamma1 * LN1(output_proj(dcnv3(...)))
+        dz1 = ops.scale_residual_bwd(dx2, c["z1"], P[pre + "gamma1"], self._e(rows, C), Gd[pre + "gamma1"], c["s1"], H * W, accumulate=True)
+        dh = self._ln_bwd(dz1, c["h"], c["m1"], c["r1"], P, Gd, pre + "norm1.0")
+        Lo = self._lin[d + "output_proj.weight"]
+        ops.gemm_tn(dh, c["y"], Gd[d + "output_proj.weight"], colsum=Gd[d + "output_proj.bias"])
+        dy = ops.gemm_nt(dh, Lo.wt, self._e(rows, C))
+        pad = K // 2
+        dxp, doff, dmask = dcn.dcnv3_backward(c["xp"].view(N, H, W, C), c["off"].view(N, H, W, -1), c["mask"].view(N, H, W, -1), K, K, 1, 1, pad, pad,
+                                              1, 1, G, C // G, self.m.offset_scale, dy.view(N, H, W, C), 256)
+        # offset / mask heads -> d(x1)
+        Lf, Lm = self._lin[d + "offset.weight"], self._lin[d + "mask.weight"]
+        doffa = ops.cast_pad_rows(doff.view(rows, -1), self._e(rows, Lf.Rp)) if (Lf.padded or self.act != F32) else doff.view(rows, -1)
+        dlog = ops.softmax_groups_bwd(c["mask"], dmask.view(rows, -1), self._e(rows, Lm.Rp), G, Pn)
+        self._wgrad(doffa, c["x1"], d + "offset.weight", Gd)
+        self._wgrad(dlog, c["x1"], d + "mask.weight", Gd)
+        dx1 = ops.gemm_nt(doffa, Lf.wt, self._e(rows, C, dtype=F32))
+        dx1 = ops.gemm_nt(dlog, Lm.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx1)
+        dx1c = self._ln_bwd(self._to_act(dx1), c["x1c"], c["m0"], c["r0"], P, Gd, d + "dw_conv.1.1", gelu=True)
+        ops.dwconv3x3_bwd_dw(dx1c, c["xa"], Gd[d + "dw_conv.0.weight"], Gd[d + "dw_conv.0.bias"], N, H, W, accumulate=True)
+        # input_proj -> d(x); plus the depth-wise branch and the residual path
+        Li = self._lin[d + "input_proj.weight"]
+        dxpa = self._to_act(dxp.view(rows, C))
+        ops.gemm_tn(dxpa, c["xa"], Gd[d + "input_proj.weight"], colsum=Gd[d + "input_proj.bias"])
+        dxin = ops.gemm_nt(dxpa, Li.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx2)
+        ops.dwconv3x3_bwd_dx(dx1c, P[d + "dw_conv.0.weight"], dxin, N, H, W, accumulate=True)
+        return dxin
+
+    # ------------------------------------------------------------------ whole forward
+    def forward(self, img, training=False, need_grad=False, feature_dtype=None):
+        m = self.m
+        self.dev = img.device
+        self.prepare_weights()
+        self.P = P = {k: v.detach() for k, v in self.params().items()}
+        N, Cin, H, W = img.shape
+        if img.dtype not in (F32, torch.bfloat16) or not img.is_contiguous() or (self.act == F32 and img.dtype != F32):
+            img = img.float().contiguous()
+        save = need_grad
+        fdt = feature_dtype or self.act
+        ch = m.channels
+        # ---- StemLayer: conv3x3 s2 -> LN -> GELU -> conv3x3 s2 -> LN
+        y1, cols1, H1, W1 = self._conv_fwd(img, (Cin * H * W, W, 1, H * W), "patch_embed.conv1.weight", P["patch_embed.conv1.bias"], N, H, W, Cin, 2)
+        a1, sm1, sr1 = self._ln(y1, P, "patch_embed.norm1.1", gelu=True)
+        c2 = ch // 2
+        y2, cols2, H2, W2 = self._conv_fwd(a1, (H1 * W1 * c2, W1 * c2, c2, 1), "patch_embed.conv2.weight", P["patch_embed.conv2.bias"], N, H1, W1, c2, 2)
+        x32, sm2, sr2 = self._ln(y2, P, "patch_embed.norm2.1", out_dtype=F32)
+        xa = self._to_act(x32)
+        nl = sum(m.depths)
+        scales = self._drop_scales(nl, N, training)
+        ctx = dict(stem=(img if save else None, cols1, y1, sm1, sr1, a1, cols2, y2, sm2, sr2, (N, Cin, H, W, H1, W1, H2, W2)), levels=[], scales=scales) if save else None
+        feats = []
+        Hc, Wc, C = H2, W2, ch
+        li = 0
+        for i, (depth, G) in enumerate(zip(m.depths, m.groups)):
+            lctx = []
+            for j in range(depth):
+                sc = (scales[2 * li], scales[2 * li + 1]) if scales is not None else None
+                x32, xa, c = self._layer_fwd("levels.%d.blocks.%d." % (i, j), x32, xa, N, Hc, Wc, C, G, sc, save)
+                lctx.append(c)
+                li += 1
+            if i in m.out_indices:
+                feats.append(ops.tokens_to_nchw(x32, self._e(N, C, Hc, Wc, dtype=fdt), N, Hc, Wc, 0))
+            down = None
+            if i < len(m.depths) - 1:
+                pre = "levels.%d.downsample." % i
+                yd, colsd, Hn, Wn = self._conv_fwd(xa, (Hc * Wc * C, Wc * C, C, 1), pre + "conv.weight", None, N, Hc, Wc, C, 2)
+                x32, dm, dr = self._ln(yd, P, pre + "norm.1", out_dtype=F32)
+                xa = self._to_act(x32)
+                down = (colsd, yd, dm, dr)
+                geom_next = (Hn, Wn, 2 * C)
+            if save:
+                ctx["levels"].append(dict(layers=lctx, down=down, geom=(Hc, Wc, C, G)))
+            if i < len(m.depths) - 1:
+                Hc, Wc, C = geom_next
+        return feats, ctx
+
+    # ------------------------------------------------------------------ whole backward
+    def backward(self, ctx, dfeats, G, need_input_grad=False):
+        """dfeats: one NCHW cotangent (or None) per entry of out_indices; G: name -> f32 gradient buffer, zero on entry"""
+        m = self.m
+        P = self.P
+        img, cols1, y1, sm1, sr1, a1, cols2, y2, sm2, sr2, (N, Cin, H, W, H1, W1, H2, W2) = ctx["stem"]
+        self.dev = cols1.device
+        taps = {}
+        for idx, d in zip([i for i in range(len(m.depths)) if i in m.out_indices], dfeats):
+            taps[idx] = d
+        dx32 = None
+        for i in range(len(m.depths) - 1, -1, -1):
+            lv = ctx["levels"][i]
+            Hc, Wc, C, Gr = lv["geom"]
+            rows = N * Hc * Wc
+            if lv["down"] is not None and dx32 is not None:
+                # gradient arriving through the downsample of this level: LN -> conv3x3 s2 (no bias)
+                colsd, yd, dm, dr = lv["down"]
+                pre = "levels.%d.downsample." % i
+                dyd = self._ln_bwd(self._to_act(dx32), yd, dm, dr, P, G, pre + "norm.1")
+                dprev = self._e(rows, C, dtype=F32)
+                self._conv_bwd(dyd, colsd, pre + "conv.weight", G, None, dprev, (Hc * Wc * C, Wc * C, C, 1), N, Hc, Wc, C, 2)
+                dx32 = dprev
+            d = taps.get(i)
+            if d is not None:
+                d = d if (d.dtype in (F32, torch.bfloat16) and d.is_contiguous()) else d.float().contiguous()
+                if dx32 is None:
+                    dx32 = ops.nchw_to_tokens(d, self._e(rows, C, dtype=F32), N, Hc, Wc, 0)
+                else:
+                    ops.axpy(dx32, ops.nchw_to_tokens(d, self._e(rows, C, dtype=F32), N, Hc, Wc, 0))
+            if dx32 is None:      # nothing downstream of this level has a gradient
+                continue
+            for j in range(len(lv["layers"]) - 1, -1, -1):
+                dx32 = self._layer_bwd("levels.%d.blocks.%d." % (i, j), lv["layers"][j], dx32, N, Hc, Wc, C, Gr, G)
+                lv["layers"][j] = None
+        if dx32 is None:
+            return None
+        # ---- stem backward
+        c2 = m.channels // 2
+        dy2 = self._ln_bwd(self._to_act(dx32), y2, sm2, sr2, P, G, "patch_embed.norm2.1")
+        da1 = self._e(N * H1 * W1, c2, dtype=F32)
+        self._conv_bwd(dy2, cols2, "patch_embed.conv2.weight", G, "patch_embed.conv2.bias", da1, (H1 * W1 * c2, W1 * c2, c2, 1), N, H1, W1, c2, 2)
+        dy1 = self._ln_bwd(self._to_act(da1), y1, sm1, sr1, P, G, "patch_embed.norm1.1", gelu=True)
+        dimg = self._e(N, Cin, H, W, dtype=F32) if need_input_grad else None
+        self._conv_bwd(dy1, cols1, "patch_embed.conv1.weight", G, "patch_embed.conv1.bias", dimg, (Cin * H * W, W, 1, H * W), N, H, W, Cin, 2)
+        return dimg

@@ -52,29 +52,30 @@ def _f32(t):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-def _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sample, aux, variant):
+def _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sample, aux, variant, n=None):
     M, K = a.shape
-    N = w.shape[0]
-    assert w.shape[1] == K and tuple(out.shape) == (M, N) and a.dtype == w.dtype
+    N = w.shape[0] if n is None else n       # n: only the first n rows of w / columns of a wider `out` (row stride out.shape[1])
+    assert w.shape[1] == K and out.shape[0] == M and out.shape[1] >= N and w.shape[0] >= N and a.dtype == w.dtype
+    assert n is not None or out.shape[1] == N
     g = GemmArgs()
     g.A, g.B, g.C = _p(a), _p(w), _p(out)
     g.M, g.N, g.K = M, N, K
-    g.lda, g.ldb, g.ldc = K, K, N
+    g.lda, g.ldb, g.ldc = K, K, out.shape[1]
     g.in_dtype, g.out_dtype, g.epilogue = _dt(a), _dt(out), epi
     g.bias, g.bias_mod = _f32(bias), bias_mod
     g.res, g.res_ld, g.res_mod = _f32(res), (res.shape[-1] if res is not None else 0), res_mod
     g.rowscale, g.rows_per_sample = _f32(rowscale), rows_per_sample
     g.aux, g.aux_ld = _p(aux), (aux.shape[-1] if aux is not None else 0)
     if aux is not None:
-        assert aux.dtype == out.dtype and tuple(aux.shape) == (M, N)
+        assert aux.dtype == out.dtype and tuple(aux.shape) == (M, N) and out.shape[1] == N
     g.split_k, g.variant = 1, variant or _NT_VARIANT
     return g
 
 
 def gemm_nt(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_mod=0, rowscale=None, rows_per_sample=0,
-            aux=None, variant=0):
+            aux=None, variant=0, n=None):
     """out (M,N) = epilogue(a (M,K) @ w (N,K)^T)."""
-    g = _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sample, aux, variant)
+    g = _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sample, aux, variant, n)
     check(lib().mtp_gemm_nt(C.byref(g), _s()), "mtp_gemm_nt")
     return out
 
@@ -108,10 +109,15 @@ def effective_split_k(K, dtype, split):
     return -(-k_tiles // per)
 
 
-def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None, defer=None):
+def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None, defer=None, m=None):
     """out (M,N) f32 = a (K,M)^T @ b (K,N)   (weight gradient dW = dY^T X).
-    colsum (M,) f32, optional: colsum += a.sum(0) -- the bias gradient, produced by the same pass over dY."""
+    colsum (M,) f32, optional: colsum += a.sum(0) -- the bias gradient, produced by the same pass over dY.
+    m: use only the first m columns of a wider `a` (row stride a.shape[1])."""
     K, M = a.shape
+    lda = M
+    if m is not None:
+        assert m <= M
+        M = m
     N = b.shape[1]
     assert b.shape[0] == K and out.dtype == torch.float32 and out.numel() == M * N and a.dtype == b.dtype
     g = GemmArgs()
@@ -120,7 +126,7 @@ def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None,
         g.colsum = _p(colsum)
     g.A, g.B, g.C = _p(a), _p(b), _p(out)
     g.M, g.N, g.K = M, N, K
-    g.lda, g.ldb, g.ldc = M, N, N
+    g.lda, g.ldb, g.ldc = lda, N, N
     g.in_dtype, g.out_dtype, g.epilogue = _dt(a), MTP_F32, EPI_BIAS
     g.split_k = effective_split_k(K, a.dtype, pick_split_k(M, N, K) if split_k is None else split_k)
     g.variant = variant
@@ -500,3 +506,113 @@ def adamw_flat(p, g, m, v, seg_start, seg_wd, hyper, sqn=None, max_norm=0.0, gra
     assert seg_start.dtype == torch.int64 and seg_start.is_cuda
     check(lib().mtp_adamw_flat(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), seg_start.data_ptr(), _f32(seg_wd), seg_start.numel(),
                                _f32(hyper), _f32(sqn), max_norm, grad_scale, _s()), "mtp_adamw_flat")
+
+
+# ------------------------------------------------------------------------------------------------ InternImage layers (csrc/conv.hip)
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def conv_out(h, stride):
+    return (h - 1) // stride + 1
+
+
+def im2col3x3(x, strides, cols, N, H, W, Cin, stride):
+    """x: any tensor addressed by element strides (sN, sH, sW, sC); cols (N*Ho*Wo, Kp) ACT"""
+    Kp = cols.shape[1]
+    assert cols.shape[0] == N * conv_out(H, stride) * conv_out(W, stride) and Kp >= 9 * Cin
+    sN, sH, sW, sC = strides
+    if not x.is_cuda:
+        raise RuntimeError("mtp_amd ops run only on an MI355X device tensor (no CPU fallback)")
+    check(lib().mtp_im2col3x3(x.data_ptr(), _dt(x), sN, sH, sW, sC, _p(cols), _dt(cols), N, H, W, Cin, stride, Kp, _s()), "mtp_im2col3x3")
+    return cols
+
+
+def col2im3x3(dcols, dx, strides, N, H, W, Cin, stride, accumulate=False):
+    sN, sH, sW, sC = strides
+    assert dx.dtype == torch.float32 and dx.is_cuda
+    check(lib().mtp_col2im3x3(_p(dcols), _dt(dcols), dx.data_ptr(), sN, sH, sW, sC, N, H, W, Cin, stride, dcols.shape[1], int(accumulate), _s()), "mtp_col2im3x3")
+    return dx
+
+
+def conv3x3_pack(w, w2, w2t):
+    Cout, Cin = w.shape[:2]
+    img = w2 if w2 is not None else w2t
+    Kp = w2.shape[1] if w2 is not None else w2t.shape[0]
+    check(lib().mtp_conv3x3_pack(_f32(w), _p(w2), _p(w2t), _dt(img), Cout, Cin, Kp, _s()), "mtp_conv3x3_pack")
+
+
+def conv3x3_unpack_grad(dw2, dw):
+    Cout, Cin = dw.shape[:2]
+    check(lib().mtp_conv3x3_unpack_grad(_f32(dw2), _f32(dw), Cout, Cin, dw2.shape[1], _s()), "mtp_conv3x3_unpack_grad")
+    return dw
+
+
+def pack_rows_padded(w, wp, wpt):
+    R, Cc = w.shape
+    img = wp if wp is not None else wpt
+    Rp = wp.shape[0] if wp is not None else wpt.shape[1]
+    check(lib().mtp_pack_rows_padded(_f32(w), _p(wp), _p(wpt), _dt(img), R, Cc, Rp, _s()), "mtp_pack_rows_padded")
+
+
+def dwconv3x3_fwd(x, w, b, y, N, H, W):
+    check(lib().mtp_dwconv3x3_fwd(_p(x), _f32(w), _f32(b), _p(y), _dt(x), N, H, W, x.shape[-1], _s()), "mtp_dwconv3x3_fwd")
+    return y
+
+
+def dwconv3x3_bwd_dx(dy, w, dx, N, H, W, accumulate=False):
+    check(lib().mtp_dwconv3x3_bwd_dx(_p(dy), _dt(dy), _f32(w), _f32(dx), int(accumulate), N, H, W, dy.shape[-1], _s()), "mtp_dwconv3x3_bwd_dx")
+    return dx
+
+
+def dwconv3x3_bwd_dw(dy, x, dw, db, N, H, W, accumulate=False):
+    """dw (C,1,3,3) f32, db (C,) f32"""
+    Cc = dy.shape[-1]
+    nb = lib().mtp_dwconv3x3_bwd_dw_partial_rows(N, H, W)
+    part = torch.empty(nb, 10 * Cc, device=dy.device, dtype=torch.float32)
+    check(lib().mtp_dwconv3x3_bwd_dw(_p(dy), _p(x), _dt(dy), _p(part), N, H, W, Cc, _s()), "mtp_dwconv3x3_bwd_dw")
+    _reduce_pair(part, 9 * Cc, dw, db, accumulate)
+
+
+def softmax_groups_fwd(logits, prob, G, P):
+    rows = logits.shape[0]
+    check(lib().mtp_softmax_groups_fwd(_p(logits), logits.shape[1], _p(prob), _dt(logits), rows, G, P, _s()), "mtp_softmax_groups_fwd")
+    return prob
+
+
+def softmax_groups_bwd(prob, dprob, dlogits, G, P):
+    rows = dlogits.shape[0]
+    check(lib().mtp_softmax_groups_bwd(_p(prob), _f32(dprob), _p(dlogits), dlogits.shape[1], _dt(prob), rows, G, P, _s()), "mtp_softmax_groups_bwd")
+    return dlogits
+
+
+def scale_residual_fwd(x, z, gamma, out, out_act=None, sample_scale=None, rows_per_sample=0):
+    rows, Cc = x.shape
+    check(lib().mtp_scale_residual_fwd(_f32(x), _p(z), _dt(z), _f32(gamma), _f32(sample_scale), rows_per_sample, _f32(out), _p(out_act), rows, Cc, _s()),
+          "mtp_scale_residual_fwd")
+    return out
+
+
+def scale_residual_bwd(dout, z, gamma, dz, dgamma, sample_scale=None, rows_per_sample=0, accumulate=False):
+    rows, Cc = dout.shape
+    nb = lib().mtp_scale_residual_bwd_partial_rows(rows)
+    part = torch.empty(nb, Cc, device=dout.device, dtype=torch.float32)
+    check(lib().mtp_scale_residual_bwd(_f32(dout), _p(z), _dt(z), _f32(gamma), _f32(sample_scale), rows_per_sample, _p(dz), _p(part), rows, Cc, _s()),
+          "mtp_scale_residual_bwd")
+    reduce_rows(part, dgamma, accumulate)
+    return dz
+
+
+def cast_pad_rows(src, dst):
+    """src (rows, n) f32 -> dst (rows, ld >= n) ACT, columns n .. ld zero"""
+    rows, n = src.shape
+    assert dst.shape[0] == rows and dst.shape[1] >= n
+    check(lib().mtp_cast_pad_rows(_f32(src), n, _p(dst), _dt(dst), dst.shape[1], rows, _s()), "mtp_cast_pad_rows")
+    return dst
+
+
+def copy_rows(src, dst, n):
+    """dst[:, :n] = src[:, :n] (same dtype, 2-D contiguous buffers of different widths)"""
+    assert src.dtype == dst.dtype and src.shape[0] == dst.shape[0]
+    check(lib().mtp_copy_rows(_p(src), src.shape[1], _p(dst), dst.shape[1], _dt(src), n, src.shape[0], _s()), "mtp_copy_rows")
+    return dst

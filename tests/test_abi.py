@@ -56,7 +56,8 @@ def test_every_entry_point_rejects_null_arguments_before_launching():
     import ctypes as C
     from mtp_amd import _lib
     lib = _lib.load()
-    queries = {"mtp_version", "mtp_layernorm_bwd_partial_rows", "mtp_full_attn_bwd_workspace_floats"}
+    queries = {"mtp_version", "mtp_layernorm_bwd_partial_rows", "mtp_full_attn_bwd_workspace_floats", "mtp_dwconv3x3_bwd_dw_partial_rows",
+               "mtp_scale_residual_bwd_partial_rows"}
     for name, (_, argtypes) in sorted(_lib.SIGNATURES.items()):
         if name in queries:
             continue

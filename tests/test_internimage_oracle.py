@@ -48,3 +48,24 @@ def test_forward_and_gradients_vs_reference(dtype, tol_f, tol_g):
     for k in FIX.files:
         if k.startswith("grad."):
             assert rel(p[k[5:]].grad.double(), torch.from_numpy(FIX[k])) < tol_g, k
+
+
+def test_hip_backbone_class_has_the_reference_state_dict_and_init_rules():
+    """mtp_amd.InternImage (the HIP-side class, constructed on CPU): state-dict keys / shapes / order of the reference (fixture f12),
+    the XL factory's parameter count, the init rules of II:672-686 + DCNv3._reset_parameters, and loud refusal of what is not built"""
+    import mtp_amd
+    net = mtp_amd.InternImage(channels=CFG["channels"], depths=CFG["depths"], groups=CFG["groups"], layer_scale=CFG["layer_scale"],
+                              offset_scale=CFG["offset_scale"], post_norm=True)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in FIX["keys"]] and [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in FIX["shapes"]]
+    assert float(sd["levels.0.blocks.0.dcn.offset.weight"].abs().max()) == 0 and float(sd["levels.1.blocks.0.dcn.mask.bias"].abs().max()) == 0
+    assert torch.equal(sd["levels.2.blocks.1.gamma2"], torch.full((128,), CFG["layer_scale"])) and torch.equal(sd["levels.0.blocks.0.norm1.0.weight"], torch.ones(32))
+    assert float(sd["levels.0.blocks.0.mlp.fc1.weight"].abs().max()) <= 2.0 and 0.01 < float(sd["levels.0.blocks.0.mlp.fc1.weight"].std()) < 0.03
+    assert len(net.drop_path_rates) == sum(CFG["depths"]) and net.drop_path_rates[0] == 0.0 and abs(net.drop_path_rates[-1] - 0.2) < 1e-6
+    assert mtp_amd.MODELS.get("InternImage") is mtp_amd.InternImage
+    with pytest.raises(NotImplementedError):
+        mtp_amd.InternImage(layer_scale=1.0, post_norm=True, center_feature_scale=True)
+    with pytest.raises(NotImplementedError):
+        mtp_amd.InternImage(layer_scale=None, post_norm=False)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64, 64))          # no CPU path
