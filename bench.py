@@ -117,7 +117,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="vit_l", choices=["vit_l", "vit_b"])
+    ap.add_argument("--model", default="vit_l", choices=["vit_l", "vit_b", "internimage_xl"],
+                    help="internimage_xl = BASELINE configs[4]'s backbone (use --image-size 512 --batch 8 --no-cpu-baseline)")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,7 +158,14 @@ def main():
         use_ckpt = "False"
         precision = args.precision
     torch.manual_seed(2023)    # identical initial replicas (main_pretrain.py:107)
-    net = (mtp_amd.vit_l_rvsa if args.model == "vit_l" else mtp_amd.vit_b_rvsa)(A)
+    if args.model == "internimage_xl":
+        net = mtp_amd.internimage_xl(precision=args.precision)       # models.py:92-104 (drop_path 0.2)
+        with torch.no_grad():      # the zero-initialised offset / mask heads re-drawn so the sampling really deforms (as fixture f12 does)
+            for n, p in net.named_parameters():
+                if ".dcn.offset.weight" in n or ".dcn.mask.weight" in n:
+                    p.normal_(0, 0.02)
+    else:
+        net = (mtp_amd.vit_l_rvsa if args.model == "vit_l" else mtp_amd.vit_b_rvsa)(A)
     with torch.no_grad():      # zero-initialised tables re-drawn N(0, 0.02^2) so no branch is trivially zero
         for n, p in net.named_parameters():
             if "rel_pos" in n:
@@ -297,20 +305,23 @@ def main():
                         avg_launch_us=round(d["seconds"] / d["launches"] * 1e6, 1), launches_per_step=d["launches"] // args.steps,
                         families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / args.steps * 1e3, 2))
                                   for k, v in fams.items()})
-        gf = FWD_GF_PER_IMAGE[args.model] * 3.0
+        gf = FWD_GF_PER_IMAGE.get(args.model, 0.0) * 3.0
+        label = {"vit_l": "ViT-L + RVSA", "vit_b": "ViT-B + RVSA", "internimage_xl": "InternImage-XL (DCNv3)"}[args.model]
         out = {
-            "metric": ("images/sec pretrain step (ViT-L+RVSA, %d^2, bf16)" if args.model == "vit_l" else "images/sec pretrain step (ViT-B+RVSA, %d^2)") % args.image_size,
+            "metric": ("images/sec pretrain step (ViT-L+RVSA, %d^2, bf16)" if args.model == "vit_l" else "images/sec pretrain step (ViT-B+RVSA, %d^2)" if args.model == "vit_b"
+                       else "images/sec backbone train step (InternImage-XL, %d^2)") % args.image_size,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "%s + RVSA backbone fwd+bwd + grad all-reduce + clip + AdamW, %dx%d, batch %d per GPU%s"
-                                   % ("ViT-L" if args.model == "vit_l" else "ViT-B", args.image_size, args.image_size, B,
-                                      (" (BASELINE configs[2]/[3])" if args.model == "vit_l" and B == 64 else " (BASELINE configs[1])" if args.model == "vit_b" and B == 32 else "")
+            "config": {"workload": "%s backbone fwd+bwd + grad all-reduce + clip + AdamW, %dx%d, batch %d per GPU%s"
+                                   % (label, args.image_size, args.image_size, B,
+                                      " (BASELINE configs[4]'s backbone and tile size; stand-in loss instead of the segmentation decoder)" if args.model == "internimage_xl" and args.image_size == 512
+                                      else (" (BASELINE configs[2]/[3])" if args.model == "vit_l" and B == 64 else " (BASELINE configs[1])" if args.model == "vit_b" and B == 32 else "")
                                       if args.image_size == 224 else " (not the headline configuration)"),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss),
                        "heads": ("3 stand-in task heads (per-map 1x1 projection + mean each; the mm* decoders are not vendored)" if args.heads == "standin3"
                                  else "sum_i mean(f_i)")},
-            "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if args.image_size == 224 else None,
+            "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if (args.image_size == 224 and gf) else None,
             "roofline": roof,
         }
         if comm is not None:

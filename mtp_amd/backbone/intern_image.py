@@ -192,6 +192,24 @@ class InternImage(nn.Module):
             out = OrderedDict((k[7:], v) for k, v in out.items())
         return self.load_state_dict(out, strict=False)
 
+    # ------------------------------------------------------------------ data-parallel training hooks (mtp_amd.parallel)
+    _unused_params = frozenset()
+
+    def _flat_param_order(self):
+        """(names in reverse execution order, name -> group id, number of layer groups): group = global layer index; a level's
+        downsample completes together with the level's last layer; the stem is group -1 (mtp_amd.parallel.FlatParams)"""
+        base = [sum(self.depths[:i]) for i in range(self.num_levels + 1)]
+        groups = {}
+        for n, _ in self.named_parameters():
+            parts = n.split(".")
+            if parts[0] == "levels":
+                i = int(parts[1])
+                groups[n] = base[i] + int(parts[3]) if parts[2] == "blocks" else base[i + 1] - 1
+            else:
+                groups[n] = -1
+        names = sorted(groups, key=lambda k: -groups[k])        # stable: the module's order inside a group
+        return names, groups, base[-1]
+
     # ------------------------------------------------------------------ execution
     def _engine(self):
         from ..engine_intern import InternEngine

@@ -284,8 +284,10 @@ class InternEngine:
         return feats, ctx
 
     # ------------------------------------------------------------------ whole backward
-    def backward(self, ctx, dfeats, G, need_input_grad=False):
-        """dfeats: one NCHW cotangent (or None) per entry of out_indices; G: name -> f32 gradient buffer, zero on entry"""
+    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None):
+        """dfeats: one NCHW cotangent (or None) per entry of out_indices; G: name -> f32 gradient buffer, zero on entry.
+        on_block_done(g): every gradient of layer group g (global layer index; InternImage._flat_param_order) and of all later layers is
+        complete on the current stream; -1 = the stem (mtp_amd.parallel.GradReducer launches the all-reduces from it)."""
         m = self.m
         P = self.P
         img, cols1, y1, sm1, sr1, a1, cols2, y2, sm2, sr2, (N, Cin, H, W, H1, W1, H2, W2) = ctx["stem"]
@@ -318,6 +320,8 @@ class InternEngine:
             for j in range(len(lv["layers"]) - 1, -1, -1):
                 dx32 = self._layer_bwd("levels.%d.blocks.%d." % (i, j), lv["layers"][j], dx32, N, Hc, Wc, C, Gr, G)
                 lv["layers"][j] = None
+                if on_block_done is not None:
+                    on_block_done(sum(m.depths[:i]) + j)
         if dx32 is None:
             return None
         # ---- stem backward
@@ -328,4 +332,6 @@ class InternEngine:
         dy1 = self._ln_bwd(self._to_act(da1), y1, sm1, sr1, P, G, "patch_embed.norm1.1", gelu=True)
         dimg = self._e(N, Cin, H, W, dtype=F32) if need_input_grad else None
         self._conv_bwd(dy1, cols1, "patch_embed.conv1.weight", G, "patch_embed.conv1.bias", dimg, (Cin * H * W, W, 1, H * W), N, H, W, Cin, 2)
+        if on_block_done is not None:
+            on_block_done(-1)
         return dimg

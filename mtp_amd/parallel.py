@@ -45,8 +45,11 @@ def execution_order(names, depth):
 class FlatParams:
     def __init__(self, module, unused=()):
         params = dict(module.named_parameters())
-        depth = len(module.blocks)
-        order, groups = execution_order(list(params), depth)
+        if hasattr(module, "_flat_param_order"):        # backbones with another layer structure (InternImage) supply their own grouping
+            order, groups, depth = module._flat_param_order()
+        else:
+            depth = len(module.blocks)
+            order, groups = execution_order(list(params), depth)
         for n in unused:
             groups[n] = None
         order = [n for n in order if groups[n] is not None] + [n for n in order if groups[n] is None]

@@ -69,3 +69,21 @@ def test_hip_backbone_class_has_the_reference_state_dict_and_init_rules():
         mtp_amd.InternImage(layer_scale=None, post_norm=False)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 64, 64))          # no CPU path
+
+
+def test_flat_gradient_layout_follows_the_backward_order_of_the_levels():
+    """mtp_amd.parallel.FlatParams over InternImage: parameters in reverse execution order (last level first, a level's downsample
+    with its last layer, the stem last), so that what the backward has finished is always a prefix of the flat gradient buffer"""
+    import mtp_amd
+    from mtp_amd.parallel import FlatParams
+    net = mtp_amd.InternImage(channels=CFG["channels"], depths=CFG["depths"], groups=CFG["groups"], layer_scale=CFG["layer_scale"],
+                              offset_scale=CFG["offset_scale"], post_norm=True)
+    flat = FlatParams(net, unused=net._unused_params)
+    gids = [flat.groups[n] for n in flat.names]
+    assert gids == sorted(gids, reverse=True) and gids[0] == sum(CFG["depths"]) - 1 and gids[-1] == -1
+    assert flat.groups["levels.1.downsample.conv.weight"] == flat.groups["levels.1.blocks.0.mlp.fc1.weight"] == 1
+    assert flat.names[-1].startswith("patch_embed") and flat.reduced == flat.total
+    b = flat.buckets(1 << 12)
+    assert b[0][1] == 0 and b[-1][2] == flat.total and all(x[2] == y[1] for x, y in zip(b, b[1:]))
+    # parameters now live in the flat buffer (views), values unchanged
+    assert net.state_dict()["levels.0.blocks.0.gamma1"].data_ptr() == flat.view(flat.data, "levels.0.blocks.0.gamma1").data_ptr()
