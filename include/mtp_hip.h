@@ -71,7 +71,8 @@ typedef struct {
                          * double-buffered / TN single-stage; bit4 TN register-transposing; bit5 / bit6 force / forbid
                          * the 256x128 8-wave NT tile; bit7 NT at 5 workgroups per CU (complete tiles only); bits8-9 the
                          * 8-wave pipelined NT kernel (1 = tile height picked per problem, 2 = 224 x 256 tiles, 3 = 256 x 256 tiles),
-                         * bit10 forbids it.  All variants of one problem give bit-identical results. */
+                         * bit10 forbids it; bits11-14 ablation builds of it (tools/ab_gemm.py); bit15 / bit16 force / forbid its
+                         * persistent-tile form.  All variants of one problem give bit-identical results. */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
     int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them

@@ -238,6 +238,120 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
     }
 }
 
+// The same epilogue through a SMALL private region (4 KiB per wave = 16 rows x 64 f32), for the persistent NT kernel: the ring is
+// already being refilled with the next tile's first K-tiles while this runs.  The wave's block is `ROWS` consecutive rows x 64
+// columns; side inputs are loaded 8 wave instructions (64 / 32 rows) ahead as above.
+template <typename Tout, int EPI, int ROWS>
+__device__ __forceinline__ void epilogue_lds16(const KArgs& p, f32x4_t (&acc)[4][8], char* wsm, int mrow0, int ncol0, int lane) {
+    const int fr = lane & 15, g = lane >> 4;
+    constexpr bool WIDE = sizeof(Tout) == 2;
+    constexpr int RSTEP = WIDE ? 8 : 4, NV = WIDE ? 8 : 4, IPP = 16 / RSTEP, PPB = 8 / IPP, NP = ROWS / 16;
+    const int cg = WIDE ? (lane & 7) : (lane & 15);
+    const int rsub = WIDE ? (lane >> 3) : (lane >> 4);
+    const int n = ncol0 + cg * NV;
+    const bool nok = n < p.N;
+    const int nc = nok ? n : 0;
+    float bias[NV];
+#pragma unroll
+    for (int q = 0; q < NV / 4; ++q) {
+        const int nb = nc + 4 * q;
+        const float* bp = (EPI != MTP_EPI_DGELU && EPI != MTP_EPI_MUL && p.bias) ? p.bias + (p.bias_mod > 0 ? nb % p.bias_mod : nb) : reinterpret_cast<const float*>(&g_zero16);
+        const float4 b = ld4f(bp);
+        bias[4 * q + 0] = b.x; bias[4 * q + 1] = b.y; bias[4 * q + 2] = b.z; bias[4 * q + 3] = b.w;
+    }
+    Tout* C = reinterpret_cast<Tout*>(p.C);
+#pragma unroll
+    for (int b0 = 0; b0 < NP; b0 += PPB) {
+        const int mb = mrow0 + 16 * b0 + rsub;     // rows mb + it * RSTEP, it = 0 .. 7
+        float4 side[(EPI == MTP_EPI_BIAS_RES) ? 8 : 1];
+        uint4 sideb[(EPI == MTP_EPI_DGELU || EPI == MTP_EPI_MUL) ? 8 : 1];
+        float rsv[(EPI == MTP_EPI_BIAS_RES) ? 8 : 1];
+        if constexpr (EPI == MTP_EPI_BIAS_RES) {
+            const int mc0 = mb < p.M ? mb : p.M - 1;
+            int smp = mc0 / p.rows_per_sample, srem = mc0 - smp * p.rows_per_sample;
+            int rrow = p.res_mod > 0 ? mc0 % p.res_mod : mc0;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                side[it] = ld4f(p.res + (int64_t)rrow * p.res_ld + nc);
+                rsv[it] = p.rowscale ? p.rowscale[smp] : 1.0f;
+                if (mb + (it + 1) * RSTEP < p.M) {
+                    srem += RSTEP;
+                    while (srem >= p.rows_per_sample) { srem -= p.rows_per_sample; ++smp; }
+                    rrow += RSTEP;
+                    if (p.res_mod > 0) while (rrow >= p.res_mod) rrow -= p.res_mod;
+                }
+            }
+        } else if constexpr (EPI == MTP_EPI_DGELU || EPI == MTP_EPI_MUL) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int m = mb + it * RSTEP;
+                m = m < p.M ? m : p.M - 1;
+                sideb[it] = ldg16(reinterpret_cast<const Tout*>(p.aux) + (int64_t)m * p.aux_ld + nc);
+            }
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPB; ++pp) {
+            const int mfl = b0 + pp;
+            if (mfl < NP) {
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                    *reinterpret_cast<f32x4_t*>(wsm + fr * 256 + (((nf * 4 + g) ^ (fr & 7)) << 4)) = acc[nf][mfl];
+#pragma unroll
+                for (int i = 0; i < IPP; ++i) {
+                    const int it = pp * IPP + i;
+                    const int r = i * RSTEP + rsub;
+                    const int m = mb + it * RSTEP;
+                    const bool ok = nok && m < p.M;
+                    float v[NV];
+                    if constexpr (WIDE) {
+                        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(wsm + r * 256 + (((2 * cg) ^ (r & 7)) << 4));
+                        const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(wsm + r * 256 + (((2 * cg + 1) ^ (r & 7)) << 4));
+                        v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3]; v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
+                    } else {
+                        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(wsm + r * 256 + ((cg ^ (r & 7)) << 4));
+                        v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3];
+                    }
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) v[e] += bias[e];
+                    if constexpr (EPI == MTP_EPI_BIAS_GELU) {
+                        if (ok) store8(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, v);
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) v[e] = gelu_f(v[e]);
+                    } else if constexpr (EPI == MTP_EPI_BIAS_GELU_DG) {
+                        float d[NV];
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) gelu_pair_f(v[e], v[e], d[e]);
+                        if (ok) store8(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, d);
+                    } else if constexpr (EPI == MTP_EPI_DGELU) {
+                        const uint32_t w[4] = {sideb[it].x, sideb[it].y, sideb[it].z, sideb[it].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] *= dgelu_f(bf16_bits_to_f32(w[e] & 0xffffu));
+                            v[2 * e + 1] *= dgelu_f(bf16_bits_to_f32(w[e] >> 16));
+                        }
+                    } else if constexpr (EPI == MTP_EPI_MUL) {
+                        const uint32_t w[4] = {sideb[it].x, sideb[it].y, sideb[it].z, sideb[it].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] *= bf16_bits_to_f32(w[e] & 0xffffu);
+                            v[2 * e + 1] *= bf16_bits_to_f32(w[e] >> 16);
+                        }
+                    } else if constexpr (EPI == MTP_EPI_BIAS_RES) {
+                        v[0] = side[it].x + rsv[it] * v[0]; v[1] = side[it].y + rsv[it] * v[1];
+                        v[2] = side[it].z + rsv[it] * v[2]; v[3] = side[it].w + rsv[it] * v[3];
+                    }
+                    if (ok) {
+                        if constexpr (WIDE)
+                            store8(C + (int64_t)m * p.ldc + n, v);
+                        else
+                            store4(C + (int64_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+                    }
+                }
+            }
+        }
+    }
+}
+
 // tile index -> (tile row, tile column): panels of 8 tile rows, rows fastest inside a panel (the 32 tiles an XCD runs at a
 // time cover 8 rows x 4 columns: 12 operand panels for 32 tiles)
 __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int plain, int& tm, int& tn) {

@@ -111,7 +111,53 @@ struct NtOps {
 // MI1 = 4: 256 x 256 tile; MI1 = 3: 224 x 256 tile (wave rows of 112 = 64 + 48 rows).  M = 12544 tokens = 49 x 256 = 56 x 224: with
 // 256-row tiles every ViT-L shape runs 0.766 of a whole number of rounds on the 256 CUs (196 / 588 / 784 tiles), with 224-row tiles
 // 0.875 (224 / 672 / 896) at 7/8 of the time per tile -- the host picks the cheaper one per problem (p8_pick_bm).
-template <typename Tout, int EPI, int MI1, int XP>
+// DMA source rows of this wave for output tile (m0, n0).  Piece q = 2 * wave + i holds rows [8q, 8q + 8) of the half tile image.
+//   A-half 0 (64 rows per wave row): image row 64 wr' + x  <->  tile row WROWS wr' + x         (wr' = q >> 3)
+//   A-half 1 (16 MI1 rows per wave row): image row 16 MI1 wr' + x  <->  tile row WROWS wr' + 64 + x; at MI1 = 3 the last four
+//     pieces (waves 6, 7) are past the 96 image rows: they fetch a valid row into the unused tail of the 16-KiB slot, so
+//     that every wave still issues two DMA instructions per half tile (the counted waits rely on it)
+//   B-half h: image row 32 wc' + x  <->  tile column 64 wc' + 32 h + x                             (wc' = q >> 2)
+// Rows past the matrix edge are clamped to the last complete 8-row piece (their outputs are never stored).
+template <int MI1>
+__device__ __forceinline__ void p8_tile_sources(const KArgs& p, P8Ctx& c, int wave, int m0, int n0, uint32_t voffA0, uint32_t voffB0) {
+    constexpr int WROWS = 64 + 16 * MI1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 2 + i;
+        int ra0 = m0 + (q >> 3) * WROWS + (q & 7) * 8;
+        const int qw = q / (2 * MI1), qx = q - qw * (2 * MI1);
+        int ra1 = qw < 2 ? m0 + qw * WROWS + 64 + qx * 8 : m0;
+        ra0 = ra0 < p.M - 8 ? ra0 : p.M - 8;
+        ra1 = ra1 < p.M - 8 ? ra1 : p.M - 8;
+        c.pA[0][i] = p.A + (int64_t)ra0 * p.lda * 2;
+        c.pA[1][i] = p.A + (int64_t)ra1 * p.lda * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int rb = n0 + (q >> 2) * 64 + h * 32 + (q & 3) * 8;
+            rb = rb < p.N - 8 ? rb : p.N - 8;
+            c.pB[h][i] = p.B + (int64_t)rb * p.ldb * 2;
+        }
+    }
+    c.voffA = voffA0;
+    c.voffB = voffB0;
+}
+// prologue: S_0 .. S_7 = B1 A0 B0 A1 of K-tile 0 (buffer 0), B0 A0 B1 A1 of K-tile 1 (buffer 1)
+__device__ __forceinline__ void p8_issue_prologue(P8Ctx& c) {
+    nt_stage<KB1, 0>(c); nt_stage<KA0, 0>(c); nt_stage<KB0, 0>(c); nt_stage<KA1, 0>(c);
+    c.voffA += 128; c.voffB += 128;
+    nt_stage<KB0, 1>(c); nt_stage<KA0, 1>(c); nt_stage<KB1, 1>(c); nt_stage<KA1, 1>(c);
+    c.voffA += 128; c.voffB += 128;
+}
+
+// MI1 = 4: 256 x 256 tile; MI1 = 3: 224 x 256 tile (wave rows of 112 = 64 + 48 rows).  M = 12544 tokens = 49 x 256 = 56 x 224: with
+// 256-row tiles every ViT-L shape runs 0.766 of a whole number of rounds on the 256 CUs (196 / 588 / 784 tiles), with 224-row tiles
+// 0.875 (224 / 672 / 896) at 7/8 of the time per tile -- the host picks the cheaper one per problem (p8_pick_bm).
+// PS = 1: persistent -- gridDim.x workgroups (one per CU) walk the tiles t = blockIdx.x, + gridDim.x, ...; when a tile's main loop
+// ends, the NEXT tile's first two K-tiles are issued into the (now idle) ring before the epilogue runs, and the epilogue transposes
+// through 4 KiB per wave beyond the ring: the first-load latency of a tile and the workgroup hand-over are hidden behind the
+// previous tile's stores.  The load queue is drained (vmcnt(0)) once per tile, after the epilogue: the counted waits of the main
+// loop assume that only the DMA stream is in flight.
+template <typename Tout, int EPI, int MI1, int XP, int PS>
 __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_p8_kernel(KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WROWS = 64 + 16 * MI1, BM = 2 * WROWS;      // rows per wave row, rows per tile
@@ -143,50 +189,21 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const uint32_t voffA0 = (uint32_t)((lane >> 3) * (int)p.lda * 2) + lanesrc;
     const uint32_t voffB0 = (uint32_t)((lane >> 3) * (int)p.ldb * 2) + lanesrc;
 
-    {
-        const int vb = blockIdx.x;
-        int tm, tn;
-        tile_coords(plain ? vb : xcd_remap(vb, ntiles), tiles_m, tiles_n, plain, tm, tn);
-        const int m0 = tm * BM, n0 = tn * P8_BN;
-        // DMA source rows of this wave.  Piece q = 2 * wave + i holds rows [8q, 8q + 8) of the half tile image.
-        //   A-half 0 (64 rows per wave row): image row 64 wr' + x  <->  tile row WROWS wr' + x         (wr' = q >> 3)
-        //   A-half 1 (16 MI1 rows per wave row): image row 16 MI1 wr' + x  <->  tile row WROWS wr' + 64 + x; at MI1 = 3 the last four
-        //     pieces (waves 6, 7) are past the 96 image rows: they fetch a valid row into the unused tail of the 16-KiB slot, so
-        //     that every wave still issues two DMA instructions per half tile (the counted waits rely on it)
-        //   B-half h: image row 32 wc' + x  <->  tile column 64 wc' + 32 h + x                             (wc' = q >> 2)
-        // Rows past the matrix edge are clamped to the last complete 8-row piece (their outputs are never stored).
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = wave * 2 + i;
-            int ra0 = m0 + (q >> 3) * WROWS + (q & 7) * 8;
-            const int qw = q / (2 * MI1), qx = q - qw * (2 * MI1);
-            int ra1 = qw < 2 ? m0 + qw * WROWS + 64 + qx * 8 : m0;
-            ra0 = ra0 < p.M - 8 ? ra0 : p.M - 8;
-            ra1 = ra1 < p.M - 8 ? ra1 : p.M - 8;
-            c.pA[0][i] = p.A + (int64_t)ra0 * p.lda * 2;
-            c.pA[1][i] = p.A + (int64_t)ra1 * p.lda * 2;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                int rb = n0 + (q >> 2) * 64 + h * 32 + (q & 3) * 8;
-                rb = rb < p.N - 8 ? rb : p.N - 8;
-                c.pB[h][i] = p.B + (int64_t)rb * p.ldb * 2;
-            }
-        }
-        c.voffA = voffA0;
-        c.voffB = voffB0;
+    int tile = blockIdx.x;
+    int tm, tn;
+    tile_coords(plain ? tile : xcd_remap(tile, ntiles), tiles_m, tiles_n, plain, tm, tn);
+    int m0 = tm * BM, n0 = tn * P8_BN;
+    p8_tile_sources<MI1>(p, c, wave, m0, n0, voffA0, voffB0);
+    p8_issue_prologue(c);
 
-        u32x4_t a[2][4], b0[2][2], b1[2][2];
-        f32x4_t acc[4][8];
+    u32x4_t a[2][4], b0[2][2], b1[2][2];
+    f32x4_t acc[4][8];
+    for (;;) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-        // ---- prologue: S_0 .. S_7 = B1 A0 B0 A1 of tile 0 (buffer 0), B0 A0 B1 A1 of tile 1 (buffer 1)
-        nt_stage<KB1, 0>(c); nt_stage<KA0, 0>(c); nt_stage<KB0, 0>(c); nt_stage<KA1, 0>(c);
-        c.voffA += 128; c.voffB += 128;
-        nt_stage<KB0, 1>(c); nt_stage<KA0, 1>(c); nt_stage<KB1, 1>(c); nt_stage<KA1, 1>(c);
-        c.voffA += 128; c.voffB += 128;
         wait_vm<12>();   // S_0, S_1 have landed (this lane's pieces)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -205,11 +222,29 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if (!(XP & 2) && wr == 0) __builtin_amdgcn_s_barrier();   // re-align: every wave has finished its last phase behind this barrier
         __builtin_amdgcn_sched_barrier(0);
 
-        if (!(XP & 4) || p.M < 0) {
-            if constexpr (XP & 16)   // A/B: straight out of the MFMA layout (the epilogue of the 128-wide kernels)
-                epilogue<Tout, EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-            else
-                epilogue_lds<Tout, EPI, 64, 32, WROWS>(p, acc, smem + wave * P8_HALF, m0 + wr * WROWS, n0 + wc * 64, lane);
+        if constexpr (PS) {
+            const int em0 = m0, en0 = n0;
+            tile += gridDim.x;
+            const bool more = tile < ntiles;
+            if (more) {   // the ring is idle: the next tile's first two K-tiles go out before this tile's stores
+                tile_coords(plain ? tile : xcd_remap(tile, ntiles), tiles_m, tiles_n, plain, tm, tn);
+                m0 = tm * BM; n0 = tn * P8_BN;
+                p8_tile_sources<MI1>(p, c, wave, m0, n0, voffA0, voffB0);
+                p8_issue_prologue(c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_lds16<Tout, EPI, WROWS>(p, acc, smem + P8_LDS + wave * 4096, em0 + wr * WROWS, en0 + wc * 64, lane);
+            if (!more) break;
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm<0>();   // stores and side loads of the epilogue retired: only the DMA stream is counted from here on
+        } else {
+            if (!(XP & 4) || p.M < 0) {
+                if constexpr (XP & 16)   // A/B: straight out of the MFMA layout (the epilogue of the 128-wide kernels)
+                    epilogue<Tout, EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+                else
+                    epilogue_lds<Tout, EPI, 64, 32, WROWS>(p, acc, smem + wave * P8_HALF, m0 + wr * WROWS, n0 + wc * 64, lane);
+            }
+            break;
         }
     }
 }
@@ -225,15 +260,17 @@ int p8_cus() {
     return ncu;
 }
 
-template <typename Tout, int EPI, int MI1, int XP>
+template <typename Tout, int EPI, int MI1, int XP, int PS = 0>
 int launch_p8_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
-    static bool attr = false;   // 128 KiB of dynamic LDS needs the opt-in once per kernel
+    constexpr int LDS = P8_LDS + (PS ? 8 * 4096 : 0);
+    static bool attr = false;   // 128 / 160 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP>), dim3(ntiles), dim3(P8_THREADS), P8_LDS, stream, a);
+    const int grid = PS ? (ntiles < p8_cus() ? ntiles : p8_cus()) : ntiles;
+    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS>), dim3(grid), dim3(P8_THREADS), LDS, stream, a);
     return mtp_launch_status();
 }
 
@@ -266,6 +303,14 @@ int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
             case 15: return launch_p8_kernel<Tout, EPI, 4, 16>(a, ntiles, stream);   // (the variant field is 4 bits wide: 15 = direct epilogue)
             default: return MTP_ERR_UNSUPPORTED;
         }
+    }
+    // persistent tiles: default for problems of more than one round of 224-row tiles (measured, tools/ab_gemm.py: +3...4 % at N = 3072 /
+    // 4096, K = 1024 and on the FPN GEMM, nothing to gain on one-round problems; the 256-row instantiations spill 2-17 VGPRs with the
+    // second tile loop and stay opt-in).  variant bit 15 forces it, bit 16 forbids it (A/B).
+    const bool persist = (flags & 256) || (!(flags & 512) && bm == 224 && ntiles > p8_cus());
+    if (persist) {
+        if (bm == 224) return launch_p8_kernel<Tout, EPI, 3, 0, 1>(a, ntiles, stream);
+        return launch_p8_kernel<Tout, EPI, 4, 0, 1>(a, ntiles, stream);
     }
     if (bm == 224) return launch_p8_kernel<Tout, EPI, 3, 0>(a, ntiles, stream);
     return launch_p8_kernel<Tout, EPI, 4, 0>(a, ntiles, stream);

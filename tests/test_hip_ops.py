@@ -115,7 +115,10 @@ P8_SHAPES = [(256, 256, 128),      # one tile, the shortest pipeline (one K-tile
              (1568, 2304, 1024)]   # more tiles than a quick run has CUs busy: several rounds / persistent tile loop
 
 
-@pytest.mark.parametrize("variant", [256, 512, 768, 514])
+PS = 32768       # variant bit 15: persistent tiles (the next tile's first K-tiles are issued before the epilogue of the current one)
+
+
+@pytest.mark.parametrize("variant", [256, 512, 768, 514, 512 + PS, 768 + PS])
 @pytest.mark.parametrize("M,N,K", P8_SHAPES)
 def test_gemm_nt_p8_vs_oracle(ops, variant, M, N, K):
     dtype = torch.bfloat16
@@ -157,7 +160,7 @@ def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
         return u, h, r, d, f, dg, h2, mu
     ref = run(1024)
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
-    for v in (512, 768):
+    for v in (512, 768, 512 + PS, 768 + PS):
         for rep in range(4):
             for x, y in zip(ref, run(v)):
                 assert torch.equal(x, y), (v, rep)
@@ -171,7 +174,7 @@ def test_gemm_nt_p8_vit_l_shapes_race_screen(ops):
     for (N, K) in [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C), (C, 3 * C)]:
         a, w, b = dev(rnd(T, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.05), dtype), dev(rnd(N, seed=2))
         ref = ops.gemm_nt(a, w, e(T, N, dtype=dtype), bias=b, variant=1024)
-        for v in (512, 768):
+        for v in (512, 768, 512 + PS, 768 + PS):
             out = e(T, N, dtype=dtype)
             for rep in range(6):
                 out.zero_()

@@ -13,7 +13,7 @@ from mtp_amd import ops
 from tools.bench_ops import r
 
 T, C = 12544, 1024
-NAMES = {1024: "w128", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
+NAMES = {1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
          256 + (3 << 11): "p8-noprio-nostagger", 256 + (4 << 11): "p8-nostore", 256 + (8 << 11): "p8-nomfma", 256 + (12 << 11): "p8-nomfma-nostore", 256 + (15 << 11): "p8-direct-epi"}
 
 
@@ -53,7 +53,7 @@ def main():
         okv = {}
         iters = 10 if M > T else 20
         for v in variants:
-            if v not in (1024, 256, 512, 768, 258) and epi != "bias":
+            if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536) and epi != "bias":
                 continue
             out.zero_()
             ops.gemm_nt(a, w, out, variant=v, **kw)
