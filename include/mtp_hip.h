@@ -118,6 +118,8 @@ int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
 /* out[c] (+)= sum_r part[r * ld + c], c < C   (per-workgroup partials -> parameter gradient; ld >= C lets one
  * partial buffer feed several parameters) */
 int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);
+/* the same, result transposed: part (rows, R*C) f32, column a*C + b is summed into out[b*R + a] (out is (C, R)) */
+int mtp_reduce_rows_t_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t R, int64_t C, int accumulate, mtp_stream_t stream);
 /* bias gradient: out[n] = sum_m dY[m][n] */
 int mtp_colsum(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream);
 /* same, accumulating: out[n] += ... (no clearing pass; used with a gradient buffer that is zeroed once per step) */

@@ -173,6 +173,20 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     atomicAdd(out + c, s);
 }
 
+// the same with a transposed result: column j = a * C + b of part (rows, R * C) goes to out[b * R + a] (per-(window, head) partials of
+// the (169, heads) bias-table gradient are written head-major by the RVSA backward: contiguous per workgroup)
+__global__ __launch_bounds__(256) void reduce_rows_t_kernel(const float* __restrict__ part, int64_t ld, float* __restrict__ out, int64_t rows, int R, int C, int64_t rows_per_block) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= (int64_t)R * C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += part[r * ld + j];
+    const int a = (int)(j / C), b = (int)(j - (int64_t)a * C);
+    atomicAdd(out + (int64_t)b * R + a, s);
+}
+
 // bias gradient: column sums of dY (M, N).  Block = 64 columns-of-4 x 4 row-lanes; grid.y splits the rows; f32 atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, int64_t ld, float* __restrict__ out, int64_t M, int64_t N, int64_t rows_per_block) {
@@ -299,6 +313,23 @@ extern "C" int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, in
     const int64_t rpb = (rows + splits - 1) / splits;
     splits = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)col_blocks, (unsigned)splits), dim3(256), 0, s, part, ld, out, rows, C, rpb);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_reduce_rows_t_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t R, int64_t C, int accumulate, mtp_stream_t stream) {
+    if (!part || !out || rows <= 0 || R <= 0 || C <= 0 || ld < R * C) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)(R * C), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int64_t col_blocks = (R * C + 255) / 256;
+    int64_t splits = 1024 / col_blocks;
+    if (splits < 1) splits = 1;
+    if (splits > rows) splits = rows;
+    const int64_t rpb = (rows + splits - 1) / splits;
+    splits = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(reduce_rows_t_kernel, dim3((unsigned)col_blocks, (unsigned)splits), dim3(256), 0, s, part, ld, out, rows, (int)R, (int)C, rpb);
     return mtp_launch_status();
 }
 

@@ -488,11 +488,9 @@ def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, dre
     check(lib().mtp_rvsa_attn_bwd(_p(qkv), _f32(samp), _p(o), _p(dout), _f32(lse), _p(dqkv), _p(dkv), _f32(dsamp), _p(rel_part), _p(tab_part),
                                   _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table), B, Hp, Wp, heads, hd, scale, _s()), "mtp_rvsa_attn_bwd")
     _reduce_pair(rel_part, 13 * hd, drel_h, drel_w, accumulate)   # per-workgroup partials -> the parameters, no staging copies
-    tsum = reduce_rows(tab_part, torch.empty(heads * 169, device=dev, dtype=torch.float32))   # sum over the windows -> (heads, 169)
-    if accumulate:
-        dtable.add_(tsum.view(heads, 169).t())       # the parameter is (169, heads)
-    else:
-        dtable.copy_(tsum.view(heads, 169).t())
+    # per-(window, head) partials (heads, 169) -> the (169, heads) parameter gradient: one launch, transposed on the way
+    check(lib().mtp_reduce_rows_t_f32(_p(tab_part), tab_part.shape[1], _f32(dtable), tab_part.shape[0], heads, 169, int(accumulate), _s()),
+          "mtp_reduce_rows_t_f32")
     return dqkv
 
 
