@@ -18,8 +18,6 @@
 
 namespace {
 
-constexpr int KB = 128;             // keys per block (dq kernel)
-constexpr int KTP = KB * 2 + 8;     // byte pitch of the K^T image
 constexpr int QTP = 40;             // byte pitch of the per-wave transposed 16-query tile [d][16 q]
 constexpr int QBP = 64 * 2 + 8;     // byte pitch of the Q^T / dO^T images (dkv kernel)
 
@@ -88,16 +86,18 @@ __global__ __launch_bounds__(256) void flash_prep_kernel(const bf16_t* __restric
 // dynamic LDS: Ks | Vs (KB x 128 B) | Kt[64][KTP] | E[(1 + WT)][4][64] x 16 B | bias[64][HWP] f32 | dbias[64][HWP] f32 |
 //              Qtt[4 waves][64][QTP] | kpos[KB] u32 | qpos[64] u32
 // ===================================================================================================================
+template <int KB>      // keys per block: 128, or 64 when that lets two workgroups share a CU
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dqkv, const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                           const float* __restrict__ bias_g, const float* __restrict__ delta_g, float* __restrict__ drel_part,
                                                           FlashGeom g, float scale) {
+    constexpr int KTP = KB * 2 + 8;     // byte pitch of the K^T image
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* Ks = sm;
     char* Vs = Ks + KB * 128;
     char* Kt = Vs + KB * 128;
     char* Eimg = Kt + 64 * KTP;
-    float* bias = reinterpret_cast<float*>(Eimg + (1 + g.WT) * 4 * 64 * 16);
+    float* bias = reinterpret_cast<float*>(Eimg + (1 + g.WT) * (KB / 32) * 64 * 16);
     float* dbias = bias + 64 * g.HWP;
     char* Qttall = reinterpret_cast<char*>(dbias + 64 * g.HWP);
     uint32_t* kpos = reinterpret_cast<uint32_t*>(Qttall + 4 * 64 * QTP);
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
         __syncthreads();
         // 0/1 indicator operands in the MFMA A layout, key order of the dS^T fragments: E[0][a][key] = (row(key) - kh0 == a),
         // E[1 + wt][a][key] = (col(key) == 16 wt + a).  sum_k E[a][k] dS^T[k][q] = the bias-row gradient of query q.
-        for (int idx = tid; idx < (1 + g.WT) * 4 * 64; idx += 256) {
-            const int t = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63, a = l & 15, gl = l >> 4;
+        for (int idx = tid; idx < (1 + g.WT) * (KB / 32) * 64; idx += 256) {
+            const int t = idx / ((KB / 32) * 64), kk = (idx >> 6) % (KB / 32), l = idx & 63, a = l & 15, gl = l >> 4;
             const uint4 k0 = *reinterpret_cast<const uint4*>(kpos + 32 * kk + 4 * gl), k1 = *reinterpret_cast<const uint4*>(kpos + 32 * kk + 16 + 4 * gl);
             const uint32_t kp[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
             const uint32_t want = t == 0 ? (uint32_t)a : (uint32_t)(16 * (t - 1) + a);
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
         }
         __syncthreads();
 
-        f32x4_t dsT[8];
+        f32x4_t dsT[KB / 16];
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
+        for (int kt = 0; kt < KB / 16; ++kt) {
             f32x4_t sT = {0.f, 0.f, 0.f, 0.f}, dpT = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
 #pragma unroll
         for (int wt = 0; wt < 4; ++wt) dqw[wt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KB / 32; ++kk) {
             const uint4 dsf = pack_bf16x8(dsT[2 * kk][0], dsT[2 * kk][1], dsT[2 * kk][2], dsT[2 * kk][3],
                                           dsT[2 * kk + 1][0], dsT[2 * kk + 1][1], dsT[2 * kk + 1][2], dsT[2 * kk + 1][3]);
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
             dqh = mma(ld16(Eimg + (kk * 64 + lane) * 16), dsf, dqh);      // D[relative key row 4gq + r][query fr]
 #pragma unroll
             for (int wt = 0; wt < 4; ++wt)
-                if (wt < g.WT) dqw[wt] = mma(ld16(Eimg + (((1 + wt) * 4 + kk) * 64 + lane) * 16), dsf, dqw[wt]);
+                if (wt < g.WT) dqw[wt] = mma(ld16(Eimg + (((1 + wt) * (KB / 32) + kk) * 64 + lane) * 16), dsf, dqw[wt]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {   // this wave's rows of dbias: nobody else touches them
@@ -394,6 +394,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const bf16_t* __rest
 int mtp_full_bwd_flash_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
                               float* drel_part, float* workspace, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     const int64_t N = Hp * Wp;
+    // (<= 256 tokens: measured at 14 x 14, B = 64: 579 us vs 590 us for the one-workgroup-per-(image, head) kernels -- 196 = 3 x 64 + 4
+    //  wastes a quarter of the query workgroups; not worth a second code path)
     if (N <= 256 || Hp > 64 || Wp > 64 || Wp < 10 || getenv("MTP_NO_FLASH_ATTN")) return MTP_ERR_UNSUPPORTED;
     if (!workspace) return MTP_ERR_ARG;
     FlashGeom g;
@@ -405,15 +407,23 @@ int mtp_full_bwd_flash_launch(const void* qkv, const void* o, const void* dout, 
     float* delta = workspace + B * heads * N * g.HW;
     hipError_t e = hipMemsetAsync(drel_part, 0, sizeof(float) * (size_t)(B * heads) * (size_t)(g.RH + g.RW) * HD, s);
     if (e != hipSuccess) return (int)e;
-    const size_t lds_q = 2 * (size_t)KB * 128 + (size_t)64 * KTP + (size_t)(1 + g.WT) * 4 * 64 * 16 + 2 * (size_t)64 * g.HWP * 4 + 4 * 64 * QTP + KB * 4 + 64 * 4;
+    const auto lds_q = [&](int kb) { return 2 * (size_t)kb * 128 + (size_t)64 * (kb * 2 + 8) + (size_t)(1 + g.WT) * (kb / 32) * 64 * 16 + 2 * (size_t)64 * g.HWP * 4 + 4 * 64 * QTP + kb * 4 + 64 * 4; };
     const size_t lds_k = 2 * (size_t)64 * 128 + 2 * (size_t)64 * QBP + (size_t)64 * (g.Wp | 1) * 4 + 64 * 9 * 4 + 2 * 64 * 4;
-    if (lds_q > 160 * 1024) return MTP_ERR_UNSUPPORTED;
+    // key block of the dq kernel: 64 keys when that brings its LDS under half a CU's (two workgroups = 8 waves per CU; 28 x 28: 70 KiB)
+    // and the indicator rows still fit one MFMA tile (64 / Wp + 2 <= 16 always holds for Wp >= 10)
+    const bool small = lds_q(64) <= 80 * 1024;
+    if (!small && lds_q(128) > 160 * 1024) return MTP_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(B * heads), (unsigned)((N + 63) / 64)), block(256);
-    (void)hipFuncSetAttribute((const void*)flash_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    (void)hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q(64));
+    (void)hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q(128));
     (void)hipFuncSetAttribute((const void*)flash_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
     hipLaunchKernelGGL(flash_prep_kernel, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, rel_h, rel_w, bias, delta, g);
-    hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, block, lds_q, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, (bf16_t*)dqkv, rel_h, rel_w,
-                       (const float*)bias, (const float*)delta, drel_part, g, scale);
+    if (small)
+        hipLaunchKernelGGL(flash_bwd_dq_kernel<64>, grid, block, lds_q(64), s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, (bf16_t*)dqkv, rel_h, rel_w,
+                           (const float*)bias, (const float*)delta, drel_part, g, scale);
+    else
+        hipLaunchKernelGGL(flash_bwd_dq_kernel<128>, grid, block, lds_q(128), s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, (bf16_t*)dqkv, rel_h, rel_w,
+                           (const float*)bias, (const float*)delta, drel_part, g, scale);
     hipLaunchKernelGGL(flash_bwd_dkv_kernel, grid, block, lds_k, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, (bf16_t*)dqkv,
                        (const float*)bias, (const float*)delta, g, scale);
     return mtp_launch_status();

@@ -138,13 +138,12 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const bf16_t* __rest
 // detection fine-tunes, 4096 tokens).
 // dynamic LDS: Ks[256*128] | Vt[64*FTPV] | QR[4 waves][32 RT][16] f32 | kpos[256] u32
 // ===================================================================================================================
-constexpr int FKB = 256;
-constexpr int FTPV = FKB * 2 + 8;
 
-template <int RT>
+template <int RT, int FKB>
 __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                                  const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                                  int N, int Hp, int Wp, int heads, float scale) {
+    constexpr int FTPV = FKB * 2 + 8;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* Ks = sm;
     char* Vt = Ks + FKB * 128;
@@ -187,15 +186,15 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
         __syncthreads();   // the previous block's K / V^T reads are done (first pass: the QR tiles are visible)
         stage_rows_swz(base + C + (int64_t)kb0 * ld, ld, rem, FKB, Ks, tid);
         stage_rows_t(base + 2 * C + (int64_t)kb0 * ld, ld, rem, FKB, FTPV, Vt, tid);
-        {
+        if (tid < FKB) {
             const int key = kb0 + tid < N ? kb0 + tid : N - 1;
             kpos[tid] = (uint32_t)(key / Wp) | ((uint32_t)(key % Wp) << 8);
         }
         __syncthreads();
         const int keys = rem < FKB ? rem : FKB, tiles = (keys + 15) / 16, kkb = (keys + 31) / 32;
-        f32x4_t s[16];
+        f32x4_t s[FKB / 16];
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt) {
+        for (int kt = 0; kt < FKB / 16; ++kt) {
             s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             if (kt < tiles) {
 #pragma unroll
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
         }
         float bm = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt)
+        for (int kt = 0; kt < FKB / 16; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kl = 16 * kt + 4 * gq + r;
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
         const float alpha = __expf(m - mnew);   // first block: exp(-inf) = 0
         float lb = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt)
+        for (int kt = 0; kt < FKB / 16; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = __expf(s[kt][r] - mnew);
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oa[dt] = f32x4_t{oa[dt][0] * alpha, oa[dt][1] * alpha, oa[dt][2] * alpha, oa[dt][3] * alpha};
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk = 0; kk < FKB / 32; ++kk) {
             if (kk < kkb) {
                 const uint4 pf = pack_bf16x8(s[2 * kk][0], s[2 * kk][1], s[2 * kk][2], s[2 * kk][3], s[2 * kk + 1][0], s[2 * kk + 1][1], s[2 * kk + 1][2], s[2 * kk + 1][3]);
 #pragma unroll
@@ -644,14 +643,18 @@ int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* 
         const int64_t N = Hp * Wp;
         if (N <= 256 || Hp > 64 || Wp > 64 || getenv("MTP_NO_FLASH_ATTN")) return MTP_ERR_UNSUPPORTED;
         const bool big = Hp > 32 || Wp > 32;          // tables of up to 127 rows: 8 row tiles each
-        const size_t lds = (size_t)FKB * 128 + (size_t)64 * FTPV + (size_t)4 * 32 * (big ? 8 : 4) * 16 * 4 + FKB * 4;   // flash-style forward, 64 queries per workgroup
         const dim3 grid((unsigned)(B * heads), (unsigned)((N + 63) / 64));
         if (big) {
-            (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(full_fwd_flash_mfma_kernel<8>, grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
+            constexpr int KBLK = 256;
+            const size_t lds = (size_t)KBLK * 128 + (size_t)64 * (KBLK * 2 + 8) + (size_t)4 * 32 * 8 * 16 * 4 + KBLK * 4;
+            (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel<8, KBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((full_fwd_flash_mfma_kernel<8, KBLK>), grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
         } else {
-            (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(full_fwd_flash_mfma_kernel<4>, grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
+            // 128-key blocks: 65 KiB of LDS, two workgroups (8 waves) per CU instead of one
+            constexpr int KBLK = 128;
+            const size_t lds = (size_t)KBLK * 128 + (size_t)64 * (KBLK * 2 + 8) + (size_t)4 * 32 * 4 * 16 * 4 + KBLK * 4;
+            (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel<4, KBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((full_fwd_flash_mfma_kernel<4, KBLK>), grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
         }
         return mtp_launch_status();
     }
