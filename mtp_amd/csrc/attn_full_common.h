@@ -38,15 +38,15 @@ struct FGeom {
 };
 
 // K (or any 64-wide row block of qkv) -> swizzled row-major LDS image, rows >= N zeroed, up to `rows` rows
-__device__ __forceinline__ void stage_rows_swz(const bf16_t* __restrict__ src, int64_t ld, int N, int rows, char* img, int tid) {
-    for (int idx = tid; idx < rows * 8; idx += 256) {
+__device__ __forceinline__ void stage_rows_swz(const bf16_t* __restrict__ src, int64_t ld, int N, int rows, char* img, int tid, int nthreads = 256) {
+    for (int idx = tid; idx < rows * 8; idx += nthreads) {
         const int row = idx >> 3, c = idx & 7;
         *reinterpret_cast<uint4*>(img + swz(row, c)) = row_frag(src, ld, row, row < N, 8 * c);
     }
 }
 // 64-wide rows -> transposed image img[d][row] (pitch TPV bytes), columns >= N zeroed, up to `cols` columns
-__device__ __forceinline__ void stage_rows_t(const bf16_t* __restrict__ src, int64_t ld, int N, int cols, int TPV, char* img, int tid) {
-    for (int idx = tid; idx < cols * 8; idx += 256) {
+__device__ __forceinline__ void stage_rows_t(const bf16_t* __restrict__ src, int64_t ld, int N, int cols, int TPV, char* img, int tid, int nthreads = 256) {
+    for (int idx = tid; idx < cols * 8; idx += nthreads) {
         const int row = idx >> 3, c = idx & 7;
         const uint4 v = row_frag(src, ld, row, row < N, 8 * c);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};

@@ -483,9 +483,10 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
 }
 
 // ===================================================================================================================
-// backward B: dK, dV.   dynamic LDS: Qt[64*TPV] | dOt[64*TPV] | QRf[64][NP] f32 | lses[NP] | delta[NP] | kpos[NP2]
+// backward B: dK, dV.  8 waves per workgroup (two per SIMD: the second hides the first one's LDS / exp latency; the LDS images are
+// shared, so the workgroup's footprint does not grow).   dynamic LDS: Qt[64*TPV] | dOt[64*TPV] | QRf[64][NP] f32 | lses[NP] | delta[NP] | kpos[NP2]
 // ===================================================================================================================
-__global__ __launch_bounds__(256) void full_bwd_b_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(512) void full_bwd_b_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                                                              const float* __restrict__ rel_h, const float* __restrict__ rel_w, FGeom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -503,13 +504,13 @@ __global__ __launch_bounds__(256) void full_bwd_b_mfma_kernel(const bf16_t* __re
     const bf16_t* dob = dout + (int64_t)b * N * C + h * HD;
     const bf16_t* ob = o + (int64_t)b * N * C + h * HD;
 
-    stage_rows_t(base, ld, N, g.NP2, g.TPV, Qt, tid);
-    stage_rows_t(dob, C, N, g.NP2, g.TPV, dOt, tid);
-    for (int i = tid; i < g.NP2; i += 256) {
+    stage_rows_t(base, ld, N, g.NP2, g.TPV, Qt, tid, 512);
+    stage_rows_t(dob, C, N, g.NP2, g.TPV, dOt, tid, 512);
+    for (int i = tid; i < g.NP2; i += 512) {
         const int n = i < N ? i : N - 1;
         kpos[i] = (uint32_t)(n / g.Wp) | ((uint32_t)(n % g.Wp) << 8);
     }
-    for (int n = tid; n < NP; n += 256) {
+    for (int n = tid; n < NP; n += 512) {
         float dl = 0.f, ls = 0.f;
         const bool nv = n < N;
         const int nc = nv ? n : 0;
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256) void full_bwd_b_mfma_kernel(const bf16_t* __re
                 th[rt][ks] = table_frag(rel_h, 16 * rt + fr, g.RH, ks * 32 + gq * 8);
                 tw[rt][ks] = table_frag(rel_w, 16 * rt + fr, g.RW, ks * 32 + gq * 8);
             }
-        for (int qt = wave; qt < g.NT; qt += 4) {
+        for (int qt = wave; qt < g.NT; qt += 8) {
             const int n = 16 * qt + fr;
             const bool nv = n < N;
             uint4 qf[2];
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256) void full_bwd_b_mfma_kernel(const bf16_t* __re
     }
     __syncthreads();
 
-    for (int kt = wave; kt < g.NT; kt += 4) {
+    for (int kt = wave; kt < g.NT; kt += 8) {
         const int key = 16 * kt + fr;
         const bool kv = key < N;
         const int kc = kv ? key : 0;
@@ -677,7 +678,7 @@ int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, c
     (void)hipFuncSetAttribute((const void*)full_bwd_b_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
     hipLaunchKernelGGL(full_bwd_a_mfma_kernel, dim3((unsigned)(B * heads)), dim3(256), lds_a, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, rel_h, rel_w, drel_part, g, scale);
-    hipLaunchKernelGGL(full_bwd_b_mfma_kernel, dim3((unsigned)(B * heads)), dim3(256), lds_b, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
+    hipLaunchKernelGGL(full_bwd_b_mfma_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_b, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, rel_h, rel_w, g, scale);
     return mtp_launch_status();
 }
