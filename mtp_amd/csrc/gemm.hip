@@ -508,8 +508,13 @@ __device__ __forceinline__ void stage_tn_glds(const KArgs& p, char* sA, char* sB
         const int f = (row & 3) | ((row >> 1) & 4);
         const int chunk = (lane & 15) ^ (f << 1);
         const int64_t t = (int64_t)kt * 64 + row;
-        const char* ga = p.A + (t * p.lda + m0 + chunk * 8) * 2;
-        const char* gb = p.B + (t * p.ldb + n0 + chunk * 8) * 2;
+        // edge tiles (M or N not a multiple of 128, e.g. InternImage's 192 channels): columns past the matrix edge re-read the last
+        // complete 16-byte chunk of the row; their products land in output columns the epilogue never stores
+        int ca = m0 + chunk * 8, cb = n0 + chunk * 8;
+        ca = ca < p.M - 8 ? ca : p.M - 8;
+        cb = cb < p.N - 8 ? cb : p.N - 8;
+        const char* ga = p.A + (t * p.lda + ca) * 2;
+        const char* gb = p.B + (t * p.ldb + cb) * 2;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
                                          (__attribute__((address_space(3))) void*)(sA + rbase * TR_ROW_BYTES), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += red[r * BM + tid];
-            atomicAdd(p.colsum + m0 + tid, s);
+            if (m0 + tid < p.M) atomicAdd(p.colsum + m0 + tid, s);
         }
     }
     epilogue<float, MTP_EPI_BIAS, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
@@ -725,7 +730,8 @@ int launch_tn(const mtp_gemm_args* a, hipStream_t stream) {
     dim3 grid(tiles_m * k.tiles_n, split), block(NT_THREADS);
     const bool full = (a->K % (8 * E) == 0) && (a->M % BM == 0) && (a->N % BN == 0);
     // bf16 complete tiles: LDS-DMA + transpose-read kernel; variant bit 4 falls back to the register-transposing kernels
-    const bool tr = full && sizeof(T) == 2 && !(a->variant & 16);
+    // (the transpose-read kernel also takes edge tiles as long as the rows split into whole 16-byte chunks and K into whole 64-row stages)
+    const bool tr = sizeof(T) == 2 && !(a->variant & 16) && (full || ((a->K % 64 == 0) && (a->M % 8 == 0) && (a->N % 8 == 0) && a->M >= 8 && a->N >= 8 && !(a->variant & 32768)));
     if (a->colsum && !tr) {   // the other kernels do not produce the column sums: separate streaming pass over A
         rc = mtp_colsum_acc(a->A, a->in_dtype, a->lda, a->colsum, a->K, a->M, stream);
         if (rc) return rc;

@@ -191,7 +191,11 @@ def test_gemm_tn(ops, dtype, Kc, M, N, split):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("Kc,M,N,split", [(1024, 384, 256, 3), (12544, 256, 128, None), (392, 256, 128, 2), (128, 128, 384, 1)])
+@pytest.mark.parametrize("Kc,M,N,split", [(1024, 384, 256, 3), (12544, 256, 128, None), (392, 256, 128, 2), (128, 128, 384, 1),
+                                          # edge tiles of the transpose-read kernel (InternImage's 192-channel level: 192 = 128 + 64,
+                                          # 216-row offset heads, the 112-row padded mask head, the 96 x 32 stem convolution)
+                                          (1024, 192, 192, None), (512, 216, 192, 2), (640, 112, 192, 1), (256, 96, 32, 1), (2048, 192, 768, None),
+                                          (128, 8, 8, 1)])
 def test_gemm_tn_bias_gradient_byproduct(ops, dtype, Kc, M, N, split):
     """colsum += dY.sum(0) out of the dW GEMM: fused in the transpose-read kernel (bf16, complete tiles), a separate pass
     otherwise; both ACCUMULATE (Linear bias gradient, VIT:50-52 backward)."""
