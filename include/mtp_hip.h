@@ -287,6 +287,16 @@ int mtp_dcnv3_bwd(const void* input, const void* offset, const void* mask, const
 
 const char* mtp_version(void);
 
+/* ---- gradient all-reduce over RCCL (reference: DistributedDataParallel, main_pretrain.py:508-518) ------ */
+/* One communicator per process / GPU.  Rank 0 draws a 128-byte id (mtp_comm_unique_id) and hands it to every rank out of band;
+ * mtp_comm_init is collective.  mtp_comm_allreduce_bucket: in-place SUM of `count` f32 values on `stream` (asynchronous; the
+ * caller orders it against the kernels that produce / consume the bucket).  RCCL is resolved at run time: MTP_ERR_UNSUPPORTED when
+ * no librccl can be loaded; RCCL's own error codes come back as 10000 + ncclResult_t. */
+int mtp_comm_unique_id(void* id128);
+int mtp_comm_init(const void* id128, int rank, int world, void** comm);
+int mtp_comm_allreduce_bucket(void* comm, float* bucket, int64_t count, mtp_stream_t stream);
+int mtp_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

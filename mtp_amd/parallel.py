@@ -155,6 +155,11 @@ class GradReducer:
         import os
         self.active = self.world > 1 or (os.environ.get("MTP_FORCE_COMM") == "1" and dist.is_available() and dist.is_initialized())
         self.stream = torch.cuda.Stream() if self.cuda and self.active else None
+        # MTP_NATIVE_COMM=1: the collectives go through the C ABI (mtp_comm_allreduce_bucket -> ncclAllReduce) instead of torch.distributed
+        self.native = None
+        if self.stream is not None and os.environ.get("MTP_NATIVE_COMM") == "1":
+            from .comm import RcclComm
+            self.native = RcclComm(group)
         self.works = []
         self.start = 0
         self.bytes_reduced = 0
@@ -188,10 +193,14 @@ class GradReducer:
             if self.timing:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(self.stream)
-            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.works.append(w)
+            if self.native is not None:
+                self.native.all_reduce_(buf)                  # ncclAllReduce on the side stream (the current one here)
+            else:
+                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.works.append(w)
             if self.timing:
-                w.wait()                      # (stream-level wait: orders t1 behind the collective on the side stream)
+                if self.native is None:
+                    w.wait()                  # (stream-level wait: orders t1 behind the collective on the side stream)
                 t1.record(self.stream)
                 self.timed.append((buf.numel() * 4, t0, t1))
 
