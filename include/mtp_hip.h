@@ -229,6 +229,14 @@ int mtp_full_attn_bwd(const void* qkv, const void* o, const void* dout, const fl
 int mtp_rvsa_pool_fwd(const void* x, int dtype, float* avg, float* pooled, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream);
 /* dx (T,C) ACT += / = dpooled * leaky'(avg) / 49 broadcast over the window */
 int mtp_rvsa_pool_bwd(const float* dpooled, const float* avg, void* dx, int dtype, int accumulate, int64_t B, int64_t Hp, int64_t Wp, int64_t C, mtp_stream_t stream);
+/* The same two stages fused per window, one launch each way: avg, pooled (B*nh*nw, C) f32 and samp (B*nh*nw, N) f32 =
+ * LeakyReLU(AvgPool(x)) . w^T + bias with w (N, C) f32 = the three heads stacked (N = 5 * heads);
+ * backward: dx (T, C) ACT += (dsamp . w) * leaky'(avg) / 49 over each window's tokens (the weight / bias gradients stay with
+ * mtp_small_linear_bwd, dx = NULL). */
+int mtp_rvsa_sampling_fwd(const void* x, int dtype, const float* w, const float* bias, float* avg, float* pooled, float* samp,
+                          int64_t B, int64_t Hp, int64_t Wp, int64_t C, int64_t N, mtp_stream_t stream);
+int mtp_rvsa_sampling_bwd(const float* dsamp, const float* w, const float* avg, void* dx, int dtype,
+                          int64_t B, int64_t Hp, int64_t Wp, int64_t C, int64_t N, mtp_stream_t stream);
 /* small f32 linear for the three 1x1 conv heads (VIT:231,236,242): y (R,N) = x (R,K) W(N,K)^T + b; and its backward */
 int mtp_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t R, int64_t N, int64_t K, mtp_stream_t stream);
 int mtp_small_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t R, int64_t N, int64_t K, mtp_stream_t stream);

@@ -93,6 +93,8 @@ SIGNATURES = {
     "mtp_full_attn_bwd": (i32, [p, p, p, p, p, i32, p, p, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_rvsa_pool_fwd": (i32, [p, i32, p, p, i64, i64, i64, i64, p]),
     "mtp_rvsa_pool_bwd": (i32, [p, p, p, i32, i32, i64, i64, i64, i64, p]),
+    "mtp_rvsa_sampling_fwd": (i32, [p, i32, p, p, p, p, p, i64, i64, i64, i64, i64, p]),
+    "mtp_rvsa_sampling_bwd": (i32, [p, p, p, p, i32, i64, i64, i64, i64, i64, p]),
     "mtp_small_linear_fwd": (i32, [p, p, p, p, i64, i64, i64, p]),
     "mtp_small_linear_bwd": (i32, [p, p, p, p, p, p, i64, i64, i64, p]),
     "mtp_rvsa_attn_fwd": (i32, [p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),

@@ -17,6 +17,7 @@ import torch
 from . import ops
 
 F32 = torch.float32
+_FUSED_SAMPLING = os.environ.get("MTP_FUSED_SAMPLING", "1") != "0"     # A/B switch: 0 = pool / linear as separate launches
 
 
 class _Blk:
@@ -180,8 +181,11 @@ class BackboneEngine:
             nh, nw = ops.rvsa_windows(Hp, Wp)
             R = B * nh * nw
             avg, pooled = self._e(R, C, dtype=F32), self._e(R, C, dtype=F32)
-            ops.rvsa_pool_fwd(ln1, avg, pooled, B, Hp, Wp)
-            samp = ops.small_linear_fwd(pooled, b.wsamp, b.bsamp, self._e(R, 5 * self.heads, dtype=F32))
+            if _FUSED_SAMPLING:
+                samp = ops.rvsa_sampling_fwd(ln1, b.wsamp, b.bsamp, avg, pooled, self._e(R, 5 * self.heads, dtype=F32), B, Hp, Wp)
+            else:     # A/B: the two-launch form
+                ops.rvsa_pool_fwd(ln1, avg, pooled, B, Hp, Wp)
+                samp = ops.small_linear_fwd(pooled, b.wsamp, b.bsamp, self._e(R, 5 * self.heads, dtype=F32))
             lse = self._e(R * self.heads * 49, dtype=F32)
             ops.rvsa_attn_fwd(qkv, samp, o, lse, P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"],
                               P[pre + "attn.relative_position_bias_table"], B, Hp, Wp, self.heads, self.scale)
@@ -234,8 +238,9 @@ class BackboneEngine:
                               P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], P[pre + "attn.relative_position_bias_table"],
                               G[pre + "attn.rel_pos_h"], G[pre + "attn.rel_pos_w"], G[pre + "attn.relative_position_bias_table"],
                               B, Hp, Wp, H, self.scale, accumulate=True)
-            dpooled, dwb = self._e(R, C, dtype=F32), self._e(5 * H * C + 5 * H, dtype=F32)   # [dW stacked | db]: one clearing pass
+            dwb = self._e(5 * H * C + 5 * H, dtype=F32)   # [dW stacked | db]: one clearing pass
             dws, dbs = dwb[:5 * H * C].view(5 * H, C), dwb[5 * H * C:]
+            dpooled = None if _FUSED_SAMPLING else self._e(R, C, dtype=F32)
             ops.small_linear_bwd(s["pooled"], b.wsamp, dsamp, dpooled, dws, dbs)
             ops.copy_segments([dws[:2 * H], dws[2 * H:4 * H], dws[4 * H:], dbs[:2 * H], dbs[2 * H:4 * H], dbs[4 * H:]],
                               [G[pre + "attn.sampling_offsets.2.weight"], G[pre + "attn.sampling_scales.2.weight"],
@@ -252,7 +257,10 @@ class BackboneEngine:
         wq.add(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], G[pre + "attn.qkv.bias"])
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         if b.window:
-            ops.rvsa_pool_bwd(dpooled, s["avg"], dln1, B, Hp, Wp, accumulate=True)
+            if _FUSED_SAMPLING:
+                ops.rvsa_sampling_bwd(dsamp, b.wsamp, s["avg"], dln1, B, Hp, Wp)     # dln1 += pool'(linear'(dsamp)), one launch
+            else:
+                ops.rvsa_pool_bwd(dpooled, s["avg"], dln1, B, Hp, Wp, accumulate=True)
         dx0, dx0_act = self._e(T, C, dtype=F32), self._e(T, C)
         self._ln_bwd(dln1, s["x"], s["mean1"], s["rstd1"], P[pre + "norm1.weight"], dx0, G[pre + "norm1.weight"], G[pre + "norm1.bias"],
                           dres=dx1, extra=extra, dx_copy=dx0_act, copy_scale=prev_scale, rows_per_sample=N)

@@ -457,6 +457,19 @@ def rvsa_pool_bwd(dpooled, avg, dx, B, Hp, Wp, accumulate=True):
     check(lib().mtp_rvsa_pool_bwd(_f32(dpooled), _f32(avg), _p(dx), _dt(dx), int(accumulate), B, Hp, Wp, dx.shape[-1], _s()), "mtp_rvsa_pool_bwd")
 
 
+def rvsa_sampling_fwd(x, w, b, avg, pooled, samp, B, Hp, Wp):
+    """pool -> LeakyReLU -> stacked 1x1 heads in one launch (mtp_rvsa_sampling_fwd)"""
+    check(lib().mtp_rvsa_sampling_fwd(_p(x), _dt(x), _f32(w), _f32(b), _f32(avg), _f32(pooled), _f32(samp), B, Hp, Wp, x.shape[-1], w.shape[0], _s()),
+          "mtp_rvsa_sampling_fwd")
+    return samp
+
+
+def rvsa_sampling_bwd(dsamp, w, avg, dx, B, Hp, Wp):
+    """dx += broadcast((dsamp . w) * leaky'(avg) / 49) in one launch (mtp_rvsa_sampling_bwd)"""
+    check(lib().mtp_rvsa_sampling_bwd(_f32(dsamp), _f32(w), _f32(avg), _p(dx), _dt(dx), B, Hp, Wp, dx.shape[-1], w.shape[0], _s()), "mtp_rvsa_sampling_bwd")
+    return dx
+
+
 def small_linear_fwd(x, w, b, y):
     R, K = x.shape
     check(lib().mtp_small_linear_fwd(_f32(x), _f32(w), _f32(b), _f32(y), R, w.shape[0], K, _s()), "mtp_small_linear_fwd")
@@ -464,6 +477,7 @@ def small_linear_fwd(x, w, b, y):
 
 
 def small_linear_bwd(x, w, dy, dx, dw, db):
+    """dx may be None (weight / bias gradients only)"""
     R, K = x.shape
     check(lib().mtp_small_linear_bwd(_f32(x), _f32(w), _f32(dy), _f32(dx), _f32(dw), _f32(db), R, w.shape[0], K, _s()), "mtp_small_linear_bwd")
 

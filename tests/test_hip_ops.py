@@ -528,6 +528,16 @@ def test_rvsa_pool_and_small_linear(ops, dtype, Hp, Wp):
     acc = dev(base, dtype)
     ops.rvsa_pool_bwd(dx, avg, acc, B, Hp, Wp, accumulate=True)
     assert rel_err(acc.float().cpu(), base + O.rvsa_pool_bwd(dx.cpu(), ar, B, Hp, Wp)) < TOL[dtype]
+    # the fused forms (one launch each way) give the same numbers
+    avg2, pooled2, y2 = e(R, C), e(R, C), e(R, 5 * heads)
+    ops.rvsa_sampling_fwd(dev(x, dtype), dev(w), dev(b), avg2, pooled2, y2, B, Hp, Wp)
+    assert rel_err(avg2.cpu(), ar) < 1e-5 and rel_err(pooled2.cpu(), pr) < 1e-5 and rel_err(y2.cpu(), pr @ w.t() + b) < 1e-5
+    acc2 = dev(base, dtype)
+    ops.rvsa_sampling_bwd(dev(dy), dev(w), avg, acc2, B, Hp, Wp)
+    assert rel_err(acc2.float().cpu(), base + O.rvsa_pool_bwd(dy @ w, ar, B, Hp, Wp)) < TOL[dtype]
+    dw2, db2 = e(5 * heads, C), e(5 * heads)
+    ops.small_linear_bwd(pooled, dev(w), dev(dy), None, dw2, db2)
+    assert rel_err(dw2.cpu(), dy.t() @ pr) < 1e-5 and rel_err(db2.cpu(), dy.sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("R,N,K", [(1024, 80, 1024), (37, 10, 128), (130, 5, 1100 * 4), (6, 83, 768), (67, 12, 1536), (300, 80, 256)])
