@@ -240,6 +240,10 @@ int mtp_rvsa_sampling_bwd(const float* dsamp, const float* w, const float* avg, 
 /* small f32 linear for the three 1x1 conv heads (VIT:231,236,242): y (R,N) = x (R,K) W(N,K)^T + b; and its backward */
 int mtp_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t R, int64_t N, int64_t K, mtp_stream_t stream);
 int mtp_small_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t R, int64_t N, int64_t K, mtp_stream_t stream);
+/* weight / bias gradients of nseg <= 4 layers stacked along N (the three RVSA heads), ACCUMULATED into their own buffers:
+ * dw[j] (rows_j, K) += dy[:, r0_j : r0_j + rows_j]^T x, db[j] (rows_j) += column sums.  seg_rows, dw, db: host arrays; db may be NULL. */
+int mtp_small_linear_dw_segments(const float* x, const float* dy, int64_t R, int64_t N, int64_t K, int nseg, const int64_t* seg_rows,
+                                 float* const* dw, float* const* db, mtp_stream_t stream);
 /* RotatedVariedSizeWindowAttention core (VIT:312-428): samp (B*nh*nw, 5*heads) f32 = [off(h,2)|scale(h,2)|angle(h)];
  * lse (B, heads, nh*nw, 49) f32 */
 int mtp_rvsa_attn_fwd(const void* qkv, const float* samp, void* o, float* lse, int dtype,

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mtp_rvsa_sampling_bwd": (i32, [p, p, p, p, i32, i64, i64, i64, i64, i64, p]),
     "mtp_small_linear_fwd": (i32, [p, p, p, p, i64, i64, i64, p]),
     "mtp_small_linear_bwd": (i32, [p, p, p, p, p, p, i64, i64, i64, p]),
+    "mtp_small_linear_dw_segments": (i32, [p, p, i64, i64, i64, i32, p, p, p, p]),
     "mtp_rvsa_attn_fwd": (i32, [p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_rvsa_attn_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_sqnorm_f32": (i32, [p, p, i64, p]),

@@ -365,7 +365,16 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __res
 // wave = a quarter of the rows (dy factors wave-uniform: scalar loads; each x vector feeds 8 outputs), waves combined through
 // LDS, then ONE set of f32 atomics per workgroup into the zeroed outputs (the atomics were the cost of the first versions).
 constexpr int SL_DW_ROWS = 32;
-__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K) {
+// SEG: the N output rows are slices of up to 4 separate parameters (the three stacked RVSA heads): row n of segment j goes to
+// seg.dw[j] + (n - seg.row0[j]) * K -- accumulated straight into the parameter gradients (no stacked scratch, no clearing pass, no copy)
+struct SlSegs {
+    float* dw[4];
+    float* db[4];
+    int row0[5];
+    int nseg;
+};
+template <bool SEG>
+__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K, SlSegs seg) {
     __shared__ float4 red[3][8][64];
     __shared__ float redb[3][8];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -410,11 +419,21 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __res
                 s[q].x += o.x; s[q].y += o.y; s[q].z += o.z; s[q].w += o.w;
                 sb[q] += redb[v][q];
             }
+            float* dwrow = dw + (int64_t)(n0 + q) * K;
+            float* dbp = db ? db + n0 + q : nullptr;
+            if constexpr (SEG) {
+                int j = 0;
+                const int n = n0 + q < N ? n0 + q : N - 1;
+#pragma unroll
+                for (int t = 1; t < 4; ++t) j += (t < seg.nseg && n >= seg.row0[t]) ? 1 : 0;
+                dwrow = seg.dw[j] + (int64_t)(n - seg.row0[j]) * K;
+                dbp = seg.db[j] ? seg.db[j] + (n - seg.row0[j]) : nullptr;
+            }
             if (kok && n0 + q < N) {
-                float* o = dw + (int64_t)(n0 + q) * K + k;
+                float* o = dwrow + k;
                 atomicAdd(o, s[q].x); atomicAdd(o + 1, s[q].y); atomicAdd(o + 2, s[q].z); atomicAdd(o + 3, s[q].w);
             }
-            if (db && blockIdx.x == 0 && lane == 0 && n0 + q < N) atomicAdd(db + n0 + q, sb[q]);
+            if (dbp && blockIdx.x == 0 && lane == 0 && n0 + q < N) atomicAdd(dbp, sb[q]);
         }
     }
 }
@@ -909,9 +928,30 @@ extern "C" int mtp_small_linear_bwd(const float* x, const float* w, const float*
             (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)(N * K), s);
             if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s);
         }
-        hipLaunchKernelGGL(small_linear_dw_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)((N + 7) / 8), (unsigned)((R + 4 * SL_DW_ROWS - 1) / (4 * SL_DW_ROWS))), dim3(256), 0, s,
-                           dy, x, dw, db, (int)R, (int)N, (int)K);
+        hipLaunchKernelGGL(small_linear_dw_kernel<false>, dim3((unsigned)((K + 255) / 256), (unsigned)((N + 7) / 8), (unsigned)((R + 4 * SL_DW_ROWS - 1) / (4 * SL_DW_ROWS))), dim3(256), 0, s,
+                           dy, x, dw, db, (int)R, (int)N, (int)K, SlSegs{});
     }
+    return mtp_launch_status();
+}
+/* the weight / bias gradients of nseg <= 4 layers stacked along N, ACCUMULATED into their own (rows_j, K) / (rows_j) f32 buffers:
+ * dw[j] += dy[:, r0_j : r0_j + rows_j]^T x.  Host arrays; db[j] may be NULL. */
+extern "C" int mtp_small_linear_dw_segments(const float* x, const float* dy, int64_t R, int64_t N, int64_t K, int nseg, const int64_t* seg_rows,
+                                            float* const* dw, float* const* db, mtp_stream_t stream) {
+    if (!x || !dy || !seg_rows || !dw || R <= 0 || N <= 0 || K <= 0 || (K % 4) || nseg < 1 || nseg > 4) return MTP_ERR_ARG;
+    SlSegs seg{};
+    int64_t r = 0;
+    for (int j = 0; j < nseg; ++j) {
+        if (!dw[j] || seg_rows[j] <= 0) return MTP_ERR_ARG;
+        seg.dw[j] = dw[j];
+        seg.db[j] = db ? db[j] : nullptr;
+        seg.row0[j] = (int)r;
+        r += seg_rows[j];
+    }
+    if (r != N) return MTP_ERR_ARG;
+    seg.row0[nseg] = (int)N;
+    seg.nseg = nseg;
+    hipLaunchKernelGGL(small_linear_dw_kernel<true>, dim3((unsigned)((K + 255) / 256), (unsigned)((N + 7) / 8), (unsigned)((R + 4 * SL_DW_ROWS - 1) / (4 * SL_DW_ROWS))), dim3(256), 0,
+                       (hipStream_t)stream, dy, x, (float*)nullptr, (float*)nullptr, (int)R, (int)N, (int)K, seg);
     return mtp_launch_status();
 }
 

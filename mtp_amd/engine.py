@@ -238,14 +238,18 @@ class BackboneEngine:
                               P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], P[pre + "attn.relative_position_bias_table"],
                               G[pre + "attn.rel_pos_h"], G[pre + "attn.rel_pos_w"], G[pre + "attn.relative_position_bias_table"],
                               B, Hp, Wp, H, self.scale, accumulate=True)
-            dwb = self._e(5 * H * C + 5 * H, dtype=F32)   # [dW stacked | db]: one clearing pass
-            dws, dbs = dwb[:5 * H * C].view(5 * H, C), dwb[5 * H * C:]
-            dpooled = None if _FUSED_SAMPLING else self._e(R, C, dtype=F32)
-            ops.small_linear_bwd(s["pooled"], b.wsamp, dsamp, dpooled, dws, dbs)
-            ops.copy_segments([dws[:2 * H], dws[2 * H:4 * H], dws[4 * H:], dbs[:2 * H], dbs[2 * H:4 * H], dbs[4 * H:]],
-                              [G[pre + "attn.sampling_offsets.2.weight"], G[pre + "attn.sampling_scales.2.weight"],
-                               G[pre + "attn.sampling_angles.2.weight"], G[pre + "attn.sampling_offsets.2.bias"],
-                               G[pre + "attn.sampling_scales.2.bias"], G[pre + "attn.sampling_angles.2.bias"]])
+            names = ("sampling_offsets", "sampling_scales", "sampling_angles")
+            if _FUSED_SAMPLING:     # the stacked heads' weight / bias gradients accumulate straight into the three parameters' buffers
+                ops.small_linear_dw_segments(s["pooled"], dsamp, [G[pre + "attn.%s.2.weight" % n].view(-1, C) for n in names],
+                                             [G[pre + "attn.%s.2.bias" % n] for n in names])
+                dpooled = None
+            else:
+                dwb = self._e(5 * H * C + 5 * H, dtype=F32)   # [dW stacked | db]: one clearing pass
+                dws, dbs = dwb[:5 * H * C].view(5 * H, C), dwb[5 * H * C:]
+                dpooled = self._e(R, C, dtype=F32)
+                ops.small_linear_bwd(s["pooled"], b.wsamp, dsamp, dpooled, dws, dbs)
+                ops.copy_segments([dws[:2 * H], dws[2 * H:4 * H], dws[4 * H:], dbs[:2 * H], dbs[2 * H:4 * H], dbs[4 * H:]],
+                                  [G[pre + "attn.%s.2.weight" % n] for n in names] + [G[pre + "attn.%s.2.bias" % n] for n in names])
         else:
             rel_h, rel_w = self._full_rel(pre, Hp, Wp)
             if pre + "attn.full_attn_rel_pos_h" in G:

@@ -482,6 +482,17 @@ def small_linear_bwd(x, w, dy, dx, dw, db):
     check(lib().mtp_small_linear_bwd(_f32(x), _f32(w), _f32(dy), _f32(dx), _f32(dw), _f32(db), R, w.shape[0], K, _s()), "mtp_small_linear_bwd")
 
 
+def small_linear_dw_segments(x, dy, dws, dbs):
+    """dws[j] (rows_j, K) += dy[:, rows of segment j]^T x, dbs[j] += column sums: the stacked heads' gradients straight into their parameters"""
+    R, K = x.shape
+    n = len(dws)
+    assert 0 < n <= 4 and len(dbs) == n and sum(d.shape[0] for d in dws) == dy.shape[1]
+    rows = (C.c_int64 * n)(*[d.shape[0] for d in dws])
+    P = C.c_void_p * n
+    check(lib().mtp_small_linear_dw_segments(_f32(x), _f32(dy), R, dy.shape[1], K, n, rows, P(*[_f32(d) for d in dws]), P(*[_f32(d) for d in dbs]), _s()),
+          "mtp_small_linear_dw_segments")
+
+
 def rvsa_attn_fwd(qkv, samp, o, lse, rel_h, rel_w, table, B, Hp, Wp, heads, scale):
     hd = qkv.shape[1] // (3 * heads)
     check(lib().mtp_rvsa_attn_fwd(_p(qkv), _f32(samp), _p(o), _f32(lse), _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table),

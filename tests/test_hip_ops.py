@@ -538,6 +538,16 @@ def test_rvsa_pool_and_small_linear(ops, dtype, Hp, Wp):
     dw2, db2 = e(5 * heads, C), e(5 * heads)
     ops.small_linear_bwd(pooled, dev(w), dev(dy), None, dw2, db2)
     assert rel_err(dw2.cpu(), dy.t() @ pr) < 1e-5 and rel_err(db2.cpu(), dy.sum(0)) < 1e-5
+    # ... and the stacked heads' gradients accumulated straight into three separate parameters (2H | 2H | H rows)
+    rows = [2 * heads, 2 * heads, heads]
+    base_w = [rnd(r, C, seed=20 + i) for i, r in enumerate(rows)]
+    base_b = [rnd(r, seed=30 + i) for i, r in enumerate(rows)]
+    gw, gb = [dev(t) for t in base_w], [dev(t) for t in base_b]
+    ops.small_linear_dw_segments(pooled, dev(dy), gw, gb)
+    full_w, full_b, r0 = dy.t() @ pr, dy.sum(0), 0
+    for i, r in enumerate(rows):
+        assert rel_err(gw[i].cpu(), base_w[i] + full_w[r0:r0 + r]) < 1e-5 and rel_err(gb[i].cpu(), base_b[i] + full_b[r0:r0 + r]) < 1e-5
+        r0 += r
 
 
 @pytest.mark.parametrize("R,N,K", [(1024, 80, 1024), (37, 10, 128), (130, 5, 1100 * 4), (6, 83, 768), (67, 12, 1536), (300, 80, 256)])
