@@ -255,22 +255,40 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
 
 // ===================================================================================================================
 // backward A: dQ and the rel-pos table gradients.
-// dynamic LDS: Ks | Vs (16NT x 128 each) | Kt[64*TPV] | QR[4][64][16] f32 | dQR[4][64][16] f32 | Qtt[4][64*40 B] | kpos[NP2] | E[2][KK][64] x16 B
+// dynamic LDS: Ks | Vs (NP2 x 128 each) | QR[NW][64][16] f32 | dQR[NW][64][16] f32 | Qtt[NW][64*40 B] | kpos[NP2] | E[2][KK][64] x16 B
 // ===================================================================================================================
 constexpr int QTP = 40;   // byte pitch of the per-wave transposed 16-query tile [d][16 q] (32 + 8)
 
-__global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+// K^T fragment (MFMA A operand: row d = 16 dt + fr, k = keys key0 .. key0+3 and key0+16 .. key0+19) out of the swizzled row-major K image:
+// in each 16-lane group, lane i supplies the address of row i >> 2, columns 4 (i & 3) .. +3 of a [4 keys][16 d] block and receives
+// column i of its four rows
+typedef short tr4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 kt_frag_tr(const char* Ks, int key0, int dt, int fr) {
+    const int c = 16 * dt + 4 * (fr & 3);
+    const int ra = key0 + (fr >> 2), rb = ra + 16;
+    const int oa = ra * 128 + ((((c >> 3) ^ (ra & 7))) << 4) + (c & 7) * 2, ob = rb * 128 + ((((c >> 3) ^ (rb & 7))) << 4) + (c & 7) * 2;
+    const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_t*)(Ks + oa));
+    const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_t*)(Ks + ob));
+    const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, h.x, h.y);
+}
+
+// NW waves per workgroup: 8 (two per SIMD, the second hides the first one's LDS / exp latency) when the per-wave tiles fit next to
+// the K / V images, else 4.  K^T fragments for dQ^T = K^T.dS^T come out of the row-major K image with the hardware transpose read
+// (ds_read_b64_tr_b16; layout probed in tools/tr_probe.hip) -- the separate K^T image of round 1 (29 KiB) is gone.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void full_bwd_a_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                                                              const float* __restrict__ rel_h, const float* __restrict__ rel_w, float* __restrict__ drel_part,
                                                              FGeom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* Ks = sm;
-    char* Vs = Ks + g.NT * 16 * 128;
-    char* Kt = Vs + g.NT * 16 * 128;
-    float* QRall = reinterpret_cast<float*>(Kt + 64 * g.TPV);
-    float* dQRall = QRall + 4 * 64 * 16;
-    char* Qttall = reinterpret_cast<char*>(dQRall + 4 * 64 * 16);
-    uint32_t* kpos = reinterpret_cast<uint32_t*>(Qttall + 4 * 64 * QTP);
+    constexpr int NTH = 64 * NW;
+    char* Vs = Ks + g.NP2 * 128;
+    float* QRall = reinterpret_cast<float*>(Vs + g.NP2 * 128);
+    float* dQRall = QRall + NW * 64 * 16;
+    char* Qttall = reinterpret_cast<char*>(dQRall + NW * 64 * 16);
+    uint32_t* kpos = reinterpret_cast<uint32_t*>(Qttall + NW * 64 * QTP);
     char* Eimg = reinterpret_cast<char*>(kpos + g.NP2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, gq = lane >> 4;
     const int bh = blockIdx.x, b = bh / g.heads, h = bh % g.heads;
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
     // 0/1 indicator operands E_h[a][key] = (row(key) == a), E_w[a][key] = (col(key) == a) in the MFMA A layout with the key
     // order of the dS^T fragments below: sum_k E[a][k] dS^T[k][q] is d(q.Rh)[q][hq - a] -- the segmented row / column sums
     // of dS come out of the matrix cores instead of LDS float atomics (measured ~190 LDS cycles per ds_add_f32 instruction).
-    for (int idx = tid; idx < 2 * g.KK * 64; idx += 256) {
+    for (int idx = tid; idx < 2 * g.KK * 64; idx += NTH) {
         const int t = idx / (g.KK * 64), rem = idx % (g.KK * 64), kk = rem >> 6, l = rem & 63, a = l & 15, gl = l >> 4;
         uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -298,10 +316,9 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
         *reinterpret_cast<uint4*>(Eimg + (size_t)idx * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 
-    stage_rows_swz(base + C, ld, N, g.NT * 16, Ks, tid);
-    stage_rows_swz(base + 2 * C, ld, N, g.NT * 16, Vs, tid);
-    stage_rows_t(base + C, ld, N, g.NP2, g.TPV, Kt, tid);
-    for (int i = tid; i < g.NP2; i += 256) {
+    stage_rows_swz(base + C, ld, N, g.NP2, Ks, tid, NTH);
+    stage_rows_swz(base + 2 * C, ld, N, g.NP2, Vs, tid, NTH);
+    for (int i = tid; i < g.NP2; i += NTH) {
         const int n = i < N ? i : N - 1;
         kpos[i] = (uint32_t)(n / g.Wp) | ((uint32_t)(n % g.Wp) << 8);
     }
@@ -327,9 +344,9 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
             for (int dt = 0; dt < 4; ++dt) tacc[t][rt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    const int iters = (g.NT + 3) / 4;
+    const int iters = (g.NT + NW - 1) / NW;
     for (int it = 0; it < iters; ++it) {
-        const int qt = wave + 4 * it;
+        const int qt = wave + NW * it;
         const bool tile_ok = qt < g.NT;
         const int n = 16 * qt + fr;
         const bool nv = tile_ok && n < N;
@@ -412,10 +429,7 @@ __global__ __launch_bounds__(256) void full_bwd_a_mfma_kernel(const bf16_t* __re
                 const uint4 dsf = pack_bf16x8(dsT[2 * kk][0], dsT[2 * kk][1], dsT[2 * kk][2], dsT[2 * kk][3],
                                               dsT[2 * kk + 1][0], dsT[2 * kk + 1][1], dsT[2 * kk + 1][2], dsT[2 * kk + 1][3]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const char* row = Kt + (16 * dt + fr) * g.TPV;
-                    dq[dt] = mma(ld8x2(row + (32 * kk + 4 * gq) * 2, row + (32 * kk + 16 + 4 * gq) * 2), dsf, dq[dt]);
-                }
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = mma(kt_frag_tr(Ks, 32 * kk + 4 * gq, dt, fr), dsf, dq[dt]);
                 dqh = mma(ld16(Eimg + (kk * 64 + lane) * 16), dsf, dqh);             // lane: d(q.Rh) of query fr for key rows 4gq + r
                 dqw = mma(ld16(Eimg + ((g.KK + kk) * 64 + lane) * 16), dsf, dqw);
             }
@@ -671,13 +685,18 @@ int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, c
     if (!make_fgeom(Hp, Wp, heads, g)) return MTP_ERR_UNSUPPORTED;
     hipError_t e = hipMemsetAsync(drel_part, 0, sizeof(float) * (size_t)(B * heads) * (size_t)(g.RH + g.RW) * HD, s);
     if (e != hipSuccess) return (int)e;
-    const size_t lds_a = 2 * (size_t)g.NT * 16 * 128 + (size_t)64 * g.TPV + 2 * 4 * 64 * 16 * 4 + 4 * 64 * QTP + (size_t)g.NP2 * 4 + 2 * (size_t)g.KK * 64 * 16;
+    const auto lds_a = [&](int nw) { return 2 * (size_t)g.NP2 * 128 + 2 * (size_t)nw * 64 * 16 * 4 + (size_t)nw * 64 * QTP + (size_t)g.NP2 * 4 + 2 * (size_t)g.KK * 64 * 16; };
     const size_t lds_b = 2 * (size_t)64 * g.TPV + (size_t)64 * g.NP * 4 + 2 * (size_t)g.NP * 4 + (size_t)g.NP2 * 4;
-    if (lds_a > 160 * 1024 || lds_b > 160 * 1024) return MTP_ERR_UNSUPPORTED;
-    (void)hipFuncSetAttribute((const void*)full_bwd_a_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+    if (lds_a(4) > 160 * 1024 || lds_b > 160 * 1024) return MTP_ERR_UNSUPPORTED;
+    (void)hipFuncSetAttribute((const void*)full_bwd_a_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_a(8) <= 160 * 1024 ? lds_a(8) : lds_a(4)));
+    (void)hipFuncSetAttribute((const void*)full_bwd_a_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a(4));
     (void)hipFuncSetAttribute((const void*)full_bwd_b_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-    hipLaunchKernelGGL(full_bwd_a_mfma_kernel, dim3((unsigned)(B * heads)), dim3(256), lds_a, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
-                       (bf16_t*)dqkv, rel_h, rel_w, drel_part, g, scale);
+    if (lds_a(8) <= 160 * 1024)
+        hipLaunchKernelGGL(full_bwd_a_mfma_kernel<8>, dim3((unsigned)(B * heads)), dim3(512), lds_a(8), s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
+                           (bf16_t*)dqkv, rel_h, rel_w, drel_part, g, scale);
+    else
+        hipLaunchKernelGGL(full_bwd_a_mfma_kernel<4>, dim3((unsigned)(B * heads)), dim3(256), lds_a(4), s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
+                           (bf16_t*)dqkv, rel_h, rel_w, drel_part, g, scale);
     hipLaunchKernelGGL(full_bwd_b_mfma_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_b, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, rel_h, rel_w, g, scale);
     return mtp_launch_status();
