@@ -937,6 +937,8 @@ extern "C" int mtp_rvsa_attn_bwd(const void* qkv, const float* samp, const void*
     const RvsaGeom g = make_geom(Hp, Wp, heads);
     const int64_t Ttok = B * Hp * Wp, C = heads * HD;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16 && mtp_use_mfma_attn() && mtp_rvsa_bwd_mfma_scatter_mode(Hp, Wp, heads) == 4)     // dense-product scatter: dqkv's k / v
+        return mtp_rvsa_bwd_mfma_launch(qkv, samp, o, dout, lse, dqkv, dkv_f32, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, B, Hp, Wp, heads, scale, s);   // parts are written once, no scratch passes
     hipError_t e = hipMemsetAsync(dkv_f32, 0, sizeof(float) * (size_t)(Ttok * 2 * C), s);
     if (e != hipSuccess) return (int)e;
     // every real token is the query of exactly one window, so the q part of dqkv is fully written by the kernel

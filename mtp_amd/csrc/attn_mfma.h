@@ -8,6 +8,9 @@ int mtp_rvsa_fwd_mfma_launch(const void* qkv, const float* samp, void* o, float*
 int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse, void* dqkv, float* dkv, float* dsamp,
                              float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
+// how the 4-wave RVSA backward scatters dK_sel / dV_sel for this grid (attn_rvsa_bwd4.hip): 4 = separate dense-product kernel (no f32
+// scratch: the caller skips its clearing / conversion passes), 1 / 0 = f32 atomics into the scratch, 2 = none
+int mtp_rvsa_bwd_mfma_scatter_mode(int64_t Hp, int64_t Wp, int64_t heads);
 int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* rel_h, const float* rel_w,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
 int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,

@@ -458,7 +458,9 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
             *reinterpret_cast<uint2*>(Ks + o) = make_uint2(pack_bf16x2(dks[dt][0], dks[dt][1]), pack_bf16x2(dks[dt][2], dks[dt][3]));
             *reinterpret_cast<uint2*>(Vs + o) = make_uint2(pack_bf16x2(dvs[dt][0], dvs[dt][1]), pack_bf16x2(dvs[dt][2], dvs[dt][3]));
         }
-        if (dense_scatter) {
+        if (dense_scatter == 4) {
+            // "gemm" scatter: the rows just written to Ks / Vs leave the kernel (below); rvsa_scatter_gemm_kernel sums them per token
+        } else if (dense_scatter) {
             // dK_sel^T / dV_sel^T -> bf16 [d][key] images over Q^T | dO^T; the scatter itself runs after the coordinate
             // gradients, see the end of the kernel
 #pragma unroll
@@ -491,6 +493,14 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     }
     __syncthreads();   // dK_sel / dV_sel rows complete
     if (stop_after == 6) return;
+    if (dense_scatter == 4) {
+        // dK_sel | dV_sel (49 x 64 bf16 each) of this (image, window, head) -> the scratch buffer, row-major: 98 rows x 8 chunks of 16 B
+        bf16_t* out = reinterpret_cast<bf16_t*>(dkv) + (int64_t)blockIdx.x * (2 * 49 * HD);
+        for (int idx = tid; idx < 2 * 49 * 8; idx += 256) {
+            const int m = idx / (49 * 8), rem = idx - m * (49 * 8), key = rem >> 3, ch = rem & 7;
+            *reinterpret_cast<uint4*>(out + (m * 49 + key) * HD + 8 * ch) = *reinterpret_cast<const uint4*>((m ? Vs : Ks) + swz(key, ch));
+        }
+    }
     {   // ---- coordinate gradients: lane = (key of a group of 8, 16-B chunk): d(K_sel, V_sel)/d(ix, iy) needs the four neighbour rows
         // (all neighbour loads of the wave's two key groups issued before the first use, as in the gather)
         const int kl = lane >> 3, ch = lane & 7;
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         const float sum = (vsum[tid] + vsum[8 + tid]) + (vsum[16 + tid] + vsum[24 + tid]);
         dp[tid < 2 ? 2 * h + tid : tid < 4 ? 2 * H + 2 * h + (tid - 2) : 4 * H + h] = sum;
     }
-    if (dense_scatter) {
+    if (dense_scatter && dense_scatter != 4) {
         // ================= scatter of dK_sel / dV_sel through the bilinear weights, as a product on the matrix cores =========
         // dK[token][d] += sum_key W[token][key] dK_sel[key][d],  W = hat(ix_key - X_token) hat(iy_key - Y_token) -- the same four
         // corner weights, summed per TOKEN before they leave the workgroup.  The memory side retires ~31 G 64-byte f32 atomics/s
@@ -630,6 +640,122 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     }
 }
 
+// ===================================================================================================================
+// "gemm" scatter (round 2, token grids of <= 256 tokens): dK[token] = sum over ALL samples of the image (windows x 49 keys) of
+// W[token][sample] dK_sel[sample],  W = hat(ix_s - X_t) hat(iy_s - Y_t) -- the bilinear scatter of a whole (image, head) as ONE dense
+// product on the matrix cores, every token row written exactly once: no atomics, no f32 scratch, no clearing pass, no conversion
+// pass (those were 26 + ~50 + 24 us per block at ViT-L, B = 64).  The backward kernel above leaves dK_sel / dV_sel (bf16 rows) in the
+// scratch buffer; one workgroup per (image, head) stages them row-major in LDS (K^T-style fragments come out of
+// ds_read_b64_tr_b16), recomputes the sample positions from the five sampling scalars and builds the W fragments in registers.
+// dynamic LDS: Kimg | Vimg (SP x 128 B, swizzled) | xs[SP] | ys[SP]          SP = samples rounded up to 32
+// ===================================================================================================================
+typedef short tr4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 rows_frag_tr(const char* img, int row0, int dt, int fr) {   // (d = 16 dt + fr; rows row0..+3, row0+16..+19)
+    const int c = 16 * dt + 4 * (fr & 3);
+    const int ra = row0 + (fr >> 2), rb = ra + 16;
+    const int oa = ra * 128 + (((c >> 3) ^ (ra & 7)) << 4) + (c & 7) * 2, ob = rb * 128 + (((c >> 3) ^ (rb & 7)) << 4) + (c & 7) * 2;
+    const tr4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4s_t*)(img + oa));
+    const tr4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4s_t*)(img + ob));
+    const uint2 l = __builtin_bit_cast(uint2, lo), hh = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, hh.x, hh.y);
+}
+
+__global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t* __restrict__ dsel, const float* __restrict__ samp, bf16_t* __restrict__ dqkv,
+                                                                  RvsaGeom g, int SP) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    char* Kimg = sm;
+    char* Vimg = Kimg + SP * 128;
+    float* xs = reinterpret_cast<float*>(Vimg + SP * 128);
+    float* ys = xs + SP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, gq = lane >> 4;
+    const int H = g.heads, nW = g.nh * g.nw, S = nW * 49;
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const int C = H * HD, N = g.Hp * g.Wp;
+    for (int s = tid; s < SP; s += 256) {
+        float x = -1.0e4f, y = -1.0e4f;
+        if (s < S) {
+            const int w = s / 49, k = s - 49 * w;
+            const Sample sa = make_sample(g, samp + (int64_t)(b * nW + w) * 5 * H, h, w / g.nw, w % g.nw, k / 7, k % 7);
+            x = (float)sa.x0 + sa.fx;
+            y = (float)sa.y0 + sa.fy;
+        }
+        xs[s] = x;
+        ys[s] = y;
+    }
+    for (int idx = tid; idx < SP * 8; idx += 256) {
+        const int s = idx >> 3, ch = idx & 7;
+        uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
+        if (s < S) {
+            const int w = s / 49, k = s - 49 * w;
+            const bf16_t* src = dsel + ((int64_t)(b * nW + w) * H + h) * (2 * 49 * HD) + k * HD + 8 * ch;
+            kv = ldg16(src);
+            vv = ldg16(src + 49 * HD);
+        }
+        *reinterpret_cast<uint4*>(Kimg + swz(s, ch)) = kv;
+        *reinterpret_cast<uint4*>(Vimg + swz(s, ch)) = vv;
+    }
+    __syncthreads();
+    const int64_t ld = 3 * (int64_t)C;
+    // wave w owns token tiles w, w + 4, w + 8, w + 12 (N <= 256): the K / V fragments and the sample coordinates of a 32-sample step are
+    // read from LDS ONCE and used for all of them (with the tile loop outside, the same fragments were re-read 13 times and the
+    // kernel was LDS-issue bound: 45 us)
+    float X[4], Y[4], live[4];
+    f32x4_t dk[4][4], dv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = 16 * (wave + 4 * i) + fr;
+        const int tc = t < N ? t : N - 1;
+        const int ty = tc / g.Wp, tx = tc - ty * g.Wp;
+        X[i] = (float)(tx + g.pad_l);
+        Y[i] = (float)(ty + g.pad_t);
+        live[i] = t < N ? 1.f : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dk[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dv[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const int ntile = (N + 15) / 16;
+    for (int kk = 0; kk < SP / 32; ++kk) {
+        const int s0 = 32 * kk + 4 * gq;
+        const float4 xa = *reinterpret_cast<const float4*>(xs + s0), xb = *reinterpret_cast<const float4*>(xs + s0 + 16);
+        const float4 ya = *reinterpret_cast<const float4*>(ys + s0), yb = *reinterpret_cast<const float4*>(ys + s0 + 16);
+        const float sx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, sy[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+        uint4 kf[4], vf[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            kf[dt] = rows_frag_tr(Kimg, s0, dt, fr);
+            vf[dt] = rows_frag_tr(Vimg, s0, dt, fr);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (wave + 4 * i < ntile) {      // (wave-uniform)
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = live[i] * fmaxf(0.f, 1.f - fabsf(sx[e] - X[i])) * fmaxf(0.f, 1.f - fabsf(sy[e] - Y[i]));
+                const uint4 wf = pack_bf16x8(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dk[i][dt] = mma(kf[dt], wf, dk[i][dt]);     // D[d = 16 dt + 4 gq + r][token fr]
+                    dv[i][dt] = mma(vf[dt], wf, dv[i][dt]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = 16 * (wave + 4 * i) + fr;
+        if (t < N) {
+            bf16_t* row = dqkv + ((int64_t)b * N + t) * ld + C + h * HD + 4 * gq;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                store4(row + 16 * dt, make_float4(dk[i][dt][0], dk[i][dt][1], dk[i][dt][2], dk[i][dt][3]));
+                store4(row + C + 16 * dt, make_float4(dv[i][dt][0], dv[i][dt][1], dv[i][dt][2], dv[i][dt][3]));
+            }
+        }
+    }
+}
+
 RvsaGeom make_geom(int64_t Hp, int64_t Wp, int64_t heads) {
     RvsaGeom g;
     const int pad_h = (int)((7 - Hp % 7) % 7), pad_w = (int)((7 - Wp % 7) % 7);
@@ -645,18 +771,36 @@ RvsaGeom make_geom(int64_t Hp, int64_t Wp, int64_t heads) {
 
 }  // namespace
 
+// 4 = the scatter runs as rvsa_scatter_gemm_kernel (the caller then skips the clearing and conversion passes of the f32 scratch),
+// 1 = f32 atomics per token tile inside the backward kernel, 0 = per (key, corner) atomics, 2 = none (ablation)
+int mtp_rvsa_bwd_mfma_scatter_mode(int64_t Hp, int64_t Wp, int64_t heads) {
+    static const int forced = []() {
+        const char* e = getenv("MTP_RVSA_SCATTER");   // "gemm" (default where it fits) | "dense" | "corner" | "none"
+        return !e ? -1 : e[0] == 'c' ? 0 : e[0] == 'n' ? 2 : e[0] == 'd' ? 1 : -1;
+    }();
+    if (forced >= 0) return forced;
+    const RvsaGeom g = make_geom(Hp, Wp, heads);
+    const int64_t N = Hp * Wp, nW = (int64_t)g.nh * g.nw, SP = (nW * 49 + 31) / 32 * 32;
+    const bool fits = N <= 256 && SP * (256 + 8) <= 80 * 1024 && nW * (2 * 49 * HD * 2) <= N * 2 * HD * 4;   // LDS for two workgroups per CU; scratch size
+    return fits ? 4 : 1;
+}
+
 int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, const void* dout, const float* lse, void* dqkv, float* dkv, float* dsamp,
                              float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     const RvsaGeom g = make_geom(Hp, Wp, heads);
-    static const int dense = []() {
-        const char* e = getenv("MTP_RVSA_SCATTER");   // "corner": per-(key, corner) atomics (A/B); "none": ablation, no scatter at all
+    static const int stop = []() {
         const char* st = getenv("MTP_RVSA_STOP");     // phase-timing ablation: return after phase 1..6
-        return ((e && e[0] == 'c') ? 0 : (e && e[0] == 'n') ? 2 : 1) | ((st ? atoi(st) : 0) << 4);
+        return st ? atoi(st) : 0;
     }();
-
-
+    const int mode = mtp_rvsa_bwd_mfma_scatter_mode(Hp, Wp, heads);
     hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
-                       (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, dense);
+                       (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, mode | (stop << 4));
+    if (mode == 4 && !stop) {
+        const int SP = (g.nh * g.nw * 49 + 31) / 32 * 32;
+        const size_t lds = (size_t)SP * (256 + 8);
+        (void)hipFuncSetAttribute((const void*)rvsa_scatter_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(rvsa_scatter_gemm_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, (const bf16_t*)dkv, samp, (bf16_t*)dqkv, g, SP);
+    }
     return mtp_launch_status();
 }
