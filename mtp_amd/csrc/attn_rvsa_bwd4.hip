@@ -661,7 +661,8 @@ __device__ __forceinline__ uint4 rows_frag_tr(const char* img, int row0, int dt,
 }
 
 __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t* __restrict__ dsel, const float* __restrict__ samp, bf16_t* __restrict__ dqkv,
-                                                                  RvsaGeom g, int SP) {
+                                                                  RvsaGeom g, int SP_) {
+    const int SP = SP_ & 0xffff, ablate = SP_ >> 16;      // ablate (MTP_RVSA_GEMM_ABLATE): bit0 no product loop, bit1 no stores
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* Kimg = sm;
     char* Vimg = Kimg + SP * 128;
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t*
         }
     }
     const int ntile = (N + 15) / 16;
-    for (int kk = 0; kk < SP / 32; ++kk) {
+    for (int kk = 0; kk < ((ablate & 1) ? 0 : SP / 32); ++kk) {
         const int s0 = 32 * kk + 4 * gq;
         const float4 xa = *reinterpret_cast<const float4*>(xs + s0), xb = *reinterpret_cast<const float4*>(xs + s0 + 16);
         const float4 ya = *reinterpret_cast<const float4*>(ys + s0), yb = *reinterpret_cast<const float4*>(ys + s0 + 16);
@@ -742,16 +743,37 @@ __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t*
             }
         }
     }
+    // results -> bf16 rows in LDS (over the K / V images, which nobody reads any more) -> whole 128-byte rows to global: out of the MFMA
+    // layout a lane holds 4 channels of one token, i.e. 8-byte stores 6 KiB apart (measured: 11.5 of the kernel's 40 us)
+    __syncthreads();
+    const bool via_lds = N <= SP;       // (always, for <= 256 tokens and >= 2 windows; otherwise straight from the registers)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int t = 16 * (wave + 4 * i) + fr;
-        if (t < N) {
-            bf16_t* row = dqkv + ((int64_t)b * N + t) * ld + C + h * HD + 4 * gq;
+        if (t < N && !(ablate & 2)) {
+            if (via_lds) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                store4(row + 16 * dt, make_float4(dk[i][dt][0], dk[i][dt][1], dk[i][dt][2], dk[i][dt][3]));
-                store4(row + C + 16 * dt, make_float4(dv[i][dt][0], dv[i][dt][1], dv[i][dt][2], dv[i][dt][3]));
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int o = t * 128 + (((2 * dt + (gq >> 1)) ^ (t & 7)) << 4) + (gq & 1) * 8;
+                    *reinterpret_cast<uint2*>(Kimg + o) = make_uint2(pack_bf16x2(dk[i][dt][0], dk[i][dt][1]), pack_bf16x2(dk[i][dt][2], dk[i][dt][3]));
+                    *reinterpret_cast<uint2*>(Vimg + o) = make_uint2(pack_bf16x2(dv[i][dt][0], dv[i][dt][1]), pack_bf16x2(dv[i][dt][2], dv[i][dt][3]));
+                }
+            } else {
+                bf16_t* row = dqkv + ((int64_t)b * N + t) * ld + C + h * HD + 4 * gq;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    store4(row + 16 * dt, make_float4(dk[i][dt][0], dk[i][dt][1], dk[i][dt][2], dk[i][dt][3]));
+                    store4(row + C + 16 * dt, make_float4(dv[i][dt][0], dv[i][dt][1], dv[i][dt][2], dv[i][dt][3]));
+                }
             }
+        }
+    }
+    if (via_lds && !(ablate & 2)) {
+        __syncthreads();
+        for (int idx = tid; idx < N * 16; idx += 256) {       // (token, K | V, 16-byte chunk)
+            const int t = idx >> 4, m = (idx >> 3) & 1, ch = idx & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>((m ? Vimg : Kimg) + swz(t, ch));
+            *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * N + t) * ld + (1 + m) * C + h * HD + 8 * ch) = v;
         }
     }
 }
@@ -800,7 +822,8 @@ int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, 
         const int SP = (g.nh * g.nw * 49 + 31) / 32 * 32;
         const size_t lds = (size_t)SP * (256 + 8);
         (void)hipFuncSetAttribute((const void*)rvsa_scatter_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(rvsa_scatter_gemm_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, (const bf16_t*)dkv, samp, (bf16_t*)dqkv, g, SP);
+        static const int abl = []() { const char* e = getenv("MTP_RVSA_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+        hipLaunchKernelGGL(rvsa_scatter_gemm_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, (const bf16_t*)dkv, samp, (bf16_t*)dqkv, g, SP | (abl << 16));
     }
     return mtp_launch_status();
 }
