@@ -176,15 +176,18 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 // the same with a transposed result: column j = a * C + b of part (rows, R * C) goes to out[b * R + a] (per-(window, head) partials of
 // the (169, heads) bias-table gradient are written head-major by the RVSA backward: contiguous per workgroup)
 __global__ __launch_bounds__(256) void reduce_rows_t_kernel(const float* __restrict__ part, int64_t ld, float* __restrict__ out, int64_t rows, int R, int C, int64_t rows_per_block) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= (int64_t)R * C) return;
+    // thread = OUTPUT element q = b * R + a (a fastest): the atomics of a wave are 64-byte runs (with thread = input column they were 64
+    // separate segments per instruction: 35 us per call); the reads are strided by C floats but come out of L2 / L1
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (int64_t)R * C) return;
+    const int a = (int)(q % R), b = (int)(q / R);
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     r1 = r1 < rows ? r1 : rows;
+    const float* src = part + (int64_t)a * C + b;
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += part[r * ld + j];
-    const int a = (int)(j / C), b = (int)(j - (int64_t)a * C);
-    atomicAdd(out + (int64_t)b * R + a, s);
+    for (int64_t r = r0; r < r1; ++r) s += src[r * ld];
+    atomicAdd(out + q, s);
 }
 
 // bias gradient: column sums of dY (M, N).  Block = 64 columns-of-4 x 4 row-lanes; grid.y splits the rows; f32 atomics.
@@ -324,9 +327,9 @@ extern "C" int mtp_reduce_rows_t_f32(const float* part, int64_t ld, float* out, 
         if (e != hipSuccess) return (int)e;
     }
     const int64_t col_blocks = (R * C + 255) / 256;
-    int64_t splits = 1024 / col_blocks;
+    int64_t splits = 512 / col_blocks;      // >= 8 rows per thread: few atomics per output, enough loads in flight
     if (splits < 1) splits = 1;
-    if (splits > rows) splits = rows;
+    if (splits > (rows + 7) / 8) splits = (rows + 7) / 8;
     const int64_t rpb = (rows + splits - 1) / splits;
     splits = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(reduce_rows_t_kernel, dim3((unsigned)col_blocks, (unsigned)splits), dim3(256), 0, s, part, ld, out, rows, (int)R, (int)C, rpb);
