@@ -1,8 +1,8 @@
 // bf16 MFMA kernels for the full (global) attention blocks of the MTP backbone (Attention.forward, VIT:90-111, with the
 // decomposed relative-position terms of calc_rel_pos_spatial, VIT:142-193), gfx950, head_dim 64, N = Hp*Wp <= 256 tokens.
 //
-// One 256-thread workgroup per (image, head); K (row-major, XOR-swizzled) and V^T (transposed image) live in LDS; each of
-// the 4 waves owns 16-query tiles.  Same tricks as the RVSA kernels (attn_mfma.hip): S^T = K.Q^T so a query's softmax is
+// One workgroup per (image, head) (forward: 4 waves; backward A / B: 8 waves where the LDS allows); K (row-major, XOR-swizzled) and
+// V^T (transposed image) live in LDS; each wave owns 16-query (or 16-key) tiles.  Same tricks as the RVSA kernels (attn_mfma.hip): S^T = K.Q^T so a query's softmax is
 // in-lane + two shuffles and P is directly the B operand of O^T = V^T.P^T; the q.Rh / q.Rw terms are one MFMA against the
 // tables, exchanged through a per-wave LDS tile; the backward uses both MFMA orientations instead of transposing P/dS:
 //   kernel A (lane: query, 4 keys)  : dQ^T = K^T.dS^T + Rh^T.dQRh + Rw^T.dQRw,  d(rel_pos_h/w) partials

@@ -654,8 +654,9 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     if (EPI == MTP_EPI_BIAS_RES && (!a->res || (a->res_ld % 4))) return MTP_ERR_ARG;
     if ((EPI == MTP_EPI_BIAS_GELU || EPI == MTP_EPI_DGELU || EPI == MTP_EPI_BIAS_GELU_DG || EPI == MTP_EPI_MUL) && (!a->aux || (a->aux_ld % 4))) return MTP_ERR_ARG;
     if (a->bias && a->bias_mod > 0 && (a->bias_mod % 4)) return MTP_ERR_ARG;
-    // 256 x 256 8-wave pipelined kernel (gemm_p8.hip; bf16, whole K-tile pairs): variant bits 8-9 = 1 one workgroup per tile,
-    // 2 persistent workgroups; falls through to the 128-wide kernels when the problem does not fit it
+    // 8-wave pipelined kernel (gemm_p8.hip; bf16, whole K-tile pairs): variant bits 8-9 pick the tile height (1 auto, 2 = 224 rows,
+    // 3 = 256 rows), bits 11-14 an ablation build, bits 15 / 16 force / forbid persistent tiles; falls through to the 128-wide kernels
+    // when the problem does not fit it
     if constexpr (sizeof(T) == 2) {
         const int p8 = nt_p8_mode(a, k);
         if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4) | (((a->variant >> 15) & 3) << 8), stream);
