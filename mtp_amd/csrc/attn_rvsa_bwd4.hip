@@ -641,13 +641,13 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
 }
 
 // ===================================================================================================================
-// "gemm" scatter (round 2, token grids of <= 256 tokens): dK[token] = sum over ALL samples of the image (windows x 49 keys) of
+// "gemm" scatter (round 2): dK[token] = sum over ALL samples of the image (windows x 49 keys) of
 // W[token][sample] dK_sel[sample],  W = hat(ix_s - X_t) hat(iy_s - Y_t) -- the bilinear scatter of a whole (image, head) as ONE dense
 // product on the matrix cores, every token row written exactly once: no atomics, no f32 scratch, no clearing pass, no conversion
 // pass (those were 26 + ~50 + 24 us per block at ViT-L, B = 64).  The backward kernel above leaves dK_sel / dV_sel (bf16 rows) in the
 // scratch buffer; one workgroup per (image, head) stages them row-major in LDS (K^T-style fragments come out of
 // ds_read_b64_tr_b16), recomputes the sample positions from the five sampling scalars and builds the W fragments in registers.
-// dynamic LDS: Kimg | Vimg (SP x 128 B, swizzled) | xs[SP] | ys[SP]          SP = samples rounded up to 32
+// LDS: Kimg | Vimg (224 x 128 B, swizzled) | xs | ys
 // ===================================================================================================================
 typedef short tr4s_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 rows_frag_tr(const char* img, int row0, int dt, int fr) {   // (d = 16 dt + fr; rows row0..+3, row0+16..+19)
@@ -660,85 +660,96 @@ __device__ __forceinline__ uint4 rows_frag_tr(const char* img, int row0, int dt,
     return make_uint4(l.x, l.y, hh.x, hh.y);
 }
 
+constexpr int SCB = 224;      // tokens per workgroup (band) = samples per staged chunk: 7 token tiles of 32 / 7 k-steps of 32
+
+// grid (B * heads, bands of SCB tokens).  The samples of the (image, head) are staged SCB at a time; a chunk none of whose samples can
+// touch the band's token rows is skipped before its rows are loaded (for near-identity sampling a band sees the windows of its own rows
+// only, so larger grids cost about one chunk per band, not windows x bands).  <= 224 tokens (the 14 x 14 grid): one band, one chunk.
 __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t* __restrict__ dsel, const float* __restrict__ samp, bf16_t* __restrict__ dqkv,
-                                                                  RvsaGeom g, int SP_) {
-    const int SP = SP_ & 0xffff, ablate = SP_ >> 16;      // ablate (MTP_RVSA_GEMM_ABLATE): bit0 no product loop, bit1 no stores
-    extern __shared__ __attribute__((aligned(16))) char sm[];
-    char* Kimg = sm;
-    char* Vimg = Kimg + SP * 128;
-    float* xs = reinterpret_cast<float*>(Vimg + SP * 128);
-    float* ys = xs + SP;
+                                                                  RvsaGeom g, int ablate) {     // ablate (MTP_RVSA_GEMM_ABLATE): bit0 no product loop, bit1 no stores
+    __shared__ __attribute__((aligned(16))) char Kimg[SCB * 128];
+    __shared__ __attribute__((aligned(16))) char Vimg[SCB * 128];
+    __shared__ __attribute__((aligned(16))) float xs[SCB];
+    __shared__ __attribute__((aligned(16))) float ys[SCB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, gq = lane >> 4;
     const int H = g.heads, nW = g.nh * g.nw, S = nW * 49;
     const int h = blockIdx.x % H, b = blockIdx.x / H;
     const int C = H * HD, N = g.Hp * g.Wp;
-    for (int s = tid; s < SP; s += 256) {
-        float x = -1.0e4f, y = -1.0e4f;
-        if (s < S) {
-            const int w = s / 49, k = s - 49 * w;
-            const Sample sa = make_sample(g, samp + (int64_t)(b * nW + w) * 5 * H, h, w / g.nw, w % g.nw, k / 7, k % 7);
-            x = (float)sa.x0 + sa.fx;
-            y = (float)sa.y0 + sa.fy;
-        }
-        xs[s] = x;
-        ys[s] = y;
-    }
-    for (int idx = tid; idx < SP * 8; idx += 256) {
-        const int s = idx >> 3, ch = idx & 7;
-        uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
-        if (s < S) {
-            const int w = s / 49, k = s - 49 * w;
-            const bf16_t* src = dsel + ((int64_t)(b * nW + w) * H + h) * (2 * 49 * HD) + k * HD + 8 * ch;
-            kv = ldg16(src);
-            vv = ldg16(src + 49 * HD);
-        }
-        *reinterpret_cast<uint4*>(Kimg + swz(s, ch)) = kv;
-        *reinterpret_cast<uint4*>(Vimg + swz(s, ch)) = vv;
-    }
-    __syncthreads();
+    const int t0 = blockIdx.y * SCB, nt = (N - t0) < SCB ? (N - t0) : SCB;      // this band: tokens [t0, t0 + nt)
     const int64_t ld = 3 * (int64_t)C;
-    // wave w owns token tiles w, w + 4, w + 8, w + 12 (N <= 256): the K / V fragments and the sample coordinates of a 32-sample step are
-    // read from LDS ONCE and used for all of them (with the tile loop outside, the same fragments were re-read 13 times and the
-    // kernel was LDS-issue bound: 45 us)
+    // wave w owns token tiles w, w + 4, w + 8, w + 12 of the band (14 tiles): the K / V fragments and the sample coordinates of a
+    // 32-sample step are read from LDS ONCE and used for all of them (with the tile loop outside the kernel was LDS-issue bound)
     float X[4], Y[4], live[4];
     f32x4_t dk[4][4], dv[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int t = 16 * (wave + 4 * i) + fr;
-        const int tc = t < N ? t : N - 1;
+        const int tl = 16 * (wave + 4 * i) + fr;
+        const int tc = t0 + (tl < nt ? tl : nt - 1);
         const int ty = tc / g.Wp, tx = tc - ty * g.Wp;
         X[i] = (float)(tx + g.pad_l);
         Y[i] = (float)(ty + g.pad_t);
-        live[i] = t < N ? 1.f : 0.f;
+        live[i] = tl < nt ? 1.f : 0.f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             dk[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             dv[i][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const int ntile = (N + 15) / 16;
-    for (int kk = 0; kk < ((ablate & 1) ? 0 : SP / 32); ++kk) {
-        const int s0 = 32 * kk + 4 * gq;
-        const float4 xa = *reinterpret_cast<const float4*>(xs + s0), xb = *reinterpret_cast<const float4*>(xs + s0 + 16);
-        const float4 ya = *reinterpret_cast<const float4*>(ys + s0), yb = *reinterpret_cast<const float4*>(ys + s0 + 16);
-        const float sx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, sy[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
-        uint4 kf[4], vf[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            kf[dt] = rows_frag_tr(Kimg, s0, dt, fr);
-            vf[dt] = rows_frag_tr(Vimg, s0, dt, fr);
+    const int ntile = (nt + 15) / 16;
+    const float ylo = (float)(t0 / g.Wp + g.pad_t) - 1.0f, yhi = (float)((t0 + nt - 1) / g.Wp + g.pad_t) + 1.0f;   // a sample outside (ylo, yhi) has weight 0 on every token row of the band
+    for (int c0 = 0; c0 < S; c0 += SCB) {
+        __syncthreads();      // the previous chunk's fragments have been read
+        int hit = 0;
+        if (tid < SCB) {
+            const int sg = c0 + tid;
+            float x = -1.0e4f, y = -1.0e4f;
+            if (sg < S) {
+                const int w = sg / 49, k = sg - 49 * w;
+                const Sample sa = make_sample(g, samp + (int64_t)(b * nW + w) * 5 * H, h, w / g.nw, w % g.nw, k / 7, k % 7);
+                x = (float)sa.x0 + sa.fx;
+                y = (float)sa.y0 + sa.fy;
+            }
+            xs[tid] = x;
+            ys[tid] = y;
+            hit = (y > ylo && y < yhi) ? 1 : 0;
         }
+        if (!__syncthreads_or(hit)) continue;       // (uniform) nothing in this chunk reaches the band
+        for (int idx = tid; idx < SCB * 8; idx += 256) {
+            const int sl = idx >> 3, ch = idx & 7, sg = c0 + sl;
+            uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
+            if (sg < S) {
+                const int w = sg / 49, k = sg - 49 * w;
+                const bf16_t* src = dsel + ((int64_t)(b * nW + w) * H + h) * (2 * 49 * HD) + k * HD + 8 * ch;
+                kv = ldg16(src);
+                vv = ldg16(src + 49 * HD);
+            }
+            *reinterpret_cast<uint4*>(Kimg + swz(sl, ch)) = kv;
+            *reinterpret_cast<uint4*>(Vimg + swz(sl, ch)) = vv;
+        }
+        __syncthreads();
+        for (int kk = 0; kk < ((ablate & 1) ? 0 : SCB / 32); ++kk) {
+            const int s0 = 32 * kk + 4 * gq;
+            const float4 xa = *reinterpret_cast<const float4*>(xs + s0), xb = *reinterpret_cast<const float4*>(xs + s0 + 16);
+            const float4 ya = *reinterpret_cast<const float4*>(ys + s0), yb = *reinterpret_cast<const float4*>(ys + s0 + 16);
+            const float sx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, sy[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+            uint4 kf[4], vf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (wave + 4 * i < ntile) {      // (wave-uniform)
-                float w[8];
+            for (int dt = 0; dt < 4; ++dt) {
+                kf[dt] = rows_frag_tr(Kimg, s0, dt, fr);
+                vf[dt] = rows_frag_tr(Vimg, s0, dt, fr);
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) w[e] = live[i] * fmaxf(0.f, 1.f - fabsf(sx[e] - X[i])) * fmaxf(0.f, 1.f - fabsf(sy[e] - Y[i]));
-                const uint4 wf = pack_bf16x8(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+            for (int i = 0; i < 4; ++i) {
+                if (wave + 4 * i < ntile) {      // (wave-uniform)
+                    float w[8];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    dk[i][dt] = mma(kf[dt], wf, dk[i][dt]);     // D[d = 16 dt + 4 gq + r][token fr]
-                    dv[i][dt] = mma(vf[dt], wf, dv[i][dt]);
+                    for (int e = 0; e < 8; ++e) w[e] = live[i] * fmaxf(0.f, 1.f - fabsf(sx[e] - X[i])) * fmaxf(0.f, 1.f - fabsf(sy[e] - Y[i]));
+                    const uint4 wf = pack_bf16x8(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        dk[i][dt] = mma(kf[dt], wf, dk[i][dt]);     // D[d = 16 dt + 4 gq + r][token fr]
+                        dv[i][dt] = mma(vf[dt], wf, dv[i][dt]);
+                    }
                 }
             }
         }
@@ -746,35 +757,24 @@ __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t*
     // results -> bf16 rows in LDS (over the K / V images, which nobody reads any more) -> whole 128-byte rows to global: out of the MFMA
     // layout a lane holds 4 channels of one token, i.e. 8-byte stores 6 KiB apart (measured: 11.5 of the kernel's 40 us)
     __syncthreads();
-    const bool via_lds = N <= SP;       // (always, for <= 256 tokens and >= 2 windows; otherwise straight from the registers)
+    if (ablate & 2) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int t = 16 * (wave + 4 * i) + fr;
-        if (t < N && !(ablate & 2)) {
-            if (via_lds) {
+        const int tl = 16 * (wave + 4 * i) + fr;
+        if (tl < nt) {
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int o = t * 128 + (((2 * dt + (gq >> 1)) ^ (t & 7)) << 4) + (gq & 1) * 8;
-                    *reinterpret_cast<uint2*>(Kimg + o) = make_uint2(pack_bf16x2(dk[i][dt][0], dk[i][dt][1]), pack_bf16x2(dk[i][dt][2], dk[i][dt][3]));
-                    *reinterpret_cast<uint2*>(Vimg + o) = make_uint2(pack_bf16x2(dv[i][dt][0], dv[i][dt][1]), pack_bf16x2(dv[i][dt][2], dv[i][dt][3]));
-                }
-            } else {
-                bf16_t* row = dqkv + ((int64_t)b * N + t) * ld + C + h * HD + 4 * gq;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    store4(row + 16 * dt, make_float4(dk[i][dt][0], dk[i][dt][1], dk[i][dt][2], dk[i][dt][3]));
-                    store4(row + C + 16 * dt, make_float4(dv[i][dt][0], dv[i][dt][1], dv[i][dt][2], dv[i][dt][3]));
-                }
+            for (int dt = 0; dt < 4; ++dt) {
+                const int o = tl * 128 + (((2 * dt + (gq >> 1)) ^ (tl & 7)) << 4) + (gq & 1) * 8;
+                *reinterpret_cast<uint2*>(Kimg + o) = make_uint2(pack_bf16x2(dk[i][dt][0], dk[i][dt][1]), pack_bf16x2(dk[i][dt][2], dk[i][dt][3]));
+                *reinterpret_cast<uint2*>(Vimg + o) = make_uint2(pack_bf16x2(dv[i][dt][0], dv[i][dt][1]), pack_bf16x2(dv[i][dt][2], dv[i][dt][3]));
             }
         }
     }
-    if (via_lds && !(ablate & 2)) {
-        __syncthreads();
-        for (int idx = tid; idx < N * 16; idx += 256) {       // (token, K | V, 16-byte chunk)
-            const int t = idx >> 4, m = (idx >> 3) & 1, ch = idx & 7;
-            const uint4 v = *reinterpret_cast<const uint4*>((m ? Vimg : Kimg) + swz(t, ch));
-            *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * N + t) * ld + (1 + m) * C + h * HD + 8 * ch) = v;
-        }
+    __syncthreads();
+    for (int idx = tid; idx < nt * 16; idx += 256) {       // (token, K | V, 16-byte chunk)
+        const int tl = idx >> 4, m = (idx >> 3) & 1, ch = idx & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>((m ? Vimg : Kimg) + swz(tl, ch));
+        *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * N + t0 + tl) * ld + (1 + m) * C + h * HD + 8 * ch) = v;
     }
 }
 
@@ -802,8 +802,8 @@ int mtp_rvsa_bwd_mfma_scatter_mode(int64_t Hp, int64_t Wp, int64_t heads) {
     }();
     if (forced >= 0) return forced;
     const RvsaGeom g = make_geom(Hp, Wp, heads);
-    const int64_t N = Hp * Wp, nW = (int64_t)g.nh * g.nw, SP = (nW * 49 + 31) / 32 * 32;
-    const bool fits = N <= 256 && SP * (256 + 8) <= 80 * 1024 && nW * (2 * 49 * HD * 2) <= N * 2 * HD * 4;   // LDS for two workgroups per CU; scratch size
+    const int64_t N = Hp * Wp, nW = (int64_t)g.nh * g.nw;
+    const bool fits = Hp <= 64 && Wp <= 64 && nW * (2 * 49 * HD * 2) <= N * 2 * HD * 4;   // (the rows live in the caller's f32 scratch)
     return fits ? 4 : 1;
 }
 
@@ -819,11 +819,9 @@ int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, 
     hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, mode | (stop << 4));
     if (mode == 4 && !stop) {
-        const int SP = (g.nh * g.nw * 49 + 31) / 32 * 32;
-        const size_t lds = (size_t)SP * (256 + 8);
-        (void)hipFuncSetAttribute((const void*)rvsa_scatter_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         static const int abl = []() { const char* e = getenv("MTP_RVSA_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-        hipLaunchKernelGGL(rvsa_scatter_gemm_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, (const bf16_t*)dkv, samp, (bf16_t*)dqkv, g, SP | (abl << 16));
+        const int64_t N = Hp * Wp;
+        hipLaunchKernelGGL(rvsa_scatter_gemm_kernel, dim3((unsigned)(B * heads), (unsigned)((N + SCB - 1) / SCB)), dim3(256), 0, s, (const bf16_t*)dkv, samp, (bf16_t*)dqkv, g, abl);
     }
     return mtp_launch_status();
 }
