@@ -204,15 +204,15 @@ class InternEngine:
         dz2 = ops.scale_residual_bwd(dx32, c["z2"], P[pre + "gamma2"], self._e(rows, C), Gd[pre + "gamma2"], c["s2"], H * W, accumulate=True)
         dv = self._ln_bwd(dz2, c["v"], c["m2"], c["r2"], P, Gd, pre + "norm2.0")
         L1, L2 = self._lin[pre + "mlp.fc1.weight"], self._lin[pre + "mlp.fc2.weight"]
-        ops.gemm_tn(dv, c["u"], Gd[pre + "mlp.fc2.weight"], colsum=Gd[pre + "mlp.fc2.bias"])
+        self._wq.add(dv, c["u"], Gd[pre + "mlp.fc2.weight"], Gd[pre + "mlp.fc2.bias"])
         du = ops.gemm_nt(dv, L2.wt, self._e(rows, L1.R), epi=ops.EPI_MUL, aux=c["ug"])
-        ops.gemm_tn(du, c["xab"], Gd[pre + "mlp.fc1.weight"], colsum=Gd[pre + "mlp.fc1.bias"])
+        self._wq.add(du, c["xab"], Gd[pre + "mlp.fc1.weight"], Gd[pre + "mlp.fc1.bias"])
         dx2 = ops.gemm_nt(du, L1.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx32)      # + the residual path
         # ---- x2 = x + s1 * gamma1 * LN1(output_proj(dcnv3(...)))
         dz1 = ops.scale_residual_bwd(dx2, c["z1"], P[pre + "gamma1"], self._e(rows, C), Gd[pre + "gamma1"], c["s1"], H * W, accumulate=True)
         dh = self._ln_bwd(dz1, c["h"], c["m1"], c["r1"], P, Gd, pre + "norm1.0")
         Lo = self._lin[d + "output_proj.weight"]
-        ops.gemm_tn(dh, c["y"], Gd[d + "output_proj.weight"], colsum=Gd[d + "output_proj.bias"])
+        self._wq.add(dh, c["y"], Gd[d + "output_proj.weight"], Gd[d + "output_proj.bias"])
         dy = ops.gemm_nt(dh, Lo.wt, self._e(rows, C))
         pad = K // 2
         dxp, doff, dmask = dcn.dcnv3_backward(c["xp"].view(N, H, W, C), c["off"].view(N, H, W, -1), c["mask"].view(N, H, W, -1), K, K, 1, 1, pad, pad,
@@ -230,7 +230,7 @@ class InternEngine:
         # input_proj -> d(x); plus the depth-wise branch and the residual path
         Li = self._lin[d + "input_proj.weight"]
         dxpa = self._to_act(dxp.view(rows, C))
-        ops.gemm_tn(dxpa, c["xa"], Gd[d + "input_proj.weight"], colsum=Gd[d + "input_proj.bias"])
+        self._wq.add(dxpa, c["xa"], Gd[d + "input_proj.weight"], Gd[d + "input_proj.bias"])
         dxin = ops.gemm_nt(dxpa, Li.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx2)
         ops.dwconv3x3_bwd_dx(dx1c, P[d + "dw_conv.0.weight"], dxin, N, H, W, accumulate=True)
         return dxin
@@ -292,6 +292,7 @@ class InternEngine:
         P = self.P
         img, cols1, y1, sm1, sr1, a1, cols2, y2, sm2, sr2, (N, Cin, H, W, H1, W1, H2, W2) = ctx["stem"]
         self.dev = cols1.device
+        self._wq = ops.WgradQueue()
         taps = {}
         for idx, d in zip([i for i in range(len(m.depths)) if i in m.out_indices], dfeats):
             taps[idx] = d
@@ -320,8 +321,12 @@ class InternEngine:
             for j in range(len(lv["layers"]) - 1, -1, -1):
                 dx32 = self._layer_bwd("levels.%d.blocks.%d." % (i, j), lv["layers"][j], dx32, N, Hc, Wc, C, Gr, G)
                 lv["layers"][j] = None
-                if on_block_done is not None:
-                    on_block_done(sum(m.depths[:i]) + j)
+                # the Linear weight gradients whose shapes the grouped TN kernel takes (multiples of 256: the 768- and 1536-channel levels)
+                # are queued and launched a few layers at a time (ops.WgradQueue); the layer is reported once they are out
+                if j == 0 or self._wq.should_flush():
+                    self._wq.flush()
+                    if on_block_done is not None:
+                        on_block_done(sum(m.depths[:i]) + j)
         if dx32 is None:
             return None
         # ---- stem backward
