@@ -261,6 +261,9 @@ int mtp_rvsa_attn_bwd(const void* qkv, const float* samp, const void* o, const v
 
 /* ---- optimizer (the step recipe around the path: MAIN:424-457,783-788) ---------------------------------------- */
 /* sum of squares of g[0:n] accumulated into *out (f32, zeroed by caller) -- for clip_grad_norm_ */
+/* base[start[i] .. start[i] + count[i]) = 0, i < n; start / count: DEVICE arrays (the accumulating segments of a flat gradient buffer;
+ * one workgroup per entry: split long runs) */
+int mtp_zero_segments_f32(float* base, const int64_t* start, const int64_t* count, int n, mtp_stream_t stream);
 int mtp_sqnorm_f32(const float* g, float* out, int64_t n, mtp_stream_t stream);
 /* AdamW over a flat f32 buffer; per-segment weight decay via sorted seg_start[nseg] (element offsets) and seg_wd[nseg];
  * hyper (device, f32[6]) = {lr, beta1, beta2, eps, bias_corr1, bias_corr2}; clip_coef = min(1, max_norm / (sqrt(*sqnorm)+1e-6)) if sqnorm */

@@ -339,6 +339,15 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
                                       pad_size_divisor=int(pad_size_divisor), pad_value=float(pad_value))
         return self
 
+    @staticmethod
+    def _overwritten_grads(name):
+        """gradients the engine writes with a full overwrite in EVERY backward (mtp_amd.parallel.FlatParams skips clearing them): the four
+        Linear weights of each block and the patch embedding -- TN GEMM outputs, 97 % of the buffer.  (Not the FPN weights: a loss that
+        ignores a feature map leaves them unwritten, and they must then read zero.)"""
+        if name.endswith((".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight", ".mlp.fc2.weight")) and name.startswith("blocks."):
+            return True
+        return name == "patch_embed.proj.weight"
+
     def _engine(self):
         from ..engine import BackboneEngine
         act = torch.bfloat16 if self.precision == "bf16" else torch.float32

@@ -955,6 +955,22 @@ extern "C" int mtp_small_linear_dw_segments(const float* x, const float* dy, int
     return mtp_launch_status();
 }
 
+// base[start[i] .. start[i] + count[i]) = 0 for n segments (device tables; the host splits long runs so that one workgroup clears at
+// most 64 K floats): the gradients that ACCUMULATE (biases, LayerNorm, rel-pos tables, sampling heads, FPN) inside the flat gradient
+// buffer, without touching the 99 % of it that the weight-gradient GEMMs overwrite
+__global__ __launch_bounds__(256) void zero_segments_kernel(float* __restrict__ base, const int64_t* __restrict__ start, const int64_t* __restrict__ count, int n) {
+    for (int sgm = blockIdx.x; sgm < n; sgm += gridDim.x) {
+        float* p = base + start[sgm];
+        const int64_t c = count[sgm];
+        for (int64_t i = threadIdx.x; i < c; i += 256) p[i] = 0.f;
+    }
+}
+extern "C" int mtp_zero_segments_f32(float* base, const int64_t* start, const int64_t* count, int n, mtp_stream_t stream) {
+    if (!base || !start || !count || n <= 0) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(zero_segments_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, (hipStream_t)stream, base, start, count, n);
+    return mtp_launch_status();
+}
+
 extern "C" int mtp_sqnorm_f32(const float* g, float* out, int64_t n, mtp_stream_t stream) {
     if (!g || !out || n <= 0) return MTP_ERR_ARG;
     hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, g, out, n);

@@ -520,6 +520,12 @@ def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, dre
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
+def zero_segments(base, start, count):
+    """base[start[i] : start[i] + count[i]] = 0 for the int64 device tables start / count (one launch, one workgroup per entry)"""
+    assert base.dtype == torch.float32 and start.dtype == torch.int64 and count.dtype == torch.int64 and start.numel() == count.numel()
+    check(lib().mtp_zero_segments_f32(_p(base), start.data_ptr(), count.data_ptr(), start.numel(), _s()), "mtp_zero_segments_f32")
+
+
 def sqnorm(g, out):
     check(lib().mtp_sqnorm_f32(_f32(g), _f32(out), g.numel(), _s()), "mtp_sqnorm_f32")
     return out

@@ -18,6 +18,7 @@ All of it also runs on CPU tensors with the gloo backend (no kernels involved) -
 covers the world_size > 1 path in the build container.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -74,6 +75,33 @@ class FlatParams:
             p.grad = None
         self.G = {n: self.view(self.grad, n) for n in order if groups[n] is not None}
         self.depth = depth
+        # Gradients the engine OVERWRITES in every backward (the blocks' Linear weights and the patch embedding: TN GEMM outputs, ~97 % of
+        # the buffer) need no clearing; everything else accumulates (bias by-products, LayerNorm / table partial sums, the stacked
+        # sampling heads; the FPN weights, which a loss that ignores a map leaves unwritten) and is cleared by ONE launch over a table of
+        # runs of at most 64 K floats (zero_accumulating()).  MTP_ZERO_ALL_GRADS=1: clear everything (A/B).
+        over = None if os.environ.get("MTP_ZERO_ALL_GRADS") == "1" else getattr(module, "_overwritten_grads", None)
+        self._zero_tab = None
+        if over is not None and self.grad.is_cuda:
+            runs = []
+            for n in order:
+                if groups[n] is None or over(n):
+                    continue
+                a, c = self.offsets[n], params[n].numel()
+                if runs and runs[-1][0] + runs[-1][1] == a:
+                    runs[-1][1] += c
+                else:
+                    runs.append([a, c])
+            ent = [(a + o, min(65536, c - o)) for a, c in runs for o in range(0, c, 65536)]
+            if ent:
+                self._zero_tab = (torch.tensor([e[0] for e in ent], dtype=torch.int64, device=dev), torch.tensor([e[1] for e in ent], dtype=torch.int64, device=dev))
+
+    def zero_accumulating(self):
+        """clear what the backward accumulates into (everything, when the module does not say which gradients it overwrites)"""
+        if self._zero_tab is None:
+            self.grad.zero_()
+        else:
+            from . import ops
+            ops.zero_segments(self.grad, *self._zero_tab)
 
     def view(self, flat, n):
         o = self.offsets[n]
@@ -396,7 +424,7 @@ class DataParallelTrainer:
 
     def step(self, img, loss_and_grads):
         """loss_and_grads(feats) -> (loss, [dfeat or None] * 4).  Returns the (local) loss tensor."""
-        self.flat.grad.zero_()     # one memset per step: the engine accumulates bias / LayerNorm gradients (engine._colsum)
+        self.flat.zero_accumulating()     # the engine accumulates bias / LayerNorm / table gradients; the big weight gradients are overwritten
         self.reducer.begin_step()
         feats, ctx = self.engine.forward(img, training=True, need_grad=True, feature_dtype=self.feature_dtype)
         loss, dfeats = loss_and_grads(feats)
