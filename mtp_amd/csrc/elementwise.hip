@@ -790,12 +790,16 @@ __global__ __launch_bounds__(256) void rvsa_sampling_fwd_kernel(const T* __restr
         const float inv = 1.0f / 49.0f;
         s = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
         const float4 p = make_float4(s.x > 0 ? s.x : 0.01f * s.x, s.y > 0 ? s.y : 0.01f * s.y, s.z > 0 ? s.z : 0.01f * s.z, s.w > 0 ? s.w : 0.01f * s.w);
-        store4(avg + (int64_t)win * C + 4 * c4, s);
-        store4(pooled + (int64_t)win * C + 4 * c4, p);
+        if (blockIdx.y == 0) {
+            store4(avg + (int64_t)win * C + 4 * c4, s);
+            store4(pooled + (int64_t)win * C + 4 * c4, p);
+        }
         *reinterpret_cast<float4*>(pl + 4 * c4) = p;
     }
     __syncthreads();
-    for (int n0 = 4 * wave; n0 < N; n0 += 16) {      // 4 output columns per pass: 4 x (C / 256) weight loads in flight per lane
+    // gridDim.y workgroups share a window: each pools it (the second reads come out of L2) and produces its share of the N outputs
+    const int nper = ((N + (int)gridDim.y - 1) / (int)gridDim.y + 3) / 4 * 4, nlo = (int)blockIdx.y * nper, nhi = (nlo + nper) < N ? (nlo + nper) : N;
+    for (int n0 = nlo + 4 * wave; n0 < nhi; n0 += 16) {      // 4 output columns per pass: 4 x (C / 256) weight loads in flight per lane
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = lane * 4; k < C; k += 256) {
             const float4 a = *reinterpret_cast<const float4*>(pl + k);
@@ -809,7 +813,7 @@ __global__ __launch_bounds__(256) void rvsa_sampling_fwd_kernel(const T* __restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float t = wave_sum(acc[q]);
-            if (lane == 0 && n0 + q < N) samp[(int64_t)win * N + n0 + q] = t + (bias ? bias[n0 + q] : 0.f);
+            if (lane == 0 && n0 + q < nhi) samp[(int64_t)win * N + n0 + q] = t + (bias ? bias[n0 + q] : 0.f);
         }
     }
 }
@@ -859,7 +863,8 @@ extern "C" int mtp_rvsa_sampling_fwd(const void* x, int dtype, const float* w, c
     if (!x || !w || !avg || !pooled || !samp || B <= 0 || Hp <= 0 || Wp <= 0 || C <= 0 || (C % 4) || C > 8192 || N <= 0) return MTP_ERR_ARG;
     int pt, pl, nh, nw;
     rvsa_geom(Hp, Wp, pt, pl, nh, nw);
-    const dim3 grid((unsigned)(B * nh * nw)), block(256);
+    static const int ysplit = []() { const char* e = getenv("MTP_SAMPLING_SPLIT"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 8 ? 8 : v; }();   // measured 24.1 / 18.1 / 19.3 us at 1 / 2 / 4
+    const dim3 grid((unsigned)(B * nh * nw), (unsigned)(N >= 16 * ysplit ? ysplit : 1)), block(256);
     const size_t lds = sizeof(float) * (size_t)C;
     if (dtype == MTP_BF16)
         hipLaunchKernelGGL((rvsa_sampling_fwd_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)x, w, bias, avg, pooled, samp, (int)Hp, (int)Wp, (int)C, (int)N, pt, pl, nh, nw);
