@@ -118,6 +118,12 @@ int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
 /* out[c] (+)= sum_r part[r * ld + c], c < C   (per-workgroup partials -> parameter gradient; ld >= C lets one
  * partial buffer feed several parameters) */
 int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);
+/* the same for n <= MTP_REDUCE_BATCH_MAX partial buffers of one shape in ONE launch: outs[i][c] (+)= sum_r parts[i][r * ld + c].
+ * parts / outs are HOST arrays of device pointers (the LayerNorm parameter gradients of a burst of blocks: the partial rows of
+ * mtp_layernorm_bwd are kept until the burst's weight-gradient group is launched, then reduced together) */
+#define MTP_REDUCE_BATCH_MAX 32
+int mtp_reduce_rows_batched_f32(const float* const* parts, float* const* outs, int n, int64_t ld, int64_t rows, int64_t C, int accumulate,
+                                mtp_stream_t stream);
 /* the same, result transposed: part (rows, R*C) f32, column a*C + b is summed into out[b*R + a] (out is (C, R)) */
 int mtp_reduce_rows_t_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t R, int64_t C, int accumulate, mtp_stream_t stream);
 /* bias gradient: out[n] = sum_m dY[m][n] */

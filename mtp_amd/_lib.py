@@ -51,6 +51,7 @@ SIGNATURES = {
     "mtp_layernorm_bwd_partial_rows": (i64, [i64]),
     "mtp_layernorm_bwd": (i32, [p, i32, p, i32, p, p, p, p, i32, p, p, p, i32, p, i32, p, i64, p, p, i64, i64, i64, p]),
     "mtp_reduce_rows_f32": (i32, [p, i64, p, i64, i64, i32, p]),
+    "mtp_reduce_rows_batched_f32": (i32, [p, p, i32, i64, i64, i64, i32, p]),
     "mtp_reduce_rows_t_f32": (i32, [p, i64, p, i64, i64, i64, i32, p]),
     "mtp_copy_segments_f32": (i32, [p, p, p, i32, p]),
     "mtp_colsum": (i32, [p, i32, i64, p, i64, i64, p]),

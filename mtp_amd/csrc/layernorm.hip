@@ -173,6 +173,23 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     atomicAdd(out + c, s);
 }
 
+// n equally-shaped partial buffers in one launch (blockIdx.z = buffer): the LayerNorm parameter gradients of a burst of blocks
+struct RrBatch {
+    const float* part[MTP_REDUCE_BATCH_MAX];
+    float* out[MTP_REDUCE_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void reduce_rows_batched_kernel(RrBatch t, int64_t ld, int64_t rows, int64_t C, int64_t rows_per_block) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* __restrict__ part = t.part[blockIdx.z];
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += part[r * ld + c];
+    atomicAdd(t.out[blockIdx.z] + c, s);
+}
+
 // the same with a transposed result: column j = a * C + b of part (rows, R * C) goes to out[b * R + a] (per-(window, head) partials of
 // the (169, heads) bias-table gradient are written head-major by the RVSA backward: contiguous per workgroup)
 __global__ __launch_bounds__(256) void reduce_rows_t_kernel(const float* __restrict__ part, int64_t ld, float* __restrict__ out, int64_t rows, int R, int C, int64_t rows_per_block) {
@@ -316,6 +333,31 @@ extern "C" int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, in
     const int64_t rpb = (rows + splits - 1) / splits;
     splits = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)col_blocks, (unsigned)splits), dim3(256), 0, s, part, ld, out, rows, C, rpb);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_reduce_rows_batched_f32(const float* const* parts, float* const* outs, int n, int64_t ld, int64_t rows, int64_t C, int accumulate,
+                                           mtp_stream_t stream) {
+    if (!parts || !outs || n <= 0 || n > MTP_REDUCE_BATCH_MAX || rows <= 0 || C <= 0 || ld < C) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RrBatch t;
+    for (int i = 0; i < n; ++i) {
+        if (!parts[i] || !outs[i]) return MTP_ERR_ARG;
+        t.part[i] = parts[i];
+        t.out[i] = outs[i];
+    }
+    if (!accumulate)
+        for (int i = 0; i < n; ++i) {
+            hipError_t e = hipMemsetAsync(outs[i], 0, sizeof(float) * (size_t)C, s);
+            if (e != hipSuccess) return (int)e;
+        }
+    const int64_t col_blocks = (C + 255) / 256;
+    int64_t splits = 1024 / col_blocks;     // as the single-buffer form (the atomics of a buffer are 1/n of the launch's)
+    if (splits < 1) splits = 1;
+    if (splits > rows) splits = rows;
+    const int64_t rpb = (rows + splits - 1) / splits;
+    splits = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(reduce_rows_batched_kernel, dim3((unsigned)col_blocks, (unsigned)splits, (unsigned)n), dim3(256), 0, s, t, ld, rows, C, rpb);
     return mtp_launch_status();
 }
 

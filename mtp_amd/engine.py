@@ -18,6 +18,7 @@ from . import ops
 
 F32 = torch.float32
 _FUSED_SAMPLING = os.environ.get("MTP_FUSED_SAMPLING", "1") != "0"     # A/B switch: 0 = pool / linear as separate launches
+_DEFER_LN = os.environ.get("MTP_DEFER_LN_REDUCE", "1") != "0"         # A/B switch: 0 = one reduction launch per LayerNorm backward
 
 
 class _Blk:
@@ -37,6 +38,7 @@ class BackboneEngine:
         self.window = [bool(w) for w in module.window_blocks]
         self.out_indices = list(module.out_indices)
         self._key = None
+        self._ln_parts = []
         self._blk = None
         self._fpn = None
         self._pe = None
@@ -132,9 +134,13 @@ class BackboneEngine:
     def _colsum(dy, out):
         return ops.colsum(dy, out, accumulate=True)
 
-    @staticmethod
-    def _ln_bwd(*args, **kw):
-        return ops.layernorm_bwd(*args, accumulate=True, **kw)
+    def _ln_bwd(self, *args, **kw):
+        # the dgamma / dbeta partial rows wait in self._ln_parts and are reduced once per burst of blocks (_ln_flush)
+        return ops.layernorm_bwd(*args, accumulate=True, defer=(self._ln_parts if _DEFER_LN else None), **kw)
+
+    def _ln_flush(self):
+        if self._ln_parts:
+            ops.reduce_rows_deferred(self._ln_parts)
 
     def _full_rel(self, pre, Hp, Wp):
         """decomposed rel-pos tables of a full-attention block; zero tables for the ViTDet-style fine-tune copies, whose full
@@ -417,6 +423,7 @@ class BackboneEngine:
         C, N, T = self.C, Hp * Wp, B * Hp * Wp
         P = self.P
         self.dev = ctx["cols"].device
+        self._ln_parts = []
         if ctx["fctx"].get("taps_only"):
             dtaps = [None if d is None else ops.nchw_to_tokens((d.contiguous() if d.dtype in (F32, torch.bfloat16) else d.float().contiguous()),
                                                                self._e(T, C, dtype=F32), B, Hp, Wp, 0) for d in dfeats]
@@ -446,6 +453,7 @@ class BackboneEngine:
                     ops.axpy(tapgrad[idx], d)
                 else:
                     tapgrad[idx] = d
+        self._ln_flush()
         if on_block_done is not None:
             on_block_done(self.depth)          # FPN (and final-norm) parameter gradients are complete on the stream
         if last not in tapgrad:
@@ -467,6 +475,7 @@ class BackboneEngine:
             waiting.append(i)
             if i == 0 or wq.should_flush():
                 wq.flush()
+                self._ln_flush()
                 if wq.stream is None:
                     if on_block_done is not None:
                         on_block_done(waiting[-1])     # the lowest block of the burst: its group end covers the whole burst

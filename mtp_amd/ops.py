@@ -242,8 +242,10 @@ def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-6, gelu=False)
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=False, dres=None, extra=None,
-                  dx_copy=None, copy_scale=None, rows_per_sample=0, accumulate=False):
-    """dx = [dres] + [extra] + LN'(dy); dgamma/dbeta (C,) f32 are overwritten (or accumulated into)."""
+                  dx_copy=None, copy_scale=None, rows_per_sample=0, accumulate=False, defer=None):
+    """dx = [dres] + [extra] + LN'(dy); dgamma/dbeta (C,) f32 are overwritten (or accumulated into).  With `defer` (a list) the
+    per-workgroup partials are kept and appended to it instead of being reduced: reduce_rows_deferred(defer) finishes several
+    LayerNorms' parameter gradients in one launch."""
     rows, Cc = x.shape
     # (an in-kernel f32-atomic accumulation of dgamma / dbeta was measured: 512 workgroups hitting the same 2C addresses took
     #  the kernel from 61 to 106 us; per-workgroup partials + two 8 us reductions are faster)
@@ -254,8 +256,30 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=F
                                   _f32(copy_scale), rows_per_sample, part.data_ptr(), part.data_ptr() + 4 * Cc, 2 * Cc, rows, Cc, _s()),
           "mtp_layernorm_bwd")
     # weight and bias gradient adjacent in one buffer (the flat gradient buffer of mtp_amd.parallel) -> ONE reduction launch
-    _reduce_pair(part, Cc, dgamma, dbeta, accumulate)
+    if defer is not None and _adjacent(dgamma, dbeta) and dgamma.numel() == Cc:
+        defer.append((part, dgamma, accumulate))
+    else:
+        _reduce_pair(part, Cc, dgamma, dbeta, accumulate)
     return dx
+
+
+REDUCE_BATCH_MAX = 32
+
+
+def reduce_rows_deferred(items):
+    """items: (part (rows, cols) f32, out (first of `cols` contiguous floats), accumulate) triples queued by layernorm_bwd(defer=...);
+    equally-shaped ones go out together, <= REDUCE_BATCH_MAX per launch (mtp_reduce_rows_batched_f32).  Empties the list."""
+    groups = {}
+    for part, out, acc in items:
+        groups.setdefault((tuple(part.shape), part.stride(0), bool(acc)), []).append((part, out))
+    for ((rows, cols), ld, acc), g in groups.items():
+        for i0 in range(0, len(g), REDUCE_BATCH_MAX):
+            chunk = g[i0:i0 + REDUCE_BATCH_MAX]
+            n = len(chunk)
+            P = C.c_void_p * n
+            check(lib().mtp_reduce_rows_batched_f32(P(*[c[0].data_ptr() for c in chunk]), P(*[c[1].data_ptr() for c in chunk]), n, ld, rows, cols,
+                                                    int(acc), _s()), "mtp_reduce_rows_batched_f32")
+    del items[:]
 
 
 def reduce_rows(part, out, accumulate=False):

@@ -340,6 +340,34 @@ def test_layernorm_fwd_bwd(ops, dtype, rows, C):
     assert rel_err(dg2.cpu(), 1 + dgr) < 2e-4 and rel_err(db2.cpu(), dbr - 2) < 2e-4 and rel_err(dx2.cpu(), tot) < 2e-4
 
 
+def test_layernorm_bwd_deferred_parameter_gradients(ops):
+    """several LayerNorm backwards keep their partial rows; ONE reduction launch per shape finishes all the dgamma / dbeta pairs"""
+    items, want, bufs = [], [], []
+    for j, (rows, C) in enumerate([(392, 128), (392, 128), (50, 768), (392, 128)]):
+        x, g = rnd(rows, C, scale=2.0, seed=10 * j) + 0.5, 1 + 0.1 * rnd(C, seed=10 * j + 1)
+        _, mr, rr = O.layernorm_fwd(x, g, torch.zeros(C))
+        dy = rnd(rows, C, seed=10 * j + 3)
+        gb = dev(torch.full((2 * C,), float(j)))          # [dgamma | dbeta] adjacent, as in the flat gradient buffer
+        ops.layernorm_bwd(dev(dy), dev(x), dev(mr), dev(rr), dev(g), e(rows, C), gb[:C], gb[C:], accumulate=True, defer=items)
+        _, dgr, dbr = O.layernorm_bwd(dy, x, mr, rr, g)
+        want.append(torch.cat([dgr, dbr]) + j)
+        bufs.append(gb)
+    assert len(items) == 4 and all(torch.equal(b.cpu(), torch.full_like(b.cpu(), float(j))) for j, b in enumerate(bufs))
+    ops.reduce_rows_deferred(items)
+    assert not items
+    for b, w in zip(bufs, want):
+        assert rel_err(b.cpu(), w) < 2e-4
+    # gradients that are NOT adjacent fall back to the immediate reduction
+    rows, C = 50, 768
+    x, g, dy = rnd(rows, C, seed=90) + 0.5, 1 + 0.1 * rnd(C, seed=91), rnd(rows, C, seed=92)
+    _, mr, rr = O.layernorm_fwd(x, g, torch.zeros(C))
+    dg, db = e(C), e(C)
+    dg.zero_(), db.zero_()
+    ops.layernorm_bwd(dev(dy), dev(x), dev(mr), dev(rr), dev(g), e(rows, C), dg, db, accumulate=True, defer=items)
+    _, dgr, dbr = O.layernorm_bwd(dy, x, mr, rr, g)
+    assert not items and rel_err(dg.cpu(), dgr) < 2e-4 and rel_err(db.cpu(), dbr) < 2e-4
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_layernorm_gelu_act_io(ops, dtype):
     rows, C = 784, 128
