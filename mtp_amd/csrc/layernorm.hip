@@ -161,6 +161,18 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
     }
 }
 
+// sum of rows r0..r1 of one column: four independent loads in flight per thread (one 4-byte load at a time ran at ~1.8 TB/s out of L2)
+__device__ __forceinline__ float column_sum(const float* __restrict__ col, int64_t ld, int64_t r0, int64_t r1) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const float a = col[r * ld], b = col[(r + 1) * ld], c = col[(r + 2) * ld], d = col[(r + 3) * ld];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; r < r1; ++r) s0 += col[r * ld];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // out[c] (+)= sum_r part[r][c]; thread per column, rows split over blockIdx.y, f32 atomics into (zeroed) out
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int64_t ld, float* __restrict__ out, int64_t rows, int64_t C, int64_t rows_per_block) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -168,9 +180,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     r1 = r1 < rows ? r1 : rows;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += part[r * ld + c];
-    atomicAdd(out + c, s);
+    atomicAdd(out + c, column_sum(part + c, ld, r0, r1));
 }
 
 // n equally-shaped partial buffers in one launch (blockIdx.z = buffer): the LayerNorm parameter gradients of a burst of blocks
@@ -185,9 +195,7 @@ __global__ __launch_bounds__(256) void reduce_rows_batched_kernel(RrBatch t, int
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     r1 = r1 < rows ? r1 : rows;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += part[r * ld + c];
-    atomicAdd(t.out[blockIdx.z] + c, s);
+    atomicAdd(t.out[blockIdx.z] + c, column_sum(part + c, ld, r0, r1));
 }
 
 // the same with a transposed result: column j = a * C + b of part (rows, R * C) goes to out[b * R + a] (per-(window, head) partials of
