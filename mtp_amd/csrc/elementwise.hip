@@ -818,42 +818,55 @@ __global__ __launch_bounds__(256) void rvsa_sampling_fwd_kernel(const T* __restr
     }
 }
 
+// workgroup = (window, 64 channel quads); its 4 waves split the N head outputs of the dsamp . w product (N / 4 dependent-free weight
+// loads each instead of N: with one quad per thread and the whole product in it the launch had one latency-bound wave per SIMD),
+// meet in LDS, then split the 7 window rows of the dx update
 template <typename T>
 __global__ __launch_bounds__(256) void rvsa_sampling_bwd_kernel(const float* __restrict__ dsamp, const float* __restrict__ w, const float* __restrict__ avg,
                                                                T* __restrict__ dx, int Hp, int Wp, int C, int N, int pad_t, int pad_l, int nh, int nw) {
     extern __shared__ __attribute__((aligned(16))) float ds[];     // dsamp row of this window
+    __shared__ float4 part[4][64];
     const int win = blockIdx.x;
     const int j = win % nw, i = (win / nw) % nh, b = win / (nw * nh);
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c4 = blockIdx.y * 64 + lane;
+    const bool live = c4 < C / 4;
     for (int n = threadIdx.x; n < N; n += 256) ds[n] = dsamp[(int64_t)win * N + n];
     __syncthreads();
-    for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
-        float4 d = make_float4(0, 0, 0, 0);
+    const int nq = (N + 3) / 4, n0 = q * nq, n1 = (n0 + nq) < N ? (n0 + nq) : N;
+    float4 d = make_float4(0, 0, 0, 0);
+    if (live) {
 #pragma unroll 4
-        for (int n = 0; n < N; ++n) {
+        for (int n = n0; n < n1; ++n) {
             const float4 ww = load4(w + (int64_t)n * C + 4 * c4);
             const float t = ds[n];
             d.x += t * ww.x; d.y += t * ww.y; d.z += t * ww.z; d.w += t * ww.w;
         }
-        const float4 a = load4(avg + (int64_t)win * C + 4 * c4);
-        const float k = 1.0f / 49.0f;
-        const float4 g = make_float4(d.x * (a.x > 0 ? k : 0.01f * k), d.y * (a.y > 0 ? k : 0.01f * k), d.z * (a.z > 0 ? k : 0.01f * k), d.w * (a.w > 0 ? k : 0.01f * k));
+    }
+    part[q][lane] = d;
+    __syncthreads();
+    if (!live) return;
+    const float4 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];   // fixed order: every wave gets the same bits
+    d = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+    const float4 a = load4(avg + (int64_t)win * C + 4 * c4);
+    const float k = 1.0f / 49.0f;
+    const float4 g = make_float4(d.x * (a.x > 0 ? k : 0.01f * k), d.y * (a.y > 0 ? k : 0.01f * k), d.z * (a.z > 0 ? k : 0.01f * k), d.w * (a.w > 0 ? k : 0.01f * k));
 #pragma unroll 1
-        for (int aa = 0; aa < 7; ++aa) {
-            const int y = i * 7 + aa - pad_t;
-            if (y < 0 || y >= Hp) continue;       // (uniform over the workgroup)
-            float4 o[7];
+    for (int aa = q; aa < 7; aa += 4) {
+        const int y = i * 7 + aa - pad_t;
+        if (y < 0 || y >= Hp) continue;       // (uniform over the wave)
+        float4 o[7];
 #pragma unroll
-            for (int bb = 0; bb < 7; ++bb) {
-                const int xx = j * 7 + bb - pad_l;
-                const int xc = (xx >= 0 && xx < Wp) ? xx : 0;
-                o[bb] = load4(dx + (((int64_t)b * Hp + y) * Wp + xc) * C + 4 * c4);
-            }
+        for (int bb = 0; bb < 7; ++bb) {
+            const int xx = j * 7 + bb - pad_l;
+            const int xc = (xx >= 0 && xx < Wp) ? xx : 0;
+            o[bb] = load4(dx + (((int64_t)b * Hp + y) * Wp + xc) * C + 4 * c4);
+        }
 #pragma unroll
-            for (int bb = 0; bb < 7; ++bb) {
-                const int xx = j * 7 + bb - pad_l;
-                if (xx >= 0 && xx < Wp)
-                    store4(dx + (((int64_t)b * Hp + y) * Wp + xx) * C + 4 * c4, make_float4(o[bb].x + g.x, o[bb].y + g.y, o[bb].z + g.z, o[bb].w + g.w));
-            }
+        for (int bb = 0; bb < 7; ++bb) {
+            const int xx = j * 7 + bb - pad_l;
+            if (xx >= 0 && xx < Wp)
+                store4(dx + (((int64_t)b * Hp + y) * Wp + xx) * C + 4 * c4, make_float4(o[bb].x + g.x, o[bb].y + g.y, o[bb].z + g.z, o[bb].w + g.w));
         }
     }
 }
@@ -879,7 +892,7 @@ extern "C" int mtp_rvsa_sampling_bwd(const float* dsamp, const float* w, const f
     if (!dsamp || !w || !avg || !dx || B <= 0 || Hp <= 0 || Wp <= 0 || C <= 0 || (C % 4) || N <= 0 || N > 4096) return MTP_ERR_ARG;
     int pt, pl, nh, nw;
     rvsa_geom(Hp, Wp, pt, pl, nh, nw);
-    const dim3 grid((unsigned)(B * nh * nw)), block(256);
+    const dim3 grid((unsigned)(B * nh * nw), (unsigned)((C / 4 + 63) / 64)), block(256);
     const size_t lds = sizeof(float) * (size_t)N;
     if (dtype == MTP_BF16)
         hipLaunchKernelGGL((rvsa_sampling_bwd_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, dsamp, w, avg, (bf16_t*)dx, (int)Hp, (int)Wp, (int)C, (int)N, pt, pl, nh, nw);
