@@ -7,6 +7,7 @@ the reference's step recipe (main_pretrain.py:721-788) with `loss = sum(mean(f))
 for the three task decoders (they live in un-vendored mmseg/mmdet/mmrotate).  Inputs are resident in HBM.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 ...          # no launcher environment: starts its own 8 ranks (torch.distributed.run on 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant GEMM kernel family, HIP-event timed inside the timed region) and, at
@@ -112,6 +113,107 @@ def cpu_baseline(model, seconds_budget=25.0):
                        % (model, B, n, threads, cores))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _error_line(args, msg):
+    """the JSON line of a run that could not be measured (one line, last on stdout, like a result): value null + `error`"""
+    return json.dumps({"metric": "images/sec pretrain step (ViT-L+RVSA, %d^2, bf16)" % args.image_size, "value": None, "unit": "images/sec",
+                       "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "error": msg})
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset): start the N ranks here, the way the
+    reference starts its own (torch.distributed launch, main_pretrain.py:121-140, 508-518): one process per GPU, rendezvous on
+    127.0.0.1.  The children's output is passed through; the ONE JSON line of rank 0 is re-printed last.  Returns the exit code."""
+    import subprocess
+    if not args.cpu_standin:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(_error_line(args, "--gpus %d but only %d GPU(s) visible to this process" % (args.gpus, have)), flush=True)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = proc.stdout.splitlines()
+    result = None
+    for i in range(len(lines) - 1, -1, -1):
+        ln = lines[i].strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                if "metric" in json.loads(ln):
+                    result = lines.pop(i)
+                    break
+            except ValueError:
+                pass
+    for ln in lines:
+        print(ln)
+    if result is None:
+        result = _error_line(args, "the %d-rank launch exited with code %d without printing a result line" % (args.gpus, proc.returncode))
+    print(result, flush=True)
+    return proc.returncode if proc.returncode else (0 if "\"error\"" not in result else 3)
+
+
+def run_cpu_standin(args, world, rank):
+    """TEST STAND-IN, not a measurement (tests/test_bench_launch.py): the same launch / rendezvous / report plumbing with gloo ranks
+    on CPU.  The HIP engine cannot run here, so a step = filling the flat gradient buffer of a small backbone and driving GradReducer
+    with the engine's completion order (FPN tail, bursts of blocks, embeddings) -- exactly what DataParallelTrainer.step does around
+    the kernels.  Prints the bench JSON schema with `standin: true` and a `comm` object."""
+    import torch.distributed as dist
+    import mtp_amd
+    from mtp_amd.parallel import FlatParams, GradReducer
+    dist.init_process_group("gloo")
+    torch.manual_seed(2023)
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=6, num_heads=2, interval=3, qkv_bias=True, use_abs_pos_emb=True, out_indices=[1, 2, 3, 5])
+    flat = FlatParams(net, unused=net._unused_params)
+    red = GradReducer(flat, bucket_bytes=1 << 20, mode=args.comm_mode, bf16=args.comm_bf16)
+    gen = torch.Generator().manual_seed(100 + rank)
+    bursts = [[6], [5, 4, 3, 2], [1], [0], [-1]]     # the engine's reports: FPN tail, a burst of blocks, split_last's block 1 / block 0, embeddings
+
+    def step():
+        flat.grad.copy_(torch.randn(flat.total, generator=gen))
+        red.begin_step()
+        for burst in bursts:
+            for g in burst:
+                red.on_block_done(g)
+        red.finish()
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    # every rank holds the same reduced gradients
+    chk = flat.grad[:flat.reduced].double().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    out = {"metric": "images/sec pretrain step (ViT-L+RVSA, %d^2, bf16)" % args.image_size, "value": round(world * args.batch * args.steps / dt, 2),
+           "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "standin": True,
+           "config": {"workload": "CPU / gloo STAND-IN of the launch + gradient-exchange plumbing (no kernels, not a measurement)",
+                      "global_batch": world * args.batch, "parallelism": "dp%d" % world},
+           "comm": dict(ranks=dist.get_world_size(), backend=dist.get_backend(), mode=red.mode, bf16=bool(red.bf16), collectives_per_step=red.collectives,
+                        bytes_per_step=int(red.bytes_reduced), replicas_identical=bool(lo.item() == hi.item()))}
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,15 +235,30 @@ def main():
                     help="what consumes the four feature maps: `mean` = sum_i mean(f_i) (the headline line); `standin3` = three labelled stand-in task "
                          "heads (BASELINE configs[1]: 'ViT-B/16 + 3 MTP decoder heads'; the real decoders live in un-vendored mmseg / mmdet / mmrotate)")
     ap.add_argument("--image-size", type=int, default=224, help="224 = the headline metric; 448 = what MTP actually pretrains at (use --batch 16)")
+    ap.add_argument("--comm-mode", default=os.environ.get("MTP_COMM_MODE", "allreduce"), choices=["allreduce", "rs_ag"],
+                    help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (mtp_amd.parallel.GradReducer)")
+    ap.add_argument("--comm-bf16", action="store_true", default=os.environ.get("MTP_COMM_BF16") == "1",
+                    help="exchange the gradient buckets as bf16 (cast on the side stream, f32 again before the optimizer): half the xGMI bytes")
+    ap.add_argument("--cpu-standin", action="store_true",
+                    help="TEST ONLY: gloo ranks on CPU exercising the launcher / rendezvous / comm-report plumbing without kernels (prints `standin: true`)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us (the driver runs `python bench.py --gpus N ...`): start the ranks ourselves
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if world != args.gpus:
+        if rank == 0:
+            print(_error_line(args, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)), flush=True)
+        raise SystemExit(2)
+    if args.cpu_standin:
+        return run_cpu_standin(args, world, rank)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        if rank == 0:
+            print(_error_line(args, "rank %d has no GPU (%d visible)" % (local, torch.cuda.device_count() if torch.cuda.is_available() else 0)), flush=True)
+        raise SystemExit(2)
     torch.cuda.set_device(local)
     import torch.distributed as dist
     force_comm = os.environ.get("MTP_FORCE_COMM") == "1"     # debugging aid: run the RCCL path on a single GPU
@@ -176,7 +293,8 @@ def main():
                 p.normal_(0, 0.02)
     net = net.cuda().train()
     fdt = torch.bfloat16 if args.precision == "bf16" else torch.float32
-    trainer = DataParallelTrainer(net, lr=6e-5, weight_decay=0.05, max_norm=5.0, total_steps=1000, feature_dtype=fdt)
+    trainer = DataParallelTrainer(net, lr=6e-5, weight_decay=0.05, max_norm=5.0, total_steps=1000, feature_dtype=fdt,
+                                  comm_mode=args.comm_mode, comm_bf16=args.comm_bf16)
     torch.manual_seed(2023 + rank)   # per-rank data / drop-path streams (main_pretrain.py:517)
     B = args.batch
     img = torch.randn(B, 3, args.image_size, args.image_size, device="cuda")
@@ -245,7 +363,8 @@ def main():
         red.timing = False
         nbytes = sum(b for b, _, _ in red.timed) / args.steps
         secs = sum(a.elapsed_time(bb) for _, a, bb in red.timed) * 1e-3 / args.steps
-        ncoll = len(red.timed) // args.steps
+        ncoll = red.collectives          # collectives issued in the last step (2 per bucket in rs_ag mode)
+        wire = red.wire_bytes
         red.active = False
         t2 = time.perf_counter()
         for _ in range(args.steps):
@@ -258,7 +377,8 @@ def main():
         ms_nocomm = float(tnc.item()) / args.steps * 1e3
         busf = 2.0 * (world - 1) / world if world > 1 else 1.0
         comm = dict(ranks=dist.get_world_size(), backend=dist.get_backend(), collectives_per_step=ncoll, bytes_per_step=int(nbytes),
-                    allreduce_ms_per_step=round(secs * 1e3, 3), bus_GBps=round(nbytes * busf / max(secs, 1e-9) / 1e9, 1),
+                    wire_bytes_per_step=int(wire), exchange=red.describe(),
+                    allreduce_ms_per_step=round(secs * 1e3, 3), bus_GBps=round(wire * busf / max(secs, 1e-9) / 1e9, 1),
                     xgmi_peak_GBps=7 * 153, ms_per_step_without_comm=round(ms_nocomm, 3), exposed_comm_ms=round(ms - ms_nocomm, 3),
                     note="all-reduce time = HIP events on the side stream around each collective (its own duration, overlapped with the "
                          "backward); exposed = step time with minus without collectives; bus GB/s = bytes x 2(N-1)/N / all-reduce time")

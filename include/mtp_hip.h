@@ -316,6 +316,15 @@ const char* mtp_version(void);
 int mtp_comm_unique_id(void* id128);
 int mtp_comm_init(const void* id128, int rank, int world, void** comm);
 int mtp_comm_allreduce_bucket(void* comm, float* bucket, int64_t count, mtp_stream_t stream);
+/* the same for a bucket of `dtype` (MTP_F32 / MTP_BF16: gradient buckets exchanged as bf16 move half the xGMI bytes) */
+int mtp_comm_allreduce_bucket_dt(void* comm, void* bucket, int64_t count, int dtype, mtp_stream_t stream);
+/* Direct exchange, in place (xGMI is point-to-point: every GPU owns 1 / world of the bucket): after mtp_comm_reduce_scatter_bucket
+ * rank r holds the SUM of bucket[r * count_per_rank, (r + 1) * count_per_rank) (the other shards are unspecified);
+ * mtp_comm_allgather_bucket spreads every rank's shard r back into all buckets.  Together = mtp_comm_allreduce_bucket on
+ * world * count_per_rank elements (ncclReduceScatter + ncclAllGather; DistributedDataParallel's reducer, main_pretrain.py:508-518,
+ * has no such mode). */
+int mtp_comm_reduce_scatter_bucket(void* comm, void* bucket, int64_t count_per_rank, int rank, int dtype, mtp_stream_t stream);
+int mtp_comm_allgather_bucket(void* comm, void* bucket, int64_t count_per_rank, int rank, int dtype, mtp_stream_t stream);
 int mtp_comm_destroy(void* comm);
 
 #ifdef __cplusplus

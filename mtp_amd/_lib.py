@@ -88,6 +88,9 @@ SIGNATURES = {
     "mtp_comm_unique_id": (i32, [p]),
     "mtp_comm_init": (i32, [p, i32, i32, C.POINTER(C.c_void_p)]),
     "mtp_comm_allreduce_bucket": (i32, [p, p, i64, p]),
+    "mtp_comm_allreduce_bucket_dt": (i32, [p, p, i64, i32, p]),
+    "mtp_comm_reduce_scatter_bucket": (i32, [p, p, i64, i32, i32, p]),
+    "mtp_comm_allgather_bucket": (i32, [p, p, i64, i32, i32, p]),
     "mtp_comm_destroy": (i32, [p]),
     "mtp_full_attn_fwd": (i32, [p, p, p, i32, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_full_attn_bwd_workspace_floats": (i64, [i64, i64, i64, i64]),

@@ -1,5 +1,5 @@
-"""RCCL communicator through the C ABI (include/mtp_hip.h: mtp_comm_unique_id / mtp_comm_init / mtp_comm_allreduce_bucket /
-mtp_comm_destroy) -- the native form of the gradient all-reduce the reference gets from DistributedDataParallel
+"""RCCL communicator through the C ABI (include/mtp_hip.h: mtp_comm_unique_id / mtp_comm_init / mtp_comm_allreduce_bucket[_dt] /
+mtp_comm_reduce_scatter_bucket / mtp_comm_allgather_bucket / mtp_comm_destroy) -- the native form of the gradient all-reduce the reference gets from DistributedDataParallel
 (main_pretrain.py:508-518).  torch.distributed is used once, to hand rank 0's 128-byte id to the other ranks; the collectives
 themselves are ncclAllReduce calls on the caller's stream.  mtp_amd.parallel.GradReducer uses it when MTP_NATIVE_COMM=1 (the default
 stays torch.distributed's all_reduce on the same side stream: same RCCL underneath, and the variant the multi-GPU runs of this
@@ -26,12 +26,32 @@ class RcclComm:
         self._h = C.c_void_p()
         _lib.check(lib.mtp_comm_init(box[0], self.rank, self.world, C.byref(self._h)), "mtp_comm_init")
 
+    @staticmethod
+    def _dt(buf):
+        if buf.dtype not in (torch.float32, torch.bfloat16) or not buf.is_cuda or not buf.is_contiguous():
+            raise TypeError("RcclComm collectives take a contiguous float32 / bfloat16 device tensor")
+        return _lib.MTP_F32 if buf.dtype == torch.float32 else _lib.MTP_BF16
+
     def all_reduce_(self, buf):
-        """in-place SUM of a contiguous float32 device tensor on torch's CURRENT stream (asynchronous)"""
-        if buf.dtype != torch.float32 or not buf.is_cuda or not buf.is_contiguous():
-            raise TypeError("RcclComm.all_reduce_ takes a contiguous float32 device tensor")
-        _lib.check(_lib.load().mtp_comm_allreduce_bucket(self._h, buf.data_ptr(), buf.numel(), torch.cuda.current_stream().cuda_stream),
-                   "mtp_comm_allreduce_bucket")
+        """in-place SUM of a contiguous float32 / bfloat16 device tensor on torch's CURRENT stream (asynchronous)"""
+        _lib.check(_lib.load().mtp_comm_allreduce_bucket_dt(self._h, buf.data_ptr(), buf.numel(), self._dt(buf), torch.cuda.current_stream().cuda_stream),
+                   "mtp_comm_allreduce_bucket_dt")
+        return buf
+
+    def reduce_scatter_(self, buf):
+        """in place: afterwards buf[rank * n : (rank + 1) * n] (n = numel / world) holds the SUM over ranks of that shard"""
+        if buf.numel() % self.world:
+            raise ValueError("bucket of %d elements is not divisible by the world size %d" % (buf.numel(), self.world))
+        _lib.check(_lib.load().mtp_comm_reduce_scatter_bucket(self._h, buf.data_ptr(), buf.numel() // self.world, self.rank, self._dt(buf),
+                                                              torch.cuda.current_stream().cuda_stream), "mtp_comm_reduce_scatter_bucket")
+        return buf
+
+    def all_gather_(self, buf):
+        """in place: every rank's shard buf[r * n : (r + 1) * n] is replaced by rank r's copy of it"""
+        if buf.numel() % self.world:
+            raise ValueError("bucket of %d elements is not divisible by the world size %d" % (buf.numel(), self.world))
+        _lib.check(_lib.load().mtp_comm_allgather_bucket(self._h, buf.data_ptr(), buf.numel() // self.world, self.rank, self._dt(buf),
+                                                         torch.cuda.current_stream().cuda_stream), "mtp_comm_allgather_bucket")
         return buf
 
     def close(self):

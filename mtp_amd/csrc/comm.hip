@@ -15,6 +15,8 @@ struct Rccl {
     ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
     ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*reduce_scatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
     bool ok = false;
 };
@@ -30,8 +32,10 @@ Rccl& rccl() {
         x.get_unique_id = reinterpret_cast<decltype(x.get_unique_id)>(dlsym(x.lib, "ncclGetUniqueId"));
         x.comm_init_rank = reinterpret_cast<decltype(x.comm_init_rank)>(dlsym(x.lib, "ncclCommInitRank"));
         x.all_reduce = reinterpret_cast<decltype(x.all_reduce)>(dlsym(x.lib, "ncclAllReduce"));
+        x.reduce_scatter = reinterpret_cast<decltype(x.reduce_scatter)>(dlsym(x.lib, "ncclReduceScatter"));
+        x.all_gather = reinterpret_cast<decltype(x.all_gather)>(dlsym(x.lib, "ncclAllGather"));
         x.comm_destroy = reinterpret_cast<decltype(x.comm_destroy)>(dlsym(x.lib, "ncclCommDestroy"));
-        x.ok = x.get_unique_id && x.comm_init_rank && x.all_reduce && x.comm_destroy;
+        x.ok = x.get_unique_id && x.comm_init_rank && x.all_reduce && x.reduce_scatter && x.all_gather && x.comm_destroy;
         return x;
     }();
     return r;
@@ -39,6 +43,12 @@ Rccl& rccl() {
 
 // RCCL's own error codes are positive and small like hipError_t's: offset them so that the host can tell them apart
 inline int rc(ncclResult_t e) { return e == ncclSuccess ? 0 : 10000 + (int)e; }
+
+inline bool nccl_type(int dtype, ncclDataType_t& t, size_t& bytes) {
+    if (dtype == MTP_F32) { t = ncclFloat32; bytes = 4; return true; }
+    if (dtype == MTP_BF16) { t = ncclBfloat16; bytes = 2; return true; }
+    return false;
+}
 
 }  // namespace
 
@@ -63,6 +73,35 @@ extern "C" int mtp_comm_allreduce_bucket(void* comm, float* bucket, int64_t coun
     if (!comm || !bucket || count <= 0) return MTP_ERR_ARG;
     if (!rccl().ok) return MTP_ERR_UNSUPPORTED;
     return rc(rccl().all_reduce(bucket, bucket, (size_t)count, ncclFloat32, ncclSum, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+extern "C" int mtp_comm_allreduce_bucket_dt(void* comm, void* bucket, int64_t count, int dtype, mtp_stream_t stream) {
+    ncclDataType_t t;
+    size_t eb;
+    if (!comm || !bucket || count <= 0 || !nccl_type(dtype, t, eb)) return MTP_ERR_ARG;
+    if (!rccl().ok) return MTP_ERR_UNSUPPORTED;
+    return rc(rccl().all_reduce(bucket, bucket, (size_t)count, t, ncclSum, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+// The direct form of the same exchange (xGMI is point-to-point, every GPU owns 1/world of the bucket): rank r ends up
+// with the SUM of shard r = bucket[r * count_per_rank, (r + 1) * count_per_rank) -- in place, RCCL's in-place convention
+// (recvbuff = sendbuff + rank * recvcount) -- and the all-gather then spreads the reduced shards back into every rank's bucket.
+extern "C" int mtp_comm_reduce_scatter_bucket(void* comm, void* bucket, int64_t count_per_rank, int rank, int dtype, mtp_stream_t stream) {
+    ncclDataType_t t;
+    size_t eb;
+    if (!comm || !bucket || count_per_rank <= 0 || rank < 0 || !nccl_type(dtype, t, eb)) return MTP_ERR_ARG;
+    if (!rccl().ok) return MTP_ERR_UNSUPPORTED;
+    char* shard = reinterpret_cast<char*>(bucket) + (size_t)rank * (size_t)count_per_rank * eb;
+    return rc(rccl().reduce_scatter(bucket, shard, (size_t)count_per_rank, t, ncclSum, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+extern "C" int mtp_comm_allgather_bucket(void* comm, void* bucket, int64_t count_per_rank, int rank, int dtype, mtp_stream_t stream) {
+    ncclDataType_t t;
+    size_t eb;
+    if (!comm || !bucket || count_per_rank <= 0 || rank < 0 || !nccl_type(dtype, t, eb)) return MTP_ERR_ARG;
+    if (!rccl().ok) return MTP_ERR_UNSUPPORTED;
+    const char* shard = reinterpret_cast<const char*>(bucket) + (size_t)rank * (size_t)count_per_rank * eb;
+    return rc(rccl().all_gather(shard, bucket, (size_t)count_per_rank, t, (ncclComm_t)comm, (hipStream_t)stream));
 }
 
 extern "C" int mtp_comm_destroy(void* comm) {

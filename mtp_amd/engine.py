@@ -156,7 +156,7 @@ class BackboneEngine:
             if h.shape[0] < 2 * Hp - 1 or w.shape[0] < 2 * Wp - 1:
                 raise ValueError("%sattn.full_attn_rel_pos_h/w have %d / %d rows, a %d x %d token grid needs %d / %d (resize them like "
                                  "init_weights does, or build the model for this input size)" % (pre, h.shape[0], w.shape[0], Hp, Wp, 2 * Hp - 1, 2 * Wp - 1))
-            return h, w
+            return h[:2 * Hp - 1], w[:2 * Wp - 1]      # (row slices of contiguous tables are contiguous)
         key = (Hp, Wp)
         if self._zero_rel.get(key) is None:
             self._zero_rel[key] = (torch.zeros(2 * Hp - 1, self.hd, device=self.dev, dtype=F32),
@@ -259,7 +259,8 @@ class BackboneEngine:
         else:
             rel_h, rel_w = self._full_rel(pre, Hp, Wp)
             if pre + "attn.full_attn_rel_pos_h" in G:
-                drel_h, drel_w = G[pre + "attn.full_attn_rel_pos_h"], G[pre + "attn.full_attn_rel_pos_w"]
+                # (tables taller than this grid needs -- every non-square input, VIT:81-84 -- get gradients in their first rows only)
+                drel_h, drel_w = G[pre + "attn.full_attn_rel_pos_h"][:2 * Hp - 1], G[pre + "attn.full_attn_rel_pos_w"][:2 * Wp - 1]
             else:   # ViTDet-style copies: no such parameters -- the table gradients go to a scratch buffer
                 drel_h, drel_w = self._e(*rel_h.shape, dtype=F32), self._e(*rel_w.shape, dtype=F32)
             ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, self.heads, self.scale,
@@ -413,12 +414,15 @@ class BackboneEngine:
         return out
 
     # ------------------------------------------------------------------ whole backward
-    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None):
+    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None, split_last=False):
         """dfeats: 4 NCHW cotangents (or None).  G: name -> f32 gradient buffer (overwritten; parameters that receive no
         gradient -- `norm.*`, blocks after the last tap -- are left untouched).  on_block_done(i) is called once the gradients
         of block i AND of every block after it (and, for i == -1, of patch-embed / pos-embed) are complete on the current stream:
         once per burst of blocks whose weight gradients were launched together (ops.WgradQueue), with the lowest block index of
-        the burst -- the hook mtp_amd.parallel uses to launch RCCL all-reduces of contiguous gradient slices on a side stream."""
+        the burst -- or after every block when nothing is queued (f32 parity mode, shapes the grouped kernel does not take: the
+        weight gradients were launched immediately) -- the hook mtp_amd.parallel uses to launch RCCL collectives of contiguous
+        gradient slices on a side stream.  split_last: launch what is queued after block 1 as well, so that the last report before
+        the embeddings covers block 0 only (data-parallel runs: that last slice is the part of the exchange nothing overlaps)."""
         B, Cin, H, W, Hp, Wp = ctx["geom"]
         C, N, T = self.C, Hp * Wp, B * Hp * Wp
         P = self.P
@@ -473,7 +477,9 @@ class BackboneEngine:
             dx, dx_act = self._block_bwd(i, s, dx, dx_act, B, Hp, Wp, dps[i], G, extra, prev_scale)
             saved[i] = None
             waiting.append(i)
-            if i == 0 or wq.should_flush():
+            # nothing queued (every weight gradient of the burst is already on the stream): report block by block -- the reducer
+            # cuts its buckets by size, and a single report at the end would leave no backward to overlap the exchange with
+            if i == 0 or wq.should_flush() or not wq.jobs or (split_last and i == 1):
                 wq.flush()
                 self._ln_flush()
                 if wq.stream is None:

@@ -284,7 +284,7 @@ class InternEngine:
         return feats, ctx
 
     # ------------------------------------------------------------------ whole backward
-    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None):
+    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None, split_last=False):
         """dfeats: one NCHW cotangent (or None) per entry of out_indices; G: name -> f32 gradient buffer, zero on entry.
         on_block_done(g): every gradient of layer group g (global layer index; InternImage._flat_param_order) and of all later layers is
         complete on the current stream; -1 = the stem (mtp_amd.parallel.GradReducer launches the all-reduces from it)."""
@@ -323,7 +323,8 @@ class InternEngine:
                 lv["layers"][j] = None
                 # the Linear weight gradients whose shapes the grouped TN kernel takes (multiples of 256: the 768- and 1536-channel levels)
                 # are queued and launched a few layers at a time (ops.WgradQueue); the layer is reported once they are out
-                if j == 0 or self._wq.should_flush():
+                # (levels whose shapes are not queued -- 192 / 384 channels -- have launched everything already: report layer by layer)
+                if j == 0 or self._wq.should_flush() or not self._wq.jobs:
                     self._wq.flush()
                     if on_block_done is not None:
                         on_block_done(sum(m.depths[:i]) + j)

@@ -168,7 +168,10 @@ class WgradQueue:
         K, M = dy.shape
         N = x.shape[1]
         t = grouped_tiles(M, N)
-        if _NO_GROUPED or t == 0 or K % 128 or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
+        # the grouped kernel's own limits (gemm_tn_p8.hip: 32-bit DMA offsets -> K * ld * 2 < 4 GiB per operand; 16-byte aligned bases):
+        # a problem outside them runs now through gemm_tn instead of failing the whole deferred launch several blocks later
+        fits = (K * M * 2 < (1 << 32) and K * N * 2 < (1 << 32) and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0)
+        if _NO_GROUPED or t == 0 or K % 128 or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not fits:
             gemm_tn(dy, x, dw, colsum=colsum)
             return False
         assert x.shape[0] == K and dw.dtype == torch.float32 and dw.numel() == M * N and dw.is_contiguous()

@@ -164,39 +164,111 @@ def reference_param_groups(named_params, weight_decay, prefix="encoder."):
 
 
 class GradReducer:
-    """Gradient all-reduce overlapped with the backward (side stream on GPU; synchronous on CPU / gloo).
+    """Gradient exchange overlapped with the backward (side stream on GPU; synchronous on CPU / gloo).
 
     The engine reports completed groups in completion order (BackboneEngine.backward(on_block_done=...): FPN tail, then the
     blocks -- in bursts, because the weight gradients of several blocks are launched together (ops.WgradQueue: 4 ViT-L blocks =
     ~200 MB of gradients per burst) -- then the embeddings).  Everything between the previous cut and the end of the reported
     group is contiguous in the flat buffer: it becomes ONE collective as soon as it is at least `bucket_bytes` long (or the
-    last group arrived).  With the default 64 MB that is one ~200 MB all-reduce per burst of blocks, issued while the next four
-    blocks' backward (~4.5 ms) runs; only the last burst (blocks 3..0 + embeddings) is exposed."""
+    last group arrived).  With the default 64 MB that is one ~200 MB exchange per burst of blocks, issued while the next four
+    blocks' backward (~4.5 ms) runs; the engine cuts the last burst short (BackboneEngine.backward(split_last=True)) so that only
+    block 0 + the embeddings (~50 MB) are exposed.
 
-    def __init__(self, flat, bucket_bytes=64 << 20, group=None):
+    mode   "allreduce": one SUM all-reduce per bucket (what DistributedDataParallel does, MAIN:508-518);
+           "rs_ag": reduce-scatter + all-gather of the same bucket, in place -- the direct form for xGMI's point-to-point links
+           (every GPU owns 1/world of the bucket; 2.1 ms vs 14.5 ms for a ring over 1.27 GB at 8 GPUs).  Same sums.
+    bf16   exchange the bucket as bf16: cast on the side stream into a scratch bucket, collective, cast back into the f32 gradient
+           buffer (half the xGMI bytes; the sum over ranks is then rounded to bf16 -- off by default).
+    A bucket whose length is not a multiple of the world size falls back to the all-reduce (buckets end on 64-element boundaries,
+    so this only happens for world sizes that do not divide 64)."""
+
+    def __init__(self, flat, bucket_bytes=64 << 20, group=None, mode=None, bf16=None):
         self.flat, self.group, self.bucket_bytes = flat, group, bucket_bytes
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
         self.buckets = flat.buckets(bucket_bytes)       # the partition one-group-at-a-time reporting produces (tests, DESIGN)
         self.last_gid = self.buckets[-1][0]
         self.cuda = flat.grad.is_cuda
+        self.mode = mode or os.environ.get("MTP_COMM_MODE", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError("GradReducer mode must be 'allreduce' or 'rs_ag', got %r" % (self.mode,))
+        self.bf16 = (os.environ.get("MTP_COMM_BF16") == "1") if bf16 is None else bool(bf16)
         # MTP_FORCE_COMM=1: issue the collectives even at world size 1 (exercises the RCCL + side-stream path on a 1-GPU box)
-        import os
         self.active = self.world > 1 or (os.environ.get("MTP_FORCE_COMM") == "1" and dist.is_available() and dist.is_initialized())
         self.stream = torch.cuda.Stream() if self.cuda and self.active else None
-        # MTP_NATIVE_COMM=1: the collectives go through the C ABI (mtp_comm_allreduce_bucket -> ncclAllReduce) instead of torch.distributed
+        # MTP_NATIVE_COMM=1: the collectives go through the C ABI (mtp_comm_* -> ncclAllReduce / ncclReduceScatter / ncclAllGather)
+        # instead of torch.distributed
         self.native = None
         if self.stream is not None and os.environ.get("MTP_NATIVE_COMM") == "1":
             from .comm import RcclComm
             self.native = RcclComm(group)
         self.works = []
+        self.pending_casts = []   # bf16 mode: (scratch bucket, f32 slice) pairs whose cast back waits for the collective
         self.start = 0
-        self.bytes_reduced = 0
+        self.bytes_reduced = 0    # gradient bytes covered (f32), independent of the wire format
+        self.wire_bytes = 0       # bytes handed to the collectives (half of bytes_reduced in bf16 mode)
         self.collectives = 0
-        self.timing = False       # bench.py: HIP events around every collective on the side stream
+        self.timing = False       # bench.py: HIP events around every bucket's exchange on the side stream
         self.timed = []
 
     def begin_step(self):
-        self.start, self.bytes_reduced, self.collectives = 0, 0, 0
+        self.start, self.bytes_reduced, self.wire_bytes, self.collectives = 0, 0, 0, 0
+
+    # ---- one bucket -----------------------------------------------------------------------------------------------------------
+    def _cast(self, src, dst):
+        if src.is_cuda:
+            from . import ops
+            ops.cast(src, dst)       # HIP kernel on the current (side) stream
+        else:
+            dst.copy_(src)
+        return dst
+
+    def _exchange(self, wire):
+        """issue the collective(s) for one bucket on the current stream / asynchronously; returns the torch Work handles"""
+        rs = self.mode == "rs_ag" and wire.numel() % self.world == 0
+        if self.native is not None:
+            if rs:
+                self.native.reduce_scatter_(wire)
+                self.native.all_gather_(wire)
+                self.collectives += 2
+            else:
+                self.native.all_reduce_(wire)
+                self.collectives += 1
+            return []
+        if rs:
+            n = wire.numel() // self.world
+            shard = wire[self.rank * n:(self.rank + 1) * n]
+            if self.stream is not None:
+                w1 = dist.reduce_scatter_tensor(shard, wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w1.wait()       # stream-level: orders the all-gather behind the reduce-scatter on the side stream
+                w2 = dist.all_gather_into_tensor(wire, shard, group=self.group, async_op=True)
+                self.collectives += 2
+                return [w2]
+            # CPU / gloo: synchronous, and through a private copy of the shard (gloo does not promise the in-place forms)
+            mine = torch.empty_like(shard)
+            dist.reduce_scatter_tensor(mine, wire, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(wire, mine, group=self.group)
+            self.collectives += 2
+            return []
+        self.collectives += 1
+        return [dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+
+    def _bucket(self, buf):
+        if self.bf16:
+            wire = self._cast(buf, torch.empty(buf.numel(), device=buf.device, dtype=torch.bfloat16))
+        else:
+            wire = buf
+        self.wire_bytes += wire.numel() * wire.element_size()
+        works = self._exchange(wire)
+        if self.bf16:
+            if self.stream is not None:
+                for w in works:
+                    w.wait()                       # stream-level wait on the side stream, then the cast back on the same stream
+                self._cast(wire, buf)
+                works = []
+            else:
+                self.pending_casts.append((wire, buf))
+        return works
 
     def on_block_done(self, gid):
         """engine hook: gradients of group `gid` (and everything before it in completion order) are on the compute stream."""
@@ -209,10 +281,9 @@ class GradReducer:
             return
         buf = self.flat.grad[self.start:end]
         self.bytes_reduced += (end - self.start) * 4
-        self.collectives += 1
         self.start = end
         if self.stream is None:
-            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.works += self._bucket(buf)
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -221,16 +292,14 @@ class GradReducer:
             if self.timing:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(self.stream)
-            if self.native is not None:
-                self.native.all_reduce_(buf)                  # ncclAllReduce on the side stream (the current one here)
-            else:
-                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self.works.append(w)
+            works = self._bucket(buf)
             if self.timing:
-                if self.native is None:
+                for w in works:
                     w.wait()                  # (stream-level wait: orders t1 behind the collective on the side stream)
                 t1.record(self.stream)
                 self.timed.append((buf.numel() * 4, t0, t1))
+                works = []
+            self.works += works
 
     def finish(self):
         """make the compute stream (or the host, on CPU) wait for every outstanding bucket."""
@@ -244,7 +313,23 @@ class GradReducer:
         else:
             for w in self.works:
                 w.wait()
+            for wire, buf in self.pending_casts:
+                buf.copy_(wire)
+            self.pending_casts = []
         self.works = []
+
+    def describe(self):
+        """what bench.py prints about the exchange (library, algorithm knobs in effect)"""
+        d = dict(mode=self.mode, wire_dtype="bf16" if self.bf16 else "f32", native_c_abi=self.native is not None, bucket_bytes=self.bucket_bytes)
+        for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE", "NCCL_DEBUG"):
+            if k in os.environ:
+                d[k] = os.environ[k]
+        try:
+            if self.cuda:
+                d["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        return d
 
 
 class FlatAdamW:
@@ -263,7 +348,11 @@ class FlatAdamW:
         self.hyper = torch.zeros(6, device=dev, dtype=torch.float32)
         self.sqn = torch.zeros(1, device=dev, dtype=torch.float32)
         self.t = 0            # Adam step count (bias correction)
-        self.last_epoch = 0   # CosineAnnealingLR.last_epoch: scheduler steps taken (the reference steps it AFTER saving, MAIN:823-832)
+        self.last_epoch = 0   # CosineAnnealingLR.last_epoch: scheduler steps taken
+        # The reference's loop is optimizer.step() -> [save the checkpoint] -> scheduler.step() (MAIN:788, 823-832).  step() here
+        # leaves the scheduler step PENDING until the next step() (or scheduler_step()), so that a checkpoint written between two
+        # steps holds what the reference's file holds at the same iteration: Adam step N, last_epoch N - 1, lr of epoch N - 1.
+        self.sched_pending = False
 
     def lr_at(self, t):
         if not self.total_steps:
@@ -334,6 +423,7 @@ class FlatAdamW:
             restored += 1
         self.t = t
         self.last_epoch = t      # (overwritten by load_scheduler_state_dict when the checkpoint carries the scheduler)
+        self.sched_pending = False
         return restored
 
     def scheduler_state_dict(self):
@@ -344,9 +434,17 @@ class FlatAdamW:
     def load_scheduler_state_dict(self, sd):
         self.total_steps = sd.get("T_max", self.total_steps)
         self.last_epoch = int(sd.get("last_epoch", self.last_epoch))
+        self.sched_pending = False     # the file's scheduler is the reference's at its save point: the resumed loop continues from it
+
+    def scheduler_step(self):
+        """scheduler.step() of MAIN:832 for the iteration step() ran last (no-op when none is pending)"""
+        if self.sched_pending:
+            self.last_epoch += 1
+            self.sched_pending = False
 
     def step(self):
         from . import ops
+        self.scheduler_step()
         self.t += 1
         self.hyper.copy_(torch.tensor(self.hyper_values(), dtype=torch.float32), non_blocking=True)
         f = self.flat
@@ -358,18 +456,19 @@ class FlatAdamW:
             ops.sqnorm(f.grad[:n], self.sqn)
             sq = self.sqn
         ops.adamw_flat(f.data[:n], f.grad[:n], self.m[:n], self.v[:n], self.seg_start, self.seg_wd, self.hyper, sq, float(self.max_norm or 0.0), gs)
-        self.last_epoch += 1     # scheduler.step() of MAIN:832
+        self.sched_pending = True     # scheduler.step() of MAIN:832 happens after the save point: see __init__
 
 
 class DataParallelTrainer:
     """fwd -> loss -> bwd (+ overlapped bucketed all-reduce) -> clip + AdamW, on the HIP engine."""
 
-    def __init__(self, module, lr=6e-5, weight_decay=0.05, max_norm=5.0, total_steps=None, bucket_bytes=64 << 20, feature_dtype=None):
+    def __init__(self, module, lr=6e-5, weight_decay=0.05, max_norm=5.0, total_steps=None, bucket_bytes=64 << 20, feature_dtype=None,
+                 comm_mode=None, comm_bf16=None):
         self.module = module
         self.engine = module._engine()
         self.flat = FlatParams(module, unused=module._unused_params)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.reducer = GradReducer(self.flat, bucket_bytes)
+        self.reducer = GradReducer(self.flat, bucket_bytes, mode=comm_mode, bf16=comm_bf16)
         self.opt = FlatAdamW(self.flat, lr=lr, weight_decay=weight_decay, max_norm=max_norm, total_steps=total_steps, world_size=self.world)
         self.feature_dtype = feature_dtype
         self.sync_replicas()
@@ -384,10 +483,12 @@ class DataParallelTrainer:
         if optimizer_state:
             dist.broadcast(self.opt.m, src=0)
             dist.broadcast(self.opt.v, src=0)
-            cnt = torch.tensor([self.opt.t, self.opt.last_epoch, self.opt.total_steps or 0], dtype=torch.int64, device=self.flat.data.device)
+            cnt = torch.tensor([self.opt.t, self.opt.last_epoch, self.opt.total_steps or 0, int(self.opt.sched_pending)], dtype=torch.int64,
+                               device=self.flat.data.device)
             dist.broadcast(cnt, src=0)
             self.opt.t, self.opt.last_epoch = int(cnt[0]), int(cnt[1])
             self.opt.total_steps = int(cnt[2]) or None
+            self.opt.sched_pending = bool(int(cnt[3]))
         self.engine._key = None
 
     # ---- encoder checkpoint in the reference's dict format (MAIN:823-829 save, MAIN:483-499 resume) -------------------------
@@ -413,8 +514,20 @@ class DataParallelTrainer:
             for k, v in ckpt["state_dict"].items():
                 if k in own:
                     own[k].copy_(v)        # in place: the parameters stay views of the flat buffer
+        self.restored_optimizer_entries = None
         if "optimizer" in ckpt:
-            self.opt.load_state_dict(ckpt["optimizer"], self.module)
+            # A checkpoint that carries optimizer state none of which matches a backbone parameter (another wrapper prefix, another
+            # architecture) would otherwise resume with zero moments and step 0 at the checkpoint's late-schedule learning rate -- silently.
+            n = self.opt.load_state_dict(ckpt["optimizer"], self.module)
+            self.restored_optimizer_entries = n
+            have = len(ckpt["optimizer"].get("state", {}))
+            want = sum(1 for k in self.flat.names if self.flat.groups[k] is not None)
+            if have and n == 0:
+                raise ValueError("the checkpoint holds optimizer state for %d parameters but none of them matches a backbone parameter (expected names "
+                                 "like 'encoder.blocks.0...' in param_groups[*]['param_names'], or a positional match)" % have)
+            if have and n < want:
+                import warnings
+                warnings.warn("optimizer state restored for %d of the backbone's %d trained parameters; the others restart with zero moments" % (n, want))
         if "scheduler" in ckpt:
             self.opt.load_scheduler_state_dict(ckpt["scheduler"])
         self.engine._key = None
@@ -428,7 +541,8 @@ class DataParallelTrainer:
         self.reducer.begin_step()
         feats, ctx = self.engine.forward(img, training=True, need_grad=True, feature_dtype=self.feature_dtype)
         loss, dfeats = loss_and_grads(feats)
-        self.engine.backward(ctx, dfeats, self.flat.G, on_block_done=self.reducer.on_block_done)
+        # (split_last: with collectives in flight, block 0's weight gradients go out on their own so that only ~50 MB stay exposed)
+        self.engine.backward(ctx, dfeats, self.flat.G, on_block_done=self.reducer.on_block_done, split_last=self.reducer.active)
         self.reducer.finish()
         self.opt.step()
         self.engine._key = None   # parameters changed under torch's version counters: rebuild the GEMM weight images next forward

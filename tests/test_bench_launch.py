@@ -1,0 +1,53 @@
+"""CPU: `python bench.py --gpus N` must be startable the way the driver starts it -- without a launcher around it (the
+N > 1 line could not even be started).  The launcher re-executes itself under torch.distributed.run on 127.0.0.1; here the ranks are
+gloo processes on CPU (`--cpu-standin`: the launch / rendezvous / report plumbing without kernels, labelled `standin: true`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _run(*argv, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600, env=e, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    return p.returncode, lines, p.stderr
+
+
+@pytest.mark.parametrize("mode,bf16", [("allreduce", False), ("rs_ag", False), ("rs_ag", True)])
+def test_gpus_2_self_launches_two_ranks_and_prints_one_json_line_last(mode, bf16):
+    rc, lines, err = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-standin", "--comm-mode", mode, *(["--comm-bf16"] if bf16 else []))
+    assert rc == 0, err[-2000:]
+    out = json.loads(lines[-1])                      # the JSON line is the LAST line of stdout
+    assert out["n_gpus"] == 2 and out["standin"] is True and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 * 64 and out["config"]["parallelism"] == "dp2"
+    c = out["comm"]
+    assert c["ranks"] == 2 and c["backend"] == "gloo" and c["mode"] == mode and c["bf16"] is bf16
+    assert c["replicas_identical"] is True and c["bytes_per_step"] > 0 and c["collectives_per_step"] >= 2
+    assert sum(1 for ln in lines if ln.startswith("{") and '"metric"' in ln) == 1
+
+
+def test_too_few_devices_gives_a_json_error_line_not_a_traceback():
+    if __import__("torch").cuda.is_available() and __import__("torch").cuda.device_count() >= 64:
+        pytest.skip("a 64-GPU box")
+    rc, lines, err = _run("--gpus", "64", "--steps", "1", "--warmup", "0")
+    assert rc != 0
+    out = json.loads(lines[-1])
+    assert out["value"] is None and out["n_gpus"] == 64 and "GPU" in out["error"]
+
+
+def test_world_size_mismatch_is_reported_as_json():
+    rc, lines, err = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-standin",
+                          env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577"})
+    assert rc != 0
+    out = json.loads(lines[-1])
+    assert out["value"] is None and "WORLD_SIZE" in out["error"]

@@ -152,3 +152,54 @@ def test_resume_from_a_whole_model_reference_checkpoint():
         assert torch.equal(tr.flat.view(tr.opt.m, n), st["exp_avg"]) and torch.equal(tr.flat.view(tr.opt.v, n), st["exp_avg_sq"])
     # the next step uses the learning rate the reference's resumed loop would use (its scheduler is still at epoch 2)
     assert tr.opt.hyper_values()[0] == pytest.approx(0.5 * 6e-5 * (1 + math.cos(math.pi * 2 / 100)))
+
+
+def test_checkpoint_scheduler_fields_match_the_reference_save_point():
+    """MAIN:788, 823-832: optimizer.step() -> save -> scheduler.step().  After N trainer steps the file must hold Adam step N and the
+    scheduler of epoch N - 1: FlatAdamW.step() leaves its scheduler step pending until the next step."""
+    net = small()
+    tr = DataParallelTrainer(net, total_steps=50)
+    opt = tr.opt
+    # what step() does around the kernels, three times (the kernels themselves need the GPU)
+    for _ in range(3):
+        opt.scheduler_step()
+        opt.t += 1
+        lr_used = opt.hyper_values()[0]
+        opt.sched_pending = True
+    assert opt.t == 3 and opt.last_epoch == 2 and lr_used == pytest.approx(opt.lr_at(2))
+    ck = tr.checkpoint()
+    ref = torch_adamw_like_reference(net)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(ref, 50, eta_min=0)
+    for _ in range(2):          # the reference's scheduler at the save point of iteration 3 has stepped twice
+        ref.step()
+        sched.step()
+    want = sched.state_dict()
+    assert ck["iteration"] == 3 and ck["scheduler"]["last_epoch"] == want["last_epoch"] == 2
+    assert ck["scheduler"]["_step_count"] == want["_step_count"] and ck["scheduler"]["_last_lr"][0] == pytest.approx(want["_last_lr"][0])
+    assert ck["optimizer"]["param_groups"][0]["lr"] == pytest.approx(ref.param_groups[0]["lr"])
+    # a resumed trainer continues like the reference's resumed loop: no pending scheduler step
+    tr2 = DataParallelTrainer(small(), total_steps=50)
+    tr2.opt.sched_pending = True
+    tr2.load_checkpoint(ck)
+    assert tr2.opt.last_epoch == 2 and tr2.opt.sched_pending is False
+
+
+def test_resume_with_foreign_optimizer_names_fails_loudly():
+    """optimizer state whose names match nothing must not silently restart Adam at a late-schedule learning rate"""
+    net = small()
+    tr = DataParallelTrainer(net, total_steps=50)
+    tr.opt.t = tr.opt.last_epoch = 5
+    tr.opt.m.fill_(0.1)
+    ck = tr.checkpoint()
+    for pg in ck["optimizer"]["param_groups"]:
+        pg["param_names"] = ["wrapper.model." + n for n in pg["param_names"]]
+    tr2 = DataParallelTrainer(small(), total_steps=50)
+    with pytest.raises(ValueError, match="none of them matches"):
+        tr2.load_checkpoint(ck)
+    # a partial match warns and reports the count
+    ck = tr.checkpoint()
+    first = ck["optimizer"]["param_groups"][0]
+    first["param_names"] = ["wrapper." + n if i % 2 else n for i, n in enumerate(first["param_names"])]
+    with pytest.warns(UserWarning, match="optimizer state restored for"):
+        tr2.load_checkpoint(ck)
+    assert 0 < tr2.restored_optimizer_entries < len([n for n in tr2.flat.names if tr2.flat.groups[n] is not None])

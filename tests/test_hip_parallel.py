@@ -31,7 +31,7 @@ def _loss(feats):
     return loss, [torch.full_like(f, 1.0 / f.numel()) for f in feats]
 
 
-def _worker(rank, world, port, q, native=False):
+def _worker(rank, world, port, q, native=False, mode="allreduce", bf16=False):
     import torch.distributed as dist
     from mtp_amd.parallel import DataParallelTrainer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -51,8 +51,9 @@ def _worker(rank, world, port, q, native=False):
         # ---- the data-parallel step: this rank's shard, replicas seeded differently on purpose (the trainer broadcasts rank 0's)
         os.environ["MTP_FORCE_COMM"] = "1"
         os.environ["MTP_NATIVE_COMM"] = "1" if native else "0"
-        tr = DataParallelTrainer(_net(0 if rank == 0 else 123).to(dev), total_steps=10, bucket_bytes=1 << 20)
+        tr = DataParallelTrainer(_net(0 if rank == 0 else 123).to(dev), total_steps=10, bucket_bytes=1 << 20, comm_mode=mode, comm_bf16=bf16)
         assert tr.reducer.active and tr.reducer.stream is not None and (tr.reducer.native is not None) == native
+        assert tr.reducer.mode == mode and tr.reducer.bf16 == bf16
         shard = imgs[2 * rank:2 * rank + 2].to(dev)
         tr.step(shard, _loss)
         torch.cuda.synchronize()
@@ -66,11 +67,11 @@ def _worker(rank, world, port, q, native=False):
         dist.destroy_process_group()
 
 
-def _run(world, native=False):
+def _run(world, native=False, mode="allreduce", bf16=False):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, native)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, native, mode, bf16)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
@@ -95,11 +96,25 @@ def test_forced_comm_single_rank_through_the_c_abi_communicator():
     assert err < 1e-5 and dparam < 1e-6 and ncoll >= 2 and all_bytes
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 @pytest.mark.parametrize("native", [False, True])
-def test_two_ranks_match_single_process_whole_batch(native):
+def test_forced_comm_single_rank_reduce_scatter_all_gather(native):
+    """mode rs_ag on one rank: every bucket goes through ncclReduceScatter + ncclAllGather (torch.distributed, or mtp_comm_* via the C ABI)
+    on the side stream; same gradients as without communication"""
+    (rank, err, dparam, ncoll, all_bytes), = _run(1, native=native, mode="rs_ag")
+    assert err < 1e-5 and dparam < 1e-6 and ncoll >= 4 and all_bytes
+
+
+def test_forced_comm_single_rank_bf16_buckets():
+    """bf16 on the wire: cast (mtp_cast on the side stream) -> collective -> cast back; on one rank the gradients come back rounded to bf16"""
+    (rank, err, dparam, ncoll, all_bytes), = _run(1, mode="rs_ag", bf16=True)
+    assert err < 1e-2 and ncoll >= 4 and all_bytes
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("native,mode", [(False, "allreduce"), (True, "allreduce"), (False, "rs_ag"), (True, "rs_ag")])
+def test_two_ranks_match_single_process_whole_batch(native, mode):
     """2 x MI355X: each rank computes half the batch; all-reduced gradients / 2 == the whole-batch gradients of one process (bf16
     rounding differs between a batch of 4 and two batches of 2 only through accumulation order: 2e-2), replicas end up identical"""
-    res = _run(2, native=native)
+    res = _run(2, native=native, mode=mode)
     for rank, err, dparam, ncoll, all_bytes in res:
         assert err < 2e-2 and ncoll >= 2 and all_bytes

@@ -105,6 +105,24 @@ def _worker(rank, world, port, q):
         red.finish()
         ok = ok and torch.equal(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
         ok = ok and n_after_burst >= 1 and red.start == flat.reduced
+        # ... and as reduce-scatter + all-gather of the same buckets (the direct form for xGMI): bit for bit the all-reduce's sums
+        flat.grad.copy_(local)
+        rs = GradReducer(flat, bucket_bytes=1 << 20, mode="rs_ag")
+        for gid in order:
+            rs.on_block_done(gid)
+        rs.finish()
+        ok = ok and torch.equal(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        ok = ok and rs.collectives == 2 * len(rs.buckets) and rs.wire_bytes == flat.reduced * 4
+        # ... and with bf16 on the wire: the sum of the bf16-rounded local gradients, rounded to bf16 (world 2: one addition)
+        flat.grad.copy_(local)
+        other = torch.randn(flat.total, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+        want = (local.bfloat16() + other.bfloat16()).float()       # bf16 + bf16 -> bf16, as gloo / RCCL reduce in the wire dtype
+        hb = GradReducer(flat, bucket_bytes=1 << 20, mode="rs_ag", bf16=True)
+        for gid in order:
+            hb.on_block_done(gid)
+        hb.finish()
+        ok = ok and torch.equal(flat.grad[:flat.reduced], want[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        ok = ok and hb.wire_bytes == flat.reduced * 2 and hb.bytes_reduced == flat.reduced * 4
         q.put((rank, bool(ok), red.bytes_reduced == flat.reduced * 4))
     finally:
         dist.destroy_process_group()
