@@ -72,12 +72,18 @@ typedef struct {
                          * the 256x128 8-wave NT tile; bit7 NT at 5 workgroups per CU (complete tiles only); bits8-9 the
                          * 8-wave pipelined NT kernel (1 = tile height picked per problem, 2 = 224 x 256 tiles, 3 = 256 x 256 tiles),
                          * bit10 forbids it; bits11-14 ablation builds of it (tools/ab_gemm.py); bit15 / bit16 force / forbid its
-                         * persistent-tile form.  All variants of one problem give bit-identical results. */
+                         * persistent-tile form; bit17 / bit18 force / forbid its stream-K form (needs `workspace`), bit19 = use it where
+                         * the built-in heuristic expects a gain.  All variants of one problem give bit-identical results. */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
     int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them
                          * later with mtp_sum_partials_batch (one launch for the weight gradients of a whole block) */
     int pad_;
+    void* workspace;    /* NT only, optional: >= mtp_gemm_nt_workspace_bytes() of device memory, 256-byte aligned, ZERO when first
+                         * used and then left to the callee (flags of the stream-K form of the pipelined kernel: work cut along K per
+                         * XCD instead of rounded up to whole tiles; partial sums handed from one workgroup to another through it).
+                         * One workspace per stream: launches that may overlap must not share it.  NULL = that form is not used. */
+    int64_t workspace_bytes;
 } mtp_gemm_args;
 
 /* y = x W^T (+epilogue): nn.Linear fwd/dgrad (VIT:50,52,78,87,256,262), patch-embed conv as GEMM (VIT:529),
@@ -87,6 +93,8 @@ int mtp_gemm_nt(const mtp_gemm_args* args, mtp_stream_t stream);
  * 256 x 256 x 64 kernel (bf16, K % 128 == 0, M % 8 == 0, N % 8 == 0), 128 = the 128-wide kernels (every other case, and f32).
  * Both families accumulate in the same k order: results are bit-identical. */
 int mtp_gemm_nt_tile(const mtp_gemm_args* args);
+/* bytes of `workspace` the stream-K form needs on this device (flags + one 256-KiB slot of partial sums per CU; 64.1 MB on MI355X) */
+int64_t mtp_gemm_nt_workspace_bytes(void);
 /* weight gradient: C[m][n] = sum_k A[k][m] * B[k][n]  (dW = dY^T X), f32 output. */
 int mtp_gemm_tn(const mtp_gemm_args* args, mtp_stream_t stream);
 /* Grouped weight gradients: `count` (<= MTP_MAX_GROUPED_GEMMS) independent problems C_i (M_i, N_i) f32 = A_i (K_i, M_i)^T B_i (K_i, N_i)

@@ -21,7 +21,8 @@ class GemmArgs(C.Structure):
                 ("in_dtype", i32), ("out_dtype", i32), ("epilogue", i32),
                 ("bias", p), ("bias_mod", i64), ("res", p), ("res_ld", i64), ("res_mod", i64),
                 ("rowscale", p), ("rows_per_sample", i64), ("aux", p), ("aux_ld", i64),
-                ("split_k", i32), ("variant", i32), ("colsum", p), ("defer_sum", i32), ("pad_", i32)]
+                ("split_k", i32), ("variant", i32), ("colsum", p), ("defer_sum", i32), ("pad_", i32),
+                ("workspace", p), ("workspace_bytes", i64)]
 
 
 class WimgDesc(C.Structure):
@@ -44,6 +45,7 @@ SIGNATURES = {
     "mtp_dcnv3_bwd": (i32, [p, p, p, p, i32, p, p, p, C.POINTER(Dcnv3Geom), p]),
     "mtp_gemm_nt": (i32, [C.POINTER(GemmArgs), p]),
     "mtp_gemm_nt_tile": (i32, [C.POINTER(GemmArgs)]),
+    "mtp_gemm_nt_workspace_bytes": (i64, []),
     "mtp_gemm_tn": (i32, [C.POINTER(GemmArgs), p]),
     "mtp_gemm_tn_grouped": (i32, [C.POINTER(GemmArgs), i32, p]),
     "mtp_sum_partials_batch": (i32, [p, p, p, p, i32, p]),

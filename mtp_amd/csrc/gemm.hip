@@ -627,6 +627,8 @@ int fill_common(const mtp_gemm_args* a, KArgs& k) {
     k.order = (a->variant >> 1) & 3;
     k.split_stride = 0;
     k.colsum = nullptr;
+    k.sk_ws = (a->workspace && !((uintptr_t)a->workspace & 255)) ? a->workspace : nullptr;
+    k.sk_ws_bytes = k.sk_ws ? (size_t)a->workspace_bytes : 0;
     return 0;
 }
 
@@ -659,7 +661,7 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     // when the problem does not fit it
     if constexpr (sizeof(T) == 2) {
         const int p8 = nt_p8_mode(a, k);
-        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4) | (((a->variant >> 15) & 3) << 8), stream);
+        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 17) & 7) << 10), stream);
     }
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);
@@ -806,6 +808,8 @@ extern "C" int mtp_gemm_nt(const mtp_gemm_args* a, mtp_stream_t stream) {
     if (a->in_dtype == MTP_BF16 && a->out_dtype == MTP_F32 && a->epilogue == MTP_EPI_BIAS) return launch_nt<bf16_t, float, MTP_EPI_BIAS>(a, s);
     return MTP_ERR_UNSUPPORTED;
 }
+
+extern "C" int64_t mtp_gemm_nt_workspace_bytes(void) { return (int64_t)mtp_nt_p8_workspace_bytes(); }
 
 extern "C" int mtp_gemm_nt_tile(const mtp_gemm_args* a) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return MTP_ERR_ARG;

@@ -12,6 +12,29 @@ from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_DG, EPI_BIAS_RES, EPI_
 
 _DT = {torch.float32: MTP_F32, torch.bfloat16: MTP_BF16}
 _NT_VARIANT = int(__import__("os").environ.get("MTP_NT_VARIANT", "0"))   # whole-model A/B of the NT GEMM kernel choices (mtp_hip.h: variant)
+NT_STREAMK, NT_NO_STREAMK, NT_STREAMK_AUTO = 1 << 17, 1 << 18, 1 << 19
+_NT_SK_DEFAULT = NT_STREAMK_AUTO if __import__("os").environ.get("MTP_NT_STREAMK", "0") != "0" else 0   # MTP_NT_STREAMK=0: never (A/B)
+_NT_WS = {}      # (device, stream) -> zero-initialised workspace of the stream-K NT kernel (flags + partial-sum slots, 64 MB)
+
+
+def nt_workspace():
+    """the stream-K workspace of the CURRENT stream (mtp_gemm_args.workspace: one per stream, zero when first used, then owned by the kernels)"""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _NT_WS.get(key)
+    if ws is None:
+        ws = _NT_WS[key] = torch.zeros(lib().mtp_gemm_nt_workspace_bytes(), device="cuda", dtype=torch.uint8)
+    return ws
+
+
+def nt_streamk_status(reset=True):
+    """nonzero when a stream-K consumer gave up waiting for its partial sums (never in a healthy run; tests check it)"""
+    bad = 0
+    for ws in _NT_WS.values():
+        st = ws[16384:16388].view(torch.int32)
+        bad |= int(st.item())
+        if reset:
+            st.zero_()
+    return bad
 
 
 def lib():
@@ -68,7 +91,10 @@ def _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sa
     g.aux, g.aux_ld = _p(aux), (aux.shape[-1] if aux is not None else 0)
     if aux is not None:
         assert aux.dtype == out.dtype and tuple(aux.shape) == (M, N) and out.shape[1] == N
-    g.split_k, g.variant = 1, variant or _NT_VARIANT
+    g.split_k, g.variant = 1, variant or (_NT_VARIANT or _NT_SK_DEFAULT)
+    if (g.variant & (NT_STREAMK | NT_STREAMK_AUTO)) and a.dtype == torch.bfloat16 and M >= 256:
+        ws = nt_workspace()
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     return g
 
 

@@ -6,6 +6,15 @@ import numpy as np
 import torch
 
 
+# Input seed of fixture f13 (ViT-L, batch 2).  Bilinear sampling is only piecewise differentiable: an input with a sample within f32
+# rounding of a cell edge makes every f32 implementation pick one of two one-sided derivatives by its last bit (round 2: seed 2023 had
+# one 3.3e-6 px from an edge and moved the gradients upstream of that block by 1e-3).  tests/golden/find_f13_seed.py evaluates the
+# reference in float64 for candidate seeds; 2074 is the first whose closest sample is >= 1e-5 px (1.24e-5) from every edge, and
+# make_golden.f13 asserts that again.
+F13_INPUT_SEED = 2074
+F13_MIN_EDGE_DISTANCE = 1e-5
+
+
 def state_shapes(embed_dim=768, depth=12, heads=12, interval=3, img_size=224, mlp_ratio=4):
     """Reference state-dict keys and shapes (float tensors only), in the reference's order
     (checked against the reference's own state_dict() in make_golden.py -> f0_state_keys.json)."""

@@ -25,8 +25,9 @@ def test_header_symbols_are_bound_and_exported():
 def test_gemm_args_struct_layout():
     import ctypes as C
     from mtp_amd._lib import GemmArgs
-    # mirrors `mtp_gemm_args` in the header: 3 ptrs, 6 i64, 3 i32 (+pad), ptr, i64, ptr, 2 i64, ptr, i64, ptr, i64, 2 i32, ptr
-    assert C.sizeof(GemmArgs) == 3 * 8 + 6 * 8 + 3 * 4 + 4 + 8 + 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    # mirrors `mtp_gemm_args` in the header: 3 ptrs, 6 i64, 3 i32 (+pad), ptr, i64, ptr, 2 i64, ptr, i64, ptr, i64, 2 i32, ptr, 2 i32, ptr, i64
+    assert C.sizeof(GemmArgs) == 3 * 8 + 6 * 8 + 3 * 4 + 4 + 8 + 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert GemmArgs.workspace.offset == 184 and GemmArgs.workspace_bytes.offset == 192
     assert GemmArgs.bias.offset == 88 and GemmArgs.split_k.offset == 160 and GemmArgs.colsum.offset == 168 and GemmArgs.defer_sum.offset == 176
 
 
@@ -57,7 +58,7 @@ def test_every_entry_point_rejects_null_arguments_before_launching():
     from mtp_amd import _lib
     lib = _lib.load()
     queries = {"mtp_version", "mtp_layernorm_bwd_partial_rows", "mtp_full_attn_bwd_workspace_floats", "mtp_dwconv3x3_bwd_dw_partial_rows",
-               "mtp_scale_residual_bwd_partial_rows"}
+               "mtp_scale_residual_bwd_partial_rows", "mtp_gemm_nt_workspace_bytes"}
     for name, (_, argtypes) in sorted(_lib.SIGNATURES.items()):
         if name in queries:
             continue

@@ -275,6 +275,62 @@ def test_internimage_xl_one_step_shapes():
     assert float(dict(net.named_parameters())["levels.0.blocks.0.dcn.input_proj.weight"].grad.abs().max()) > 0
 
 
+def test_internimage_xl_at_512_batch_1_vs_oracle():
+    """BASELINE configs[4] at size: InternImage-XL (models.py:92-104: 192..1536 channels, depths 5 5 24 5, 12..96 groups) on ONE 512 x 512
+    tile -- DCNv3 level shapes 128^2 x 12 groups ... 16^2 x 96 groups, 16384 ... 256 rows per level, exactly what the segmentation
+    fine-tune runs per device (intern-xl-upernet-512-imp-mtp-loveda.py: batch 1).  fp32 mode against the oracle's forward AND autograd at
+    this size (features 1e-3, input gradient and a spread of parameter gradients 5e-3); bf16 mode against the same oracle run as
+    relative L2 (the throughput mode the benchmark times).  Offset / mask heads are re-drawn (they are zero at init, which would put
+    every sample exactly on a pixel centre -- a kink of the bilinear interpolation)."""
+    torch.manual_seed(11)
+    ref_net = mtp_amd.internimage_xl(drop_path_rate=0.0, precision="fp32", feature_dtype=torch.float32)
+    with torch.no_grad():
+        for n, q in ref_net.named_parameters():
+            if ".dcn.offset.weight" in n or ".dcn.mask.weight" in n:
+                q.normal_(0, 0.02)
+            if n.endswith("gamma1") or n.endswith("gamma2"):
+                q.fill_(0.1)          # layer scale 1e-5 at init would hide the 39 DCNv3 layers behind the residual stream
+    sd = {k: v.detach().clone() for k, v in ref_net.state_dict().items()}
+    img = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(21))
+    gs = None
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = img.clone().requires_grad_(True)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    ref = IO.backbone_forward(xr, p, [5, 5, 24, 5], [12, 24, 48, 96], 2.0)
+    assert [tuple(f.shape) for f in ref] == [(1, 192, 128, 128), (1, 384, 64, 64), (1, 768, 32, 32), (1, 1536, 16, 16)]
+    gs = [torch.randn(f.shape, generator=torch.Generator().manual_seed(300 + i)) / f[0].numel() ** 0.5 for i, f in enumerate(ref)]
+    sum((f * g).sum() for f, g in zip(ref, gs)).backward()
+    names = ["patch_embed.conv1.weight", "levels.0.blocks.0.dcn.offset.weight", "levels.0.blocks.4.dcn.input_proj.weight", "levels.0.blocks.2.gamma1",
+             "levels.1.blocks.3.dcn.mask.weight", "levels.1.downsample.conv.weight", "levels.2.blocks.0.mlp.fc1.weight", "levels.2.blocks.23.dcn.output_proj.weight",
+             "levels.2.blocks.11.dcn.dw_conv.0.weight", "levels.3.blocks.4.mlp.fc2.weight", "levels.3.blocks.0.norm1.0.weight"]
+    for precision in ("fp32", "bf16"):
+        net = mtp_amd.internimage_xl(drop_path_rate=0.0, precision=precision, feature_dtype=torch.float32)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        x = img.cuda().requires_grad_(True)
+        feats = net(x)
+        sum((f * g.cuda()).sum() for f, g in zip(feats, gs)).backward()
+        grads = dict(net.named_parameters())
+        for n, q in grads.items():
+            assert q.grad is not None and torch.isfinite(q.grad).all(), n
+        group = "internimage_xl_512_" + precision
+        for i, (f, r) in enumerate(zip(feats, ref)):
+            assert tuple(f.shape) == tuple(r.shape)
+            v = rel_err(f.cpu(), r.detach()) if precision == "fp32" else _l2(f.cpu(), r)
+            record_parity(group, "feat%d" % i, v)
+            assert v < (1e-3 if precision == "fp32" else 2e-2), (precision, i, v)
+        v = rel_err(x.grad.cpu(), xr.grad) if precision == "fp32" else _l2(x.grad.cpu(), xr.grad)
+        record_parity(group, "grad_img", v)
+        assert v < (5e-3 if precision == "fp32" else 0.15), (precision, v)
+        for n in names:
+            assert n in grads, n
+            v = rel_err(grads[n].grad.cpu(), p[n].grad) if precision == "fp32" else _l2(grads[n].grad.cpu(), p[n].grad)
+            record_parity(group, n, v)
+            assert v < (5e-3 if precision == "fp32" else 0.3), (precision, n, v)
+        del net, feats, x
+        torch.cuda.empty_cache()
+
+
 def test_internimage_through_the_data_parallel_trainer():
     """mtp_amd.parallel.DataParallelTrainer over InternImage (flat parameter / gradient buffers ordered by level and layer, clip + AdamW):
     the gradients of one step equal those of the autograd path, the parameters move, a second step runs"""

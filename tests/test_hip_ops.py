@@ -182,6 +182,59 @@ def test_gemm_nt_p8_vit_l_shapes_race_screen(ops):
                 assert torch.equal(out, ref), (N, K, v, rep)
 
 
+SK = 512 + (1 << 17)     # 224-row tiles, stream-K forced (variant bit 17; needs the workspace ops.gemm_nt attaches)
+
+
+@pytest.mark.parametrize("M,N,K", [(12544, 3072, 1024),     # qkv forward: 672 tiles = 2.625 per CU, a cut inside every XCD boundary (7 x 32 hand-offs)
+                                   (12544, 4096, 1024),     # fc1 forward / fc2 dgrad: 3.5 per CU, cuts at the odd boundaries only
+                                   (12544, 1024, 4096),     # 224 tiles < 256 CUs: the kernel must decline (falls back to the persistent form)
+                                   (12544 + 5 * 224, 2816, 256),    # ragged last super-tile (671 tiles: workgroups without a tile in it), ONE pair per tile... 2 k-tiles
+                                   (12552, 2056, 384),      # ragged M and N edges inside the last tiles, 3 pairs per tile
+                                   (50176, 4096, 1024)])    # the FPN GEMM: 14 rounds, no cut needed (pure de-synchronisation)
+def test_gemm_nt_streamk_bit_identical_and_repeatable(ops, M, N, K):
+    """stream-K form of the pipelined NT kernel (work cut along K per XCD, partial sums handed between workgroups through the
+    workspace): same k order -> bit-identical to the 128-wide kernels for every epilogue; every launch with FRESH data, so that a
+    partial sum left over from the previous launch (stale flag, stale cache line) or a hand-off race shows up as a mismatch"""
+    dtype, rps = torch.bfloat16, 196
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+
+    def grnd(*shape, dt=torch.float32, scale=1.0):          # drawn on the device: the operands are up to 0.8 GB
+        return (torch.randn(*shape, device="cuda", generator=g) * scale).to(dt)
+    for rep in range(1 if M > 20000 else 3):
+        a, w, b = grnd(M, K, dt=dtype), grnd(N, K, dt=dtype, scale=0.1), grnd(N)
+        res, uu = grnd(M, N), grnd(M, N, dt=dtype)
+        rs = 1.0 + 0.1 * grnd((M + rps - 1) // rps)
+
+        def run(v):
+            r = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=v)
+            f = ops.gemm_nt(a, w, e(M, N, dtype=dtype), bias=b, variant=v)
+            dg = e(M, N, dtype=dtype)
+            h2 = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU_DG, bias=b, aux=dg, variant=v)
+            mu = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_MUL, aux=uu, variant=v)
+            return r, f, dg, h2, mu
+        ref = run(1024)
+        for k2 in range(2):
+            for x, y in zip(ref, run(SK)):
+                assert torch.equal(x, y), (rep, k2)
+    assert ops.nt_streamk_status() == 0        # no consumer ever gave up waiting for its partial sums
+
+
+def test_gemm_nt_streamk_back_to_back_different_shapes(ops):
+    """launches of different shapes share the workspace back to back on one stream (flags are left at zero by the consumers)"""
+    dtype = torch.bfloat16
+    shapes = [(12544, 3072, 1024), (12544, 4096, 1024), (12544, 3072, 1024), (50176, 4096, 1024), (12544, 4096, 1024)]
+    data = []
+    g = torch.Generator(device="cuda").manual_seed(77)
+    for i, (M, N, K) in enumerate(shapes):
+        a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        w = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(dtype)
+        data.append((a, w, ops.gemm_nt(a, w, e(M, N, dtype=dtype), variant=1024)))
+    outs = [ops.gemm_nt(a, w, e(*ref.shape, dtype=dtype), variant=SK) for a, w, ref in data]     # no sync in between
+    for (a, w, ref), out in zip(data, outs):
+        assert torch.equal(out, ref)
+    assert ops.nt_streamk_status() == 0
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Kc,M,N,split", [(392, 384, 128, 1), (392, 256, 128, 3), (1000, 128, 768, 4), (64, 128, 128, 1), (12544, 256, 128, None)])
 def test_gemm_tn(ops, dtype, Kc, M, N, split):

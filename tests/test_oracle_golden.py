@@ -294,16 +294,16 @@ def test_f13_vitl_whole_forward_and_gradients(golden):
     """the headline model (BASELINE configs 3 / 4): ViT-L + RVSA from the reference's own factory, batch 2 -- the oracle is pinned at
     the size the benchmark runs (C = 1024, 16 heads, 24 blocks), forward, input gradient and twelve parameter gradients.
 
-    Gradient tolerance: bilinear sampling is only piecewise differentiable in the sample position.  Among the ~6 M samples of this
-    run one (in block 12) sits within f32 rounding of a cell boundary: the oracle's closed-form grid in f32 puts it on the other
-    side than the reference's (and than the oracle's own f64 run, which agrees with the reference to 1.5e-6 everywhere), i.e.
-    picks the other one-sided derivative for that sample -- block 12's sampling-offset gradient moves by 7e-3 and everything
-    upstream of block 12 by 4e-4 .. 1.3e-3 (relative L2), while blocks 13 .. 23 and the FPN agree to 1e-6.  Both are correct f32
-    evaluations; the HIP kernels will pick a side of their own.  Hence 3e-3 upstream of block 13, 1e-4 (5 x TOL) from there on."""
+    The input is one without a bilinear sample near a cell edge (recipe.F13_INPUT_SEED: the closest of the 501,760 sample
+    coordinates is 1.24e-5 px from an edge in the reference's float64 run; make_golden.f13 asserts it).  Round 2's fixture (input
+    seed 2023) had a sample 3.3e-6 px from an edge: the oracle's f32 grid put it on the other side than the reference's, picked
+    the other one-sided derivative, and everything upstream of that block moved by up to 1.3e-3 -- a property of that input, not
+    of an implementation.  With this input every gradient agrees to 5 x TOL."""
     g = golden("f13_vitl.npz")
     p = {k: v.requires_grad_(True) for k, v in recipe.make_params(recipe.state_shapes(1024, 24, 16, 6)).items()}
     assert sum(v.numel() for v in p.values()) == int(g["n_params"][0])
-    img = recipe.make_input(2, 224, 224, seed=2023).requires_grad_(True)
+    assert int(g["input_seed"][0]) == recipe.F13_INPUT_SEED and float(g["min_edge_distance_px"][0]) >= recipe.F13_MIN_EDGE_DISTANCE
+    img = recipe.make_input(2, 224, 224, seed=recipe.F13_INPUT_SEED).requires_grad_(True)
     feats = O.backbone_forward(img, p, 24, 16, 6, [int(i) for i in g["out_indices"]])
     loss = 0
     for i, f in enumerate(feats):
@@ -311,10 +311,9 @@ def test_f13_vitl_whole_forward_and_gradients(golden):
         _check_summary(f, g["f%d_sum" % i], g["f%d_samples" % i], TOL, 4096)
         loss = loss + (f * recipe.loss_weights(f.shape, 600 + i)).sum()
     loss.backward()
-    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], 3e-3, 4096)
+    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], 5 * TOL, 4096)
     for k in g:
         if k.startswith("g_") and k.endswith("_samples"):
             n = k[2:-len("_samples")]
-            late = n.startswith("fpn") or (n.startswith("blocks.") and int(n.split(".")[1]) >= 13)
-            _check_summary(p[n].grad, g["g_%s_sum" % n], g[k], 5 * TOL if late else 3e-3, 2048)
+            _check_summary(p[n].grad, g["g_%s_sum" % n], g[k], 5 * TOL, 2048)
     assert p["norm.weight"].grad is None and not bool(g["norm_has_grad"][0])

@@ -13,7 +13,8 @@ from mtp_amd import ops
 from tools.bench_ops import r
 
 T, C = 12544, 1024
-NAMES = {1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
+SK = 1 << 17
+NAMES = {512 + SK: "p8-224-streamk", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
          256 + (3 << 11): "p8-noprio-nostagger", 256 + (4 << 11): "p8-nostore", 256 + (8 << 11): "p8-nomfma", 256 + (12 << 11): "p8-nomfma-nostore", 256 + (15 << 11): "p8-direct-epi"}
 
 
@@ -34,7 +35,7 @@ def main():
     cases = []
     for (M, N, K) in [(T, 3 * C, C), (T, C, C), (T, 4 * C, C), (T, C, 4 * C), (T, C, 3 * C), (4 * T, 4 * C, C), (T, C, 768)]:
         cases.append(("bias", M, N, K))
-    cases += [("gelu", T, 4 * C, C), ("dgelu", T, 4 * C, C), ("res", T, C, C), ("res", T, C, 4 * C)]
+    cases += [("gelu", T, 4 * C, C), ("dgelu", T, 4 * C, C), ("gelu_dg", T, 4 * C, C), ("mul", T, 4 * C, C), ("res", T, C, C), ("res", T, C, 4 * C)]
     for (epi, M, N, K) in cases:
         a, w = r(M, K), r(N, K, scale=0.02)
         bias = torch.randn(N, device="cuda")
@@ -44,6 +45,10 @@ def main():
             kw.update(epi=ops.EPI_BIAS_GELU, aux=torch.empty(M, N, device="cuda", dtype=bf))
         elif epi == "dgelu":
             kw = dict(epi=ops.EPI_DGELU, aux=r(M, N))
+        elif epi == "gelu_dg":      # what the engine's fc1 forward runs (gelu + gelu' out)
+            kw.update(epi=ops.EPI_BIAS_GELU_DG, aux=torch.empty(M, N, device="cuda", dtype=bf))
+        elif epi == "mul":          # ... and its fc2 dgrad
+            kw = dict(epi=ops.EPI_MUL, aux=r(M, N))
         elif epi == "res":
             kw.update(epi=ops.EPI_BIAS_RES, res=torch.randn(M, N, device="cuda"))
             odt = torch.float32
@@ -53,7 +58,7 @@ def main():
         okv = {}
         iters = 10 if M > T else 20
         for v in variants:
-            if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536) and epi != "bias":
+            if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + SK) and epi != "bias":
                 continue
             out.zero_()
             ops.gemm_nt(a, w, out, variant=v, **kw)
