@@ -73,7 +73,7 @@ typedef struct {
                          * 8-wave pipelined NT kernel (1 = tile height picked per problem, 2 = 224 x 256 tiles, 3 = 256 x 256 tiles),
                          * bit10 forbids it; bits11-14 ablation builds of it (tools/ab_gemm.py); bit15 / bit16 force / forbid its
                          * persistent-tile form; bit17 / bit18 force / forbid its stream-K form (needs `workspace`), bit19 = use it where
-                         * the built-in heuristic expects a gain.  All variants of one problem give bit-identical results. */
+                         * the built-in heuristic expects a gain; bits20-21 store policy of its epilogue (0 = by epilogue: nt, sc1 for the f32 residual form; 1 = nt, 2 = sc1 write-through, 3 = plain).  All variants of one problem give bit-identical results. */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
     int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them

@@ -653,6 +653,7 @@ bool make_fgeom(int64_t Hp, int64_t Wp, int64_t heads, FGeom& g) {
 
 int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* rel_h, const float* rel_w,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
+    if (mtp_full_v3_fits(Hp, Wp)) return mtp_full_v3_fwd_launch(qkv, o, lse, rel_h, rel_w, B, Hp, Wp, heads, scale, s);
     FGeom g;
     if (!make_fgeom(Hp, Wp, heads, g)) {
         const int64_t N = Hp * Wp;
@@ -681,6 +682,7 @@ int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* 
 
 int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
                              float* drel_part, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
+    if (mtp_full_v3_fits(Hp, Wp)) return mtp_full_v3_bwd_launch(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_part, B, Hp, Wp, heads, scale, s);
     FGeom g;
     if (!make_fgeom(Hp, Wp, heads, g)) return MTP_ERR_UNSUPPORTED;
     hipError_t e = hipMemsetAsync(drel_part, 0, sizeof(float) * (size_t)(B * heads) * (size_t)(g.RH + g.RW) * HD, s);

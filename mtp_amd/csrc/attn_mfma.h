@@ -15,6 +15,12 @@ int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* 
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
 int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
                              float* drel_part, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
+// token grids of at most 16 x 16 (attn_full_v3.hip: row-aligned tiles, relative-position logits as MFMA k-slots); MTP_ATTN_V3=0 turns them off
+bool mtp_full_v3_fits(int64_t Hp, int64_t Wp);
+int mtp_full_v3_fwd_launch(const void* qkv, void* o, float* lse, const float* rel_h, const float* rel_w, int64_t B, int64_t Hp, int64_t Wp, int64_t heads,
+                           float scale, hipStream_t s);
+int mtp_full_v3_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
+                           float* drel_part, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
 // beyond 256 tokens (attn_full_flash_bwd.hip); workspace as mtp_full_attn_bwd_workspace_floats
 int mtp_full_bwd_flash_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
                               float* drel_part, float* workspace, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);

@@ -661,7 +661,7 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     // when the problem does not fit it
     if constexpr (sizeof(T) == 2) {
         const int p8 = nt_p8_mode(a, k);
-        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 17) & 7) << 10), stream);
+        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 17) & 7) << 10) | (((a->variant >> 20) & 3) << 13), stream);
     }
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);

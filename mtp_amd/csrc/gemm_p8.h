@@ -123,6 +123,36 @@ __device__ __forceinline__ float4 ld4f(const float* p) {
 // tile row mrow0 + h * RSTRIDE, block columns [32s, 32s + 32) sit at tile column ncol0 + s * CSTRIP (NT kernel: one solid block,
 // RSTRIDE = 64, CSTRIP = 32; TN kernel: strips 128 apart, so that its DMA reads whole 256-B runs of the token-major operands).
 // ROWS = rows of the wave's block that exist (128; 112 in the 224-row NT tile, whose second pass has 48 rows).
+// 16-byte output store with a cache policy (A/B of the epilogue's write path): 0 = plain (the line stays in the XCD's
+// L2 until evicted), 1 = nt (streaming hint), 2 = sc1 (write-through: the line is not kept in L2, so a tile's 229 KiB of output
+// do not push the next tile's operand panels out of the 4-MiB L2)
+typedef __attribute__((ext_vector_type(4))) unsigned int p8_u32v4_t;
+template <int POL>
+__device__ __forceinline__ void p8_st16(void* ptr, const uint4& v) {
+    if constexpr (POL == 1) {
+        __builtin_nontemporal_store(p8_u32v4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<p8_u32v4_t*>(ptr));
+    } else if constexpr (POL == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(p8_u32v4_t{v.x, v.y, v.z, v.w}) : "memory");
+    } else {
+        *reinterpret_cast<uint4*>(ptr) = v;
+    }
+}
+template <int POL>
+__device__ __forceinline__ void p8_store8(bf16_t* p, const float (&o)[8]) {
+    p8_st16<POL>(p, make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])));
+}
+template <int POL>
+__device__ __forceinline__ void p8_store8(float* p, const float (&o)[8]) {
+    p8_st16<POL>(p, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])));
+    p8_st16<POL>(p + 4, make_uint4(__float_as_uint(o[4]), __float_as_uint(o[5]), __float_as_uint(o[6]), __float_as_uint(o[7])));
+}
+template <int POL>
+__device__ __forceinline__ void p8_store4(float* p, float4 v) {
+    p8_st16<POL>(p, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+}
+template <int POL>
+__device__ __forceinline__ void p8_store4(bf16_t* p, float4 v) { store4(p, v); }
+
 template <typename Tout, int EPI, int RSTRIDE = 64, int CSTRIP = 32, int ROWS = 128>
 __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8], char* wsm, int mrow0, int ncol0, int lane) {
     const int fr = lane & 15, g = lane >> 4;
@@ -241,7 +271,7 @@ __device__ __forceinline__ void epilogue_lds(const KArgs& p, f32x4_t (&acc)[4][8
 // The same epilogue through a SMALL private region (4 KiB per wave = 16 rows x 64 f32), for the persistent NT kernel: the ring is
 // already being refilled with the next tile's first K-tiles while this runs.  The wave's block is `ROWS` consecutive rows x 64
 // columns; side inputs are loaded 8 wave instructions (64 / 32 rows) ahead as above.
-template <typename Tout, int EPI, int ROWS>
+template <typename Tout, int EPI, int ROWS, int POL = 0>
 __device__ __forceinline__ void epilogue_lds16(const KArgs& p, f32x4_t (&acc)[4][8], char* wsm, int mrow0, int ncol0, int lane) {
     const int fr = lane & 15, g = lane >> 4;
     constexpr bool WIDE = sizeof(Tout) == 2;
@@ -314,14 +344,14 @@ __device__ __forceinline__ void epilogue_lds16(const KArgs& p, f32x4_t (&acc)[4]
 #pragma unroll
                     for (int e = 0; e < NV; ++e) v[e] += bias[e];
                     if constexpr (EPI == MTP_EPI_BIAS_GELU) {
-                        if (ok) store8(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, v);
+                        if (ok) p8_store8<POL>(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, v);
 #pragma unroll
                         for (int e = 0; e < NV; ++e) v[e] = gelu_f(v[e]);
                     } else if constexpr (EPI == MTP_EPI_BIAS_GELU_DG) {
                         float d[NV];
 #pragma unroll
                         for (int e = 0; e < NV; ++e) gelu_pair_f(v[e], v[e], d[e]);
-                        if (ok) store8(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, d);
+                        if (ok) p8_store8<POL>(reinterpret_cast<Tout*>(p.aux) + (int64_t)m * p.aux_ld + n, d);
                     } else if constexpr (EPI == MTP_EPI_DGELU) {
                         const uint32_t w[4] = {sideb[it].x, sideb[it].y, sideb[it].z, sideb[it].w};
 #pragma unroll
@@ -342,9 +372,9 @@ __device__ __forceinline__ void epilogue_lds16(const KArgs& p, f32x4_t (&acc)[4]
                     }
                     if (ok) {
                         if constexpr (WIDE)
-                            store8(C + (int64_t)m * p.ldc + n, v);
+                            p8_store8<POL>(C + (int64_t)m * p.ldc + n, v);
                         else
-                            store4(C + (int64_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+                            p8_store4<POL>(C + (int64_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
                     }
                 }
             }

@@ -157,7 +157,7 @@ __device__ __forceinline__ void p8_issue_prologue(P8Ctx& c) {
 // through 4 KiB per wave beyond the ring: the first-load latency of a tile and the workgroup hand-over are hidden behind the
 // previous tile's stores.  The load queue is drained (vmcnt(0)) once per tile, after the epilogue: the counted waits of the main
 // loop assume that only the DMA stream is in flight.
-template <typename Tout, int EPI, int MI1, int XP, int PS>
+template <typename Tout, int EPI, int MI1, int XP, int PS, int SP = 0>
 __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_p8_kernel(KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WROWS = 64 + 16 * MI1, BM = 2 * WROWS;      // rows per wave row, rows per tile
@@ -233,12 +233,14 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 p8_issue_prologue(c);
             }
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_lds16<Tout, EPI, WROWS>(p, acc, smem + P8_LDS + wave * 4096, em0 + wr * WROWS, en0 + wc * 64, lane);
+            epilogue_lds16<Tout, EPI, WROWS, SP>(p, acc, smem + P8_LDS + wave * 4096, em0 + wr * WROWS, en0 + wc * 64, lane);
             if (!more) break;
             __builtin_amdgcn_sched_barrier(0);
             wait_vm<0>();   // stores and side loads of the epilogue retired: only the DMA stream is counted from here on
         } else {
-            if (!(XP & 4) || p.M < 0) {
+            if constexpr (SP != 0) {   // (store-policy A/B: the one-shot kernel through the same small-region epilogue)
+                epilogue_lds16<Tout, EPI, WROWS, SP>(p, acc, smem + P8_LDS + wave * 4096, m0 + wr * WROWS, n0 + wc * 64, lane);
+            } else if (!(XP & 4) || p.M < 0) {
                 if constexpr (XP & 16)   // A/B: straight out of the MFMA layout (the epilogue of the 128-wide kernels)
                     epilogue<Tout, EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
                 else
@@ -440,17 +442,17 @@ int p8_cus() {
     return ncu;
 }
 
-template <typename Tout, int EPI, int MI1, int XP, int PS = 0>
+template <typename Tout, int EPI, int MI1, int XP, int PS = 0, int SP = 0>
 int launch_p8_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
-    constexpr int LDS = P8_LDS + (PS ? 8 * 4096 : 0);
+    constexpr int LDS = P8_LDS + ((PS || SP) ? 8 * 4096 : 0);
     static bool attr = false;   // 128 / 160 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     const int grid = PS ? (ntiles < p8_cus() ? ntiles : p8_cus()) : ntiles;
-    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS>), dim3(grid), dim3(P8_THREADS), LDS, stream, a);
+    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>), dim3(grid), dim3(P8_THREADS), LDS, stream, a);
     return mtp_launch_status();
 }
 
@@ -534,6 +536,14 @@ int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
         }
     }
     const bool persist = (flags & 256) || (!(flags & 512) && bm == 224 && ntiles > p8_cus());
+    // store policy of the epilogue (224-row tiles; flags bits 13-14: 0 = by epilogue, 1 = nt, 2 = sc1 write-through, 3 = plain).  Measured with
+    // rotating output buffers (tools/ab_gemm.py, MTP_AB_ROTATE=8: in the training step every GEMM writes fresh memory) and in the step
+    // itself (profiles/r03_ab_store_policy.txt): nt wins for the bf16 outputs (+2...4 %), sc1 for the f32 residual epilogue (+1...5 %:
+    // its 103 MB of output per launch do not evict the operand panels from the 4-MiB L2s); whole step +1.0 %.
+    int sp = (flags >> 13) & 3;
+    if (sp == 0) sp = (EPI == MTP_EPI_BIAS_RES) ? 2 : 1;
+    if (bm == 224 && sp == 1) return persist ? launch_p8_kernel<Tout, EPI, 3, 0, 1, 1>(a, ntiles, stream) : launch_p8_kernel<Tout, EPI, 3, 0, 0, 1>(a, ntiles, stream);
+    if (bm == 224 && sp == 2) return persist ? launch_p8_kernel<Tout, EPI, 3, 0, 1, 2>(a, ntiles, stream) : launch_p8_kernel<Tout, EPI, 3, 0, 0, 2>(a, ntiles, stream);
     if (persist) {
         if (bm == 224) return launch_p8_kernel<Tout, EPI, 3, 0, 1>(a, ntiles, stream);
         return launch_p8_kernel<Tout, EPI, 4, 0, 1>(a, ntiles, stream);

@@ -160,7 +160,8 @@ def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
         return u, h, r, d, f, dg, h2, mu
     ref = run(1024)
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
-    for v in (512, 768, 512 + PS, 768 + PS):
+    NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20          # store policy of the epilogue: nt / sc1 (write-through) / plain stores (0 = picked per epilogue)
+    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN):
         for rep in range(4):
             for x, y in zip(ref, run(v)):
                 assert torch.equal(x, y), (v, rep)
@@ -558,6 +559,37 @@ def test_full_attention_fwd_bwd(ops, dtype, Hp, Wp):                            
     ops.full_attn_bwd(dev(qkv, dtype), o, dev(do, dtype), lse, dqkv, dev(rh), dev(rw), drh, drw, B, Hp, Wp, heads, hd ** -0.5)
     assert rel_err(dqkv.float().cpu(), gq) < TOL[dtype]
     assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype]
+
+
+@pytest.mark.parametrize("Hp,Wp,B", [(16, 16, 2), (15, 13, 2), (7, 16, 3), (16, 5, 2), (3, 3, 2), (1, 1, 2), (13, 14, 1), (2, 9, 4)])
+def test_full_attention_row_aligned_kernels_small_grids(ops, Hp, Wp, B):
+    """token grids of at most 16 x 16 run on the row-aligned kernels (attn_full_v3.hip: one MFMA tile = one image row, the
+    relative-position logits as one-hot k-slots of the same contraction, bias rows in two bf16 halves): full width / height (no padding
+    column, no -30000 slots), odd Hp (a key-tile pair with a missing tile), narrow and single-token grids -- forward, dq / dk / dv and both
+    table gradients vs the oracle's autograd"""
+    dtype = torch.bfloat16
+    heads, hd = 3, 64
+    C, N = heads * hd, Hp * Wp
+    T = B * N
+    qkv = _attn_inputs(T, C, dtype, seed=7)
+    rh, rw = 0.3 * rnd(2 * Hp - 1, hd, seed=1), 0.3 * rnd(2 * Wp - 1, hd, seed=2)
+    o, lse = e(T, C, dtype=dtype), e(B * heads * N)
+    ops.full_attn_fwd(dev(qkv, dtype), o, lse, dev(rh), dev(rw), B, Hp, Wp, heads, hd ** -0.5)
+    q = qkv.clone().requires_grad_(True)
+    rhr, rwr = rh.clone().requires_grad_(True), rw.clone().requires_grad_(True)
+    oref, lref = O.full_attn_fwd(q, B, Hp, Wp, heads, rhr, rwr)
+    assert rel_err(o.float().cpu(), oref) < TOL[dtype] and rel_err(lse.cpu().reshape(lref.shape), lref) < 5e-3
+    do = rnd(T, C, dtype=dtype, seed=3)
+    gq, gh, gw = torch.autograd.grad(oref, (q, rhr, rwr), do)
+    dqkv, drh, drw = e(T, 3 * C, dtype=dtype), e(*rh.shape), e(*rw.shape)
+    ops.full_attn_bwd(dev(qkv, dtype), o, dev(do, dtype), lse, dqkv, dev(rh), dev(rw), drh, drw, B, Hp, Wp, heads, hd ** -0.5)
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        if N == 1 and name != "dv":      # one key: softmax = 1, the exact dq / dk are zero (the kernel's are bf16 rounding noise of dP - delta)
+            assert float(dqkv[:, sl].float().abs().max()) < 1e-6, name
+            continue
+        assert rel_err(dqkv[:, sl].float().cpu(), gq[:, sl]) < TOL[dtype], name
+    if N > 1:
+        assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype]
 
 
 @pytest.mark.parametrize("Hp,Wp,B", [(64, 64, 1), (40, 25, 2), (33, 40, 1), (20, 50, 2), (40, 8, 2), (26, 10, 2)])

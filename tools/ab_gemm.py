@@ -14,7 +14,8 @@ from tools.bench_ops import r
 
 T, C = 12544, 1024
 SK = 1 << 17
-NAMES = {512 + SK: "p8-224-streamk", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
+NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20
+NAMES = {512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + SK: "p8-224-streamk", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
          256 + (3 << 11): "p8-noprio-nostagger", 256 + (4 << 11): "p8-nostore", 256 + (8 << 11): "p8-nomfma", 256 + (12 << 11): "p8-nomfma-nostore", 256 + (15 << 11): "p8-direct-epi"}
 
 
@@ -53,20 +54,33 @@ def main():
             kw.update(epi=ops.EPI_BIAS_RES, res=torch.randn(M, N, device="cuda"))
             odt = torch.float32
         out, ref = torch.empty(M, N, device="cuda", dtype=odt), torch.empty(M, N, device="cuda", dtype=odt)
+        # MTP_AB_ROTATE=n: cycle through n output (and aux-out) buffers, as the training step does -- every GEMM there writes fresh memory,
+        # while a benchmark that rewrites ONE buffer keeps its output lines resident in the 256-MB infinity cache
+        nrot = int(os.environ.get("MTP_AB_ROTATE", "1"))
+        outs = [out] + [torch.empty_like(out) for _ in range(nrot - 1)]
+        auxs = [kw.get("aux")] + [torch.empty_like(kw["aux"]) if (epi in ("gelu", "gelu_dg")) else kw.get("aux") for _ in range(nrot - 1)]
+        rot = [0]
+
+        def launch(v):
+            i = rot[0] = (rot[0] + 1) % nrot
+            k2 = dict(kw)
+            if auxs[i] is not None:
+                k2["aux"] = auxs[i]
+            ops.gemm_nt(a, w, outs[i], variant=v, **k2)
         ops.gemm_nt(a, w, ref, variant=1024, **kw)
         ts = {v: [] for v in variants}
         okv = {}
         iters = 10 if M > T else 20
         for v in variants:
-            if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + SK) and epi != "bias":
+            if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + SK, 512 + NT_, 512 + SC1, 512 + PLAIN) and epi != "bias":
                 continue
             out.zero_()
             ops.gemm_nt(a, w, out, variant=v, **kw)
             okv[v] = torch.equal(out, ref) or ((v >> 11) & 12) != 0     # the nostore / nomfma ablations compute nothing to compare
-            time_many(lambda: ops.gemm_nt(a, w, out, variant=v, **kw), 3)
+            time_many(lambda: launch(v), 3)
         for _ in range(rounds):
             for v in okv:
-                ts[v].append(time_many(lambda: ops.gemm_nt(a, w, out, variant=v, **kw), iters))
+                ts[v].append(time_many(lambda: launch(v), iters))
         fl = 2.0 * M * N * K
         cells = []
         for v in okv:
