@@ -56,6 +56,26 @@ __device__ __forceinline__ void v3_stage(const bf16_t* __restrict__ src, int64_t
     }
 }
 
+// The same in two halves: ALL loads of a workgroup's images are issued before the first LDS store (v3_stage alone is a loop of
+// load -> wait -> store round trips: 7 serialized global latencies per image with 256 threads, a third of the first version's time).
+template <int NTH, int IT>
+__device__ __forceinline__ void v3_stage_load(const bf16_t* __restrict__ src, int64_t ld, const V3Geom& g, int rows, int tid, uint4 (&v)[IT]) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTH, row = idx >> 3, c = idx & 7, y = row >> 4, x = row & 15;
+        const bool ok = idx < rows * 8 && y < g.Hp && x < g.Wp;
+        v[i] = row_frag(src, ld, ok ? y * g.Wp + x : 0, ok, 8 * c);
+    }
+}
+template <int NTH, int IT>
+__device__ __forceinline__ void v3_stage_store(char* img, int rows, int tid, const uint4 (&v)[IT]) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTH, row = idx >> 3, c = idx & 7;
+        if (idx < rows * 8) *reinterpret_cast<uint4*>(img + swz(row, c)) = v[i];
+    }
+}
+
 // a rel-pos table (rows x 64 f32) -> 32-row bf16 swizzled LDS image (4 KiB), rows >= `rows` zero
 __device__ __forceinline__ void v3_stage_table(const float* __restrict__ tab, int rows, char* img, int tid, int nthreads) {
     for (int idx = tid; idx < 32 * 8; idx += nthreads) {
@@ -117,7 +137,10 @@ __device__ __forceinline__ void v3_bias_rows(const V3Geom& g, const char* RhI, c
 // forward: one workgroup (NW waves) per (image, head); wave = query tiles (image rows) w, w + NW, ...
 // dynamic LDS: Ks | Vs (NPR x 128 each) | RhI | RwI (4 KiB each) | xr[NW][768] f32
 // ===================================================================================================================
-template <int NW>
+// HPT = the number of image rows when known at compile time (14: the 224^2 configurations), 0 = read it from the geometry.  With a runtime
+// row count every key-tile step sits in its own branch, which pins its LDS reads and its chain of four dependent MFMAs between two waits;
+// with a constant the compiler batches the reads of all tiles and interleaves their independent accumulation chains.
+template <int NW, int HPT>
 __global__ __launch_bounds__(64 * NW) void v3_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                          const float* __restrict__ rel_h, const float* __restrict__ rel_w, V3Geom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -139,12 +162,19 @@ __global__ __launch_bounds__(64 * NW) void v3_fwd_kernel(const bf16_t* __restric
     uint4 qn[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qn[ks] = row_frag(base, ld, wave * g.Wp + (nv ? fr : 0), nv && wave < g.Hp, ks * 32 + gq * 8);
-    v3_stage(base + C, ld, g, Ks, tid, 64 * NW, NR);
-    v3_stage(base + 2 * C, ld, g, Vs, tid, 64 * NW, NR);
-    v3_stage_table(rel_h, g.RH, RhI, tid, 64 * NW);
-    v3_stage_table(rel_w, g.RW, RwI, tid, 64 * NW);
+    {
+        constexpr int IT = (256 * 8 + 64 * NW - 1) / (64 * NW);     // NR <= 256 rows
+        uint4 vk[IT], vv[IT];
+        v3_stage_load<64 * NW, IT>(base + C, ld, g, NR, tid, vk);
+        v3_stage_load<64 * NW, IT>(base + 2 * C, ld, g, NR, tid, vv);
+        v3_stage_table(rel_h, g.RH, RhI, tid, 64 * NW);
+        v3_stage_table(rel_w, g.RW, RwI, tid, 64 * NW);
+        v3_stage_store<64 * NW, IT>(Ks, NR, tid, vk);
+        v3_stage_store<64 * NW, IT>(Vs, NR, tid, vv);
+    }
     __syncthreads();
 
+    constexpr int KTMAX = HPT ? HPT : 16, KKMAX = (KTMAX + 1) / 2;
     for (int y = wave; y < g.Hp; y += NW) {
         const int tok = y * g.Wp + (nv ? fr : 0);
         uint4 qf[2], ahi, alo;
@@ -154,12 +184,13 @@ __global__ __launch_bounds__(64 * NW) void v3_fwd_kernel(const bf16_t* __restric
             qn[ks] = row_frag(base, ld, (y + NW) * g.Wp + (nv ? fr : 0), nv && y + NW < g.Hp, ks * 32 + gq * 8);
         }
         v3_bias_rows(g, RhI, RwI, qf, xr, y, fr, gq, ahi, alo);
-        f32x4_t s[16];
+        f32x4_t s[2 * KKMAX];
         float m = -INFINITY;
+        if constexpr (KTMAX & 1) s[KTMAX] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt) {
+        for (int kt = 0; kt < KTMAX; ++kt) {
             s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (kt < g.Hp) {
+            if (HPT || kt < g.Hp) {
                 const uint4 ec = v3_ecode(kt, fr, gq);
                 s[kt] = mma(ld16(Ks + swz(16 * kt + fr, gq)), qf[0], s[kt]);
                 s[kt] = mma(ld16(Ks + swz(16 * kt + fr, 4 + gq)), qf[1], s[kt]);
@@ -176,10 +207,10 @@ __global__ __launch_bounds__(64 * NW) void v3_fwd_kernel(const bf16_t* __restric
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float l = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 16; ++kt)
+        for (int kt = 0; kt < KTMAX; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = kt < g.Hp ? __expf(s[kt][r] - m) : 0.f;     // (padding key columns: scale * -30000 -> 0)
+                const float p = (HPT || kt < g.Hp) ? __expf(s[kt][r] - m) : 0.f;     // (padding key columns: scale * -30000 -> 0)
                 s[kt][r] = p;
                 l += p;
             }
@@ -189,8 +220,8 @@ __global__ __launch_bounds__(64 * NW) void v3_fwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (kk < g.KK) {
+        for (int kk = 0; kk < KKMAX; ++kk) {
+            if (HPT || kk < g.KK) {
                 const uint4 pf = pack_bf16x8(s[2 * kk][0], s[2 * kk][1], s[2 * kk][2], s[2 * kk][3], s[2 * kk + 1][0], s[2 * kk + 1][1], s[2 * kk + 1][2], s[2 * kk + 1][3]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) oa[dt] = mma(v3_frag_tr(Vs, 32 * kk + 4 * gq, dt, fr), pf, oa[dt]);
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void v3_fwd_kernel(const bf16_t* __restric
 // forward's lse is known), the table fragments come out of the LDS images (R^T through the transpose read), so what stays live across
 // a query tile is dq (16) + the table-gradient accumulators (64).
 // ===================================================================================================================
-template <int NW>
+template <int NW, int HPT>
 __global__ __launch_bounds__(64 * NW) void v3_bwd_a_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, bf16_t* __restrict__ dqkv, const float* __restrict__ rel_h,
                                                            const float* __restrict__ rel_w, float* __restrict__ drel_part, V3Geom g, float scale) {
@@ -248,11 +279,18 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_a_kernel(const bf16_t* __restr
             on[ks] = row_frag(ob, C, tok0, ok0, ks * 32 + gq * 8);
         }
     }
-    v3_stage(base + C, ld, g, Ks, tid, 64 * NW);
-    v3_stage(base + 2 * C, ld, g, Vs, tid, 64 * NW);
-    v3_stage(base, ld, g, Qs, tid, 64 * NW);
-    v3_stage_table(rel_h, g.RH, RhI, tid, 64 * NW);
-    v3_stage_table(rel_w, g.RW, RwI, tid, 64 * NW);
+    {
+        constexpr int IT = (272 * 8 + 64 * NW - 1) / (64 * NW);     // NPR <= 272 rows
+        uint4 vk[IT], vv[IT], vq[IT];
+        v3_stage_load<64 * NW, IT>(base + C, ld, g, g.NPR, tid, vk);
+        v3_stage_load<64 * NW, IT>(base + 2 * C, ld, g, g.NPR, tid, vv);
+        v3_stage_load<64 * NW, IT>(base, ld, g, g.NPR, tid, vq);
+        v3_stage_table(rel_h, g.RH, RhI, tid, 64 * NW);
+        v3_stage_table(rel_w, g.RW, RwI, tid, 64 * NW);
+        v3_stage_store<64 * NW, IT>(Ks, g.NPR, tid, vk);
+        v3_stage_store<64 * NW, IT>(Vs, g.NPR, tid, vv);
+        v3_stage_store<64 * NW, IT>(Qs, g.NPR, tid, vq);
+    }
     f32x4_t tacc[2][2][4];   // [table][row tile][d tile]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -300,8 +338,9 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_a_kernel(const bf16_t* __restr
         f32x4_t dq[4], dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int kk = 0; kk < g.KK; ++kk) {
+        // two key-tile pairs per loop iteration (the independent chains of one pair cover the latencies of the other); a fully unrolled
+        // loop makes hipcc hoist every LDS read of the tile and spill
+        auto pair_step = [&](int kk) __attribute__((always_inline)) {
             float ds[2][4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -317,7 +356,7 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_a_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __expf(fminf(scale * sT[r] - ls, 30.f));
-                    ds[half][r] = kt < g.Hp ? p * (dpT[r] - dl) : 0.f;
+                    ds[half][r] = ((HPT && kt < HPT) || (!HPT && kt < g.Hp)) ? p * (dpT[r] - dl) : 0.f;
                 }
             }
             const uint4 dsf = pack_bf16x8(ds[0][0], ds[0][1], ds[0][2], ds[0][3], ds[1][0], ds[1][1], ds[1][2], ds[1][3]);
@@ -327,6 +366,18 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_a_kernel(const bf16_t* __restr
             const uint4 ehT = make_uint4(fr == 2 * kk ? o2 : 0u, fr == 2 * kk ? o2 : 0u, fr == 2 * kk + 1 ? o2 : 0u, fr == 2 * kk + 1 ? o2 : 0u);
             dh = mma(ehT, dsf, dh);      // lane (fr = query, gq): d(bias row)[hk = 4 gq + r]
             dw = mma(ewT, dsf, dw);      //                        d(bias row)[16 + wk], wk = 4 gq + r
+        };
+        if constexpr (HPT != 0) {
+            constexpr int nkk = (HPT + 1) / 2;
+#pragma unroll 1
+            for (int k2 = 0; k2 + 1 < nkk; k2 += 2) {
+                pair_step(k2);
+                pair_step(k2 + 1);
+            }
+            if (nkk & 1) pair_step(nkk - 1);
+        } else {
+#pragma unroll 1
+            for (int kk = 0; kk < g.KK; ++kk) pair_step(kk);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -406,7 +457,7 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_a_kernel(const bf16_t* __restr
 // backward B: dK, dV.  wave = key tiles.
 // dynamic LDS: Qs | dOs | QA (NPR x 128 each; QA row = [16 slots H | 16 slots W] hi, then lo) | RhI | RwI | lses[NPR] | delta[NPR] | xr[NW][768] f32
 // ===================================================================================================================
-template <int NW>
+template <int NW, int HPT>
 __global__ __launch_bounds__(64 * NW) void v3_bwd_b_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, bf16_t* __restrict__ dqkv, const float* __restrict__ rel_h,
                                                            const float* __restrict__ rel_w, V3Geom g, float scale) {
@@ -435,10 +486,16 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_b_kernel(const bf16_t* __restr
         kn[ks] = row_frag(base + C, ld, wave * g.Wp + (kv ? fr : 0), kv && wave < g.Hp, ks * 32 + gq * 8);
         vn[ks] = row_frag(base + 2 * C, ld, wave * g.Wp + (kv ? fr : 0), kv && wave < g.Hp, ks * 32 + gq * 8);
     }
-    v3_stage(base, ld, g, Qs, tid, 64 * NW);
-    v3_stage(dob, C, g, dOs, tid, 64 * NW);
-    v3_stage_table(rel_h, g.RH, RhI, tid, 64 * NW);
-    v3_stage_table(rel_w, g.RW, RwI, tid, 64 * NW);
+    {
+        constexpr int IT = (272 * 8 + 64 * NW - 1) / (64 * NW);
+        uint4 vq[IT], vd[IT];
+        v3_stage_load<64 * NW, IT>(base, ld, g, g.NPR, tid, vq);
+        v3_stage_load<64 * NW, IT>(dob, C, g, g.NPR, tid, vd);
+        v3_stage_table(rel_h, g.RH, RhI, tid, 64 * NW);
+        v3_stage_table(rel_w, g.RW, RwI, tid, 64 * NW);
+        v3_stage_store<64 * NW, IT>(Qs, g.NPR, tid, vq);
+        v3_stage_store<64 * NW, IT>(dOs, g.NPR, tid, vd);
+    }
     for (int row = tid; row < g.NPR; row += 64 * NW) {
         const int y = row >> 4, x = row & 15;
         const bool ok = y < g.Hp && x < g.Wp;
@@ -488,8 +545,7 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_b_kernel(const bf16_t* __restr
             dks[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             dvs[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-#pragma unroll 2
-        for (int kk = 0; kk < g.KK; ++kk) {
+        auto pair_step = [&](int kk) __attribute__((always_inline)) {
             float pv[2][4], dv[2][4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -518,6 +574,18 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_b_kernel(const bf16_t* __restr
                 dks[dt] = mma(v3_frag_tr(Qs, 32 * kk + 4 * gq, dt, fr), dsfb, dks[dt]);   // D[d][key fr]
                 dvs[dt] = mma(v3_frag_tr(dOs, 32 * kk + 4 * gq, dt, fr), pfb, dvs[dt]);
             }
+        };
+        if constexpr (HPT != 0) {
+            constexpr int nkk = (HPT + 1) / 2;
+#pragma unroll 1
+            for (int k2 = 0; k2 + 1 < nkk; k2 += 2) {
+                pair_step(k2);
+                pair_step(k2 + 1);
+            }
+            if (nkk & 1) pair_step(nkk - 1);
+        } else {
+#pragma unroll 1
+            for (int kk = 0; kk < g.KK; ++kk) pair_step(kk);
         }
         if (kv) {
             bf16_t* dk = dqkv + ((int64_t)b * N + tok) * ld + C + h * HD + 4 * gq;
@@ -551,10 +619,16 @@ int mtp_full_v3_fwd_launch(const void* qkv, void* o, float* lse, const float* re
                            float scale, hipStream_t s) {
     V3Geom g;
     if (!v3_geom(Hp, Wp, heads, g)) return MTP_ERR_UNSUPPORTED;
-    constexpr int NW = 4;        // 2 x 32 KiB images + 12 KiB: two workgroups (8 waves) per CU
+    constexpr int NW = 4;        // 2 x 28 KiB images + tables + 12 KiB: two workgroups (8 waves) per CU at 14 x 14
     const size_t lds = 2 * (size_t)(g.NPR - 16) * 128 + 8192 + (size_t)NW * 768 * 4;      // 76 KiB at 14 x 14
-    (void)hipFuncSetAttribute((const void*)v3_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(v3_fwd_kernel<NW>, dim3((unsigned)(B * heads)), dim3(64 * NW), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, g, scale);
+    const dim3 grid((unsigned)(B * heads)), block(64 * NW);
+    if (Hp == 14) {
+        (void)hipFuncSetAttribute((const void*)v3_fwd_kernel<NW, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((v3_fwd_kernel<NW, 14>), grid, block, lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, g, scale);
+    } else {
+        (void)hipFuncSetAttribute((const void*)v3_fwd_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((v3_fwd_kernel<NW, 0>), grid, block, lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, g, scale);
+    }
     return mtp_launch_status();
 }
 
@@ -567,11 +641,21 @@ int mtp_full_v3_bwd_launch(const void* qkv, const void* o, const void* dout, con
     constexpr int NW = 8;
     const size_t lds_a = 3 * (size_t)g.NPR * 128 + 8192 + (size_t)NW * 1280 * 4;
     const size_t lds_b = 3 * (size_t)g.NPR * 128 + 8192 + 2 * (size_t)g.NPR * 4 + (size_t)NW * 768 * 4;
-    (void)hipFuncSetAttribute((const void*)v3_bwd_a_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-    (void)hipFuncSetAttribute((const void*)v3_bwd_b_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-    hipLaunchKernelGGL(v3_bwd_a_kernel<NW>, dim3((unsigned)(B * heads)), dim3(64 * NW), lds_a, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
-                       (bf16_t*)dqkv, rel_h, rel_w, drel_part, g, scale);
-    hipLaunchKernelGGL(v3_bwd_b_kernel<NW>, dim3((unsigned)(B * heads)), dim3(64 * NW), lds_b, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse,
-                       (bf16_t*)dqkv, rel_h, rel_w, g, scale);
+    const dim3 grid((unsigned)(B * heads)), block(64 * NW);
+    if (Hp == 14) {
+        (void)hipFuncSetAttribute((const void*)v3_bwd_a_kernel<NW, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        (void)hipFuncSetAttribute((const void*)v3_bwd_b_kernel<NW, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        hipLaunchKernelGGL((v3_bwd_a_kernel<NW, 14>), grid, block, lds_a, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqkv, rel_h,
+                           rel_w, drel_part, g, scale);
+        hipLaunchKernelGGL((v3_bwd_b_kernel<NW, 14>), grid, block, lds_b, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqkv, rel_h,
+                           rel_w, g, scale);
+    } else {
+        (void)hipFuncSetAttribute((const void*)v3_bwd_a_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        (void)hipFuncSetAttribute((const void*)v3_bwd_b_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        hipLaunchKernelGGL((v3_bwd_a_kernel<NW, 0>), grid, block, lds_a, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqkv, rel_h,
+                           rel_w, drel_part, g, scale);
+        hipLaunchKernelGGL((v3_bwd_b_kernel<NW, 0>), grid, block, lds_b, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse, (bf16_t*)dqkv, rel_h,
+                           rel_w, g, scale);
+    }
     return mtp_launch_status();
 }

@@ -142,12 +142,17 @@ constexpr int SMP_F = 10;
 // key-major phase, so the problem's critical path is 4x shorter and 12 waves share a CU (3 workgroups x 4) instead of 3.
 // LDS: Ks | Vs (K_sel / V_sel rows, later P^T / dS^T) | R2 = {K^T} then {Q^T | dO^T} | QR | dQR | tab | lses | delta | smp | vsum
 // ===================================================================================================================
+// MODE: the scatter form, known at compile time for the product path (4 = rvsa_scatter_gemm_kernel takes the dK_sel / dV_sel rows; the
+// atomic forms and the phase-timing ablation stay runtime switches of the MODE = -1 instantiation): the in-kernel scatter paths cost the
+// "gemm" instantiation 40 VGPRs and ~800 instructions of code it never runs.
+template <int MODE>
 __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ samp, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv, float* __restrict__ dkv, float* __restrict__ dsamp,
                                                             float* __restrict__ rel_part, float* __restrict__ tab_part,
                                                             const float* __restrict__ rel_h, const float* __restrict__ rel_w, const float* __restrict__ bias_table,
                                                             RvsaGeom g, float scale, int dense_scatter_) {
-    const int dense_scatter = dense_scatter_ & 15, stop_after = dense_scatter_ >> 4;   // stop_after: phase-timing ablation (tools/ab_rvsa.py)
+    const int dense_scatter = MODE >= 0 ? MODE : (dense_scatter_ & 15);
+    const int stop_after = MODE >= 0 ? 0 : (dense_scatter_ >> 4);   // stop_after: phase-timing ablation (tools/ab_rvsa.py)
     __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
     __shared__ __attribute__((aligned(16))) char R2[2 * 64 * TP];
@@ -816,8 +821,12 @@ int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, 
         return st ? atoi(st) : 0;
     }();
     const int mode = mtp_rvsa_bwd_mfma_scatter_mode(Hp, Wp, heads);
-    hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
-                       (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, mode | (stop << 4));
+    if (mode == 4 && !stop)
+        hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel<4>, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
+                           (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, 4);
+    else
+        hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel<-1>, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
+                           (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, mode | (stop << 4));
     if (mode == 4 && !stop) {
         static const int abl = []() { const char* e = getenv("MTP_RVSA_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
         const int64_t N = Hp * Wp;

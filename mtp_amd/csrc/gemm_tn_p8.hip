@@ -260,6 +260,8 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     g.nprob = count;
     g.ntiles = tiles;
     g.plain = (args[0].variant >> 1) & 1;
+    // the 4-wave 32x32x16 form (gemm_tn_w4.hip): variant bit 5 of the first problem asks for it, bit 6 forbids it
+    if ((args[0].variant & 32) && !(args[0].variant & 64)) return mtp_gemm_tn_grouped_w4(args, count, (hipStream_t)stream);
     const int xp = (args[0].variant >> 11) & 15;   // ablation builds (tools/ab_wgrad.py): 2 = no stagger, 8 = no MFMAs
     void (*kern)(TnGroup) = xp == 2 ? gemm_tn_p8_kernel<2> : xp == 8 ? gemm_tn_p8_kernel<8> : gemm_tn_p8_kernel<0>;
     static bool attr[3] = {false, false, false};

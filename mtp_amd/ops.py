@@ -167,6 +167,8 @@ def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None,
 
 
 MAX_GROUPED = 32      # MTP_MAX_GROUPED_GEMMS
+TN_W4, TN_NO_W4 = 32, 64      # mtp_gemm_tn_grouped variant bits: the 4-wave 32x32x16 form (gemm_tn_w4.hip) / the 8-wave 8-phase form (gemm_tn_p8.hip)
+_TN_DEFAULT = TN_W4 if __import__("os").environ.get("MTP_TN_W4", "0") != "0" else 0
 _NO_GROUPED = bool(int(__import__("os").environ.get("MTP_NO_GROUPED_WGRAD", "0")))   # A/B: every weight gradient through mtp_gemm_tn
 
 
@@ -183,7 +185,7 @@ class WgradQueue:
     (f32 parity mode, sizes that are not multiples of 256 / 128) run immediately through gemm_tn."""
 
     def __init__(self, cus=256, variant=0, stream=None):
-        self.jobs, self.tiles, self.cus, self.variant = [], 0, cus, variant
+        self.jobs, self.tiles, self.cus, self.variant = [], 0, cus, variant or _TN_DEFAULT
         # stream: launch on this (side) stream instead of the current one.  The weight gradients are off the backward pass's
         # critical path; next to the chain of data-gradient GEMMs (224 or 672 tiles on 256 CUs: 12.5 % of the CUs idle in the last
         # round) their tiles fill the idle CUs.  flush() orders the launch after everything issued so far; wait() orders the

@@ -279,8 +279,10 @@ def _wgrad_group(ops, shapes, seed=0):
     [(128, 256, 256, True)],                                                                  # one tile, one K-tile pair
     [(256, 512, 256, True), (384, 256, 768, False), (1024, 256, 256, True)],                   # different contractions in one launch
     [(1536, 768, 256, True), (1536, 256, 256, True), (1536, 1024, 256, False), (1536, 256, 1024, True)]])   # a block's four gradients
-def test_gemm_tn_grouped_vs_oracle(ops, shapes):
+@pytest.mark.parametrize("variant", [0, 32])       # 0 = the 8-wave 8-phase kernel, 32 = the 4-wave 32x32x16 kernel (gemm_tn_w4.hip)
+def test_gemm_tn_grouped_vs_oracle(ops, shapes, variant):
     q, refs = _wgrad_group(ops, shapes)
+    q.variant = variant
     q.flush()
     for a, b, cs0, dw, cs in refs:
         assert rel_err(dw.cpu(), a.t() @ b) < 3e-4
@@ -288,7 +290,8 @@ def test_gemm_tn_grouped_vs_oracle(ops, shapes):
             assert rel_err(cs.cpu(), cs0 + a.sum(0)) < 1e-4
 
 
-def test_gemm_tn_grouped_vit_l_block_repeatable(ops):
+@pytest.mark.parametrize("variant", [0, 32])
+def test_gemm_tn_grouped_vit_l_block_repeatable(ops, variant):
     """the four weight gradients of a ViT-L block at the training size (T = 12544 tokens, 192 tiles, 98 K-tile pairs each) against
     the split-K kernels of gemm.hip, and launch-to-launch bit-identical (no atomics on dW; one atomic per bias-gradient entry):
     a stale or half-landed LDS tile in the counted-wait pipeline would show up as a difference"""
@@ -298,7 +301,7 @@ def test_gemm_tn_grouped_vit_l_block_repeatable(ops):
            for i, (K, M, N, _) in enumerate(shapes)]
     first = None
     for rep in range(3):
-        q = ops.WgradQueue()
+        q = ops.WgradQueue(variant=variant)
         outs = []
         for (a, b), (K, M, N, _) in zip(ins, shapes):
             dw, cs = e(M, N), torch.zeros(M, device="cuda")
@@ -314,7 +317,11 @@ def test_gemm_tn_grouped_vit_l_block_repeatable(ops):
                 assert rel_err(dw, ref) < 2e-5 and rel_err(cs, rcs) < 2e-5
         else:
             for (x, xc), (y, yc) in zip(first, outs):
-                assert torch.equal(x, y) and torch.equal(xc, yc), rep
+                assert torch.equal(x, y), rep
+                if variant == 0:
+                    assert torch.equal(xc, yc), rep
+                else:      # the 4-wave form spreads the bias gradient over the tile row: tiles_n f32 atomics per entry, order not fixed
+                    assert rel_err(xc, yc) < 1e-6, rep
 
 
 def test_wgrad_queue_falls_back_for_other_problems(ops):

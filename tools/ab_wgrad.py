@@ -46,14 +46,20 @@ def main():
                 ops.gemm_tn(a, b, dw, colsum=cs, defer=pend)
             ops.sum_partials(pend)
 
-        grouped(); split()
-        tg, ts, abl = [], [], {"nostagger": [], "nomfma": []}
+        grouped(64); split()
+        ref = [p[2].clone() for p in probs]
+        grouped(32)
+        err = max(float((p[2] - x).abs().max() / x.abs().max()) for p, x in zip(probs, ref))
+        tg, tw, ts, abl = [], [], [], {"nostagger": [], "nomfma": []}
         for _ in range(rounds):
-            tg.append(timed(grouped, 5))
+            tg.append(timed(lambda: grouped(64), 5))
+            tw.append(timed(lambda: grouped(32), 5))
             ts.append(timed(split, 5))
-            abl["nostagger"].append(timed(lambda: grouped(2 << 11), 3))
-            abl["nomfma"].append(timed(lambda: grouped(8 << 11), 3))
+            abl["nostagger"].append(timed(lambda: grouped(64 + (2 << 11)), 3))
+            abl["nomfma"].append(timed(lambda: grouped(64 + (8 << 11)), 3))
         print("   ablations: " + "  ".join("%s %.1f us" % (k, statistics.median(v) * 1e6) for k, v in abl.items()))
+        print("   4-wave 32x32x16 form (gemm_tn_w4.hip): %.1f us  %.0f TF/s (min %.1f us), max rel. difference to the 8-wave form %.2e" % (
+            statistics.median(tw) * 1e6, fl / statistics.median(tw) / 1e12, min(tw) * 1e6, err))
         print("%d block(s), %d tiles: grouped %.1f us  %.0f TF/s (min %.1f us) | split-K %.1f us  %.0f TF/s" % (
             nblk, sum((a.shape[1] // 256) * (b.shape[1] // 256) for a, b, _, _ in probs), statistics.median(tg) * 1e6, fl / statistics.median(tg) / 1e12,
             min(tg) * 1e6, statistics.median(ts) * 1e6, fl / statistics.median(ts) / 1e12), flush=True)
