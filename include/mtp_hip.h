@@ -304,13 +304,16 @@ typedef struct {
     float offset_scale;
     int im2col_step;
     int remove_center;
-    int variant;   /* 0 = default; bit0 = plain workgroup order instead of one contiguous pixel range per XCD (A/B) */
+    int variant;   /* 0 = default; bit0 = plain workgroup order instead of one contiguous pixel range per XCD (A/B);
+                    * bit1 = backward always as the per-corner f32-atomic scatter (default: the gather form where the geometry allows it) */
 } mtp_dcnv3_geom;
 /* Ho = (H + 2 pad_h - (dilation_h (kernel_h - 1) + 1)) / stride_h + 1, Wo likewise (dcnv3_cuda.cu:40-45) */
 int mtp_dcnv3_out_size(const mtp_dcnv3_geom* geom, int64_t* Ho, int64_t* Wo);
 int mtp_dcnv3_fwd(const void* input, const void* offset, const void* mask, void* output, int dtype, const mtp_dcnv3_geom* geom, mtp_stream_t stream);
 /* grad_input (N, H, W, C), grad_offset, grad_mask: f32, shaped like input / offset / mask; zero-filled by the callee where
- * the kernel accumulates into them (grad_input always: bilinear scatter with f32 atomics, like the reference). */
+ * the kernel accumulates into them.  grad_input: stride 1, "same" padding, 16-channel groups, <= 9 points (every InternImage
+ * level) -> summed per input pixel from the output pixels around it, plain stores, atomics only for samples displaced by more
+ * than a pixel beyond the kernel's reach; any other geometry -> bilinear scatter with f32 atomics, like the reference. */
 int mtp_dcnv3_bwd(const void* input, const void* offset, const void* mask, const void* grad_output, int dtype, float* grad_input, float* grad_offset,
                   float* grad_mask, const mtp_dcnv3_geom* geom, mtp_stream_t stream);
 

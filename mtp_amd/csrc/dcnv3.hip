@@ -19,6 +19,7 @@ struct DcnGeom {
     int N, H, W, Ho, Wo, G, GC, kh, kw, sh, sw, ph, pw, dh, dw, P, remove_center;
     float os;
     int xcd_order;   // 1: each of the 8 XCDs takes a contiguous range of workgroups (= of pixels), see block_index()
+    int scatter_bwd; // 1: always the per-corner atomic scatter backward (A/B, variant bit 1)
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring pixels gather from / scatter into the
@@ -196,6 +197,222 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward without the per-corner scatter (stride 1, "same" padding, 16-channel groups, <= 9 points: every InternImage level).
+//
+//   grad_input[i][c] = sum_o grad_out[o][c] * S(o, i),   S(o, i) = sum_p mask[o][p] * hat(loc_w(o, p) - i_x) * hat(loc_h(o, p) - i_y),
+//   hat(d) = max(0, 1 - |d|)  (the bilinear corner weight written from the corner's side)
+//
+// S does not depend on the channel: one lane = one INPUT pixel of one group (16 f32 accumulators) walks the (2R+1)^2 output pixels
+// around it, computes S from the sample locations staged once per workgroup in LDS, and adds S * grad_out[o][0..15] -- plain
+// stores, no atomics, no zero-fill (the scatter form: 36 f32 atomics per element = 67 % of the old kernel).
+// A sample whose weighted corners are not all within R pixels of its own output pixel ("far") is left out here (its mask entry is
+// staged as 0) and scattered with atomics by the offset / mask kernel below, which decides with the same predicate: together
+// every sample is counted exactly once.  R = ceil(half kernel span * offset_scale) + 1, i.e. offsets up to one pixel outwards
+// stay on the fast path (3 for InternImage's 3 x 3, offset_scale 2).
+constexpr int DT_TILE = 16;   // input tile edge: 256 lanes = 16 x 16 pixels of one group
+
+template <typename T>
+struct DtLds {   // per window pixel: loc_w[9] | loc_h[9] | mask'[9] | pad (28 f32 = 112 B), then grad_out[16] -- pitch / 16 odd: conflict-free b128 rows
+    static constexpr int kPitch = 112 + 16 * (int)sizeof(T);
+};
+
+__device__ __forceinline__ bool sample_valid(const DcnGeom& g, float loc_h, float loc_w) {
+    return loc_h > -1.f && loc_w > -1.f && loc_h < (float)g.H && loc_w < (float)g.W;
+}
+// (valid samples only) every corner that carries weight lies within R pixels of the output pixel (ho, wo)
+__device__ __forceinline__ bool sample_near(float loc_h, float loc_w, int ho, int wo, int R) {
+    const float fh = floorf(loc_h), fw = floorf(loc_w);
+    const int h0 = (int)fh, w0 = (int)fw;
+    const int h1 = h0 + (loc_h > fh ? 1 : 0), w1 = w0 + (loc_w > fw ? 1 : 0);
+    return h0 >= ho - R && h1 <= ho + R && w0 >= wo - R && w1 <= wo + R;
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(256, 2) void dcnv3_bwd_input_kernel(const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
+                                                                 float* __restrict__ grad_input, DcnGeom g, int tiles_x, int tiles_y) {
+    constexpr int WW = DT_TILE + 2 * R, NWIN = WW * WW, PITCH = DtLds<T>::kPitch;
+    extern __shared__ __attribute__((aligned(16))) char dt_sm[];
+    const int tid = threadIdx.x;
+    int64_t b = block_index(g);
+    const int gi = (int)(b % g.G);
+    b /= g.G;
+    const int tx0 = (int)(b % tiles_x) * DT_TILE;
+    b /= tiles_x;
+    const int ty0 = (int)(b % tiles_y) * DT_TILE, n = (int)(b / tiles_y);
+    const int C = g.G * 16;
+    const int halfw = (g.dw * (g.kw - 1)) >> 1, halfh = (g.dh * (g.kh - 1)) >> 1;
+    const int cw = g.kw / 2, chh = g.kh / 2;
+    // ---- stage the window: sample locations, masks (0 for invalid / far samples and for window pixels outside the map), grad_out
+    for (int w = tid; w < NWIN; w += 256) {
+        const int wy = w / WW, wx = w - wy * WW;
+        const int ho = ty0 - R + wy, wo = tx0 - R + wx;
+        const bool inmap = ho >= 0 && ho < g.H && wo >= 0 && wo < g.W;
+        const int hc = min(max(ho, 0), g.H - 1), wc = min(max(wo, 0), g.W - 1);
+        const int64_t pix = ((int64_t)n * g.H + hc) * g.W + wc, item = pix * g.G + gi;
+        const T* offp = offset + item * (2 * g.P);
+        const T* mp = mask + item * g.P;
+        float* f = reinterpret_cast<float*>(dt_sm + w * PITCH);
+        const float p0w = (float)(halfw - g.pw + wc) - (float)halfw * g.os;
+        const float p0h = (float)(halfh - g.ph + hc) - (float)halfh * g.os;
+        int p = 0;
+        for (int i = 0; i < g.kw; ++i)
+            for (int j = 0; j < g.kh; ++j) {
+                if (g.remove_center && i == cw && j == chh) continue;
+                const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
+                const float loc_h = p0h + ((float)(j * g.dh) + oh) * g.os, loc_w = p0w + ((float)(i * g.dw) + ow) * g.os;
+                const bool take = inmap && sample_valid(g, loc_h, loc_w) && sample_near(fminf(fmaxf(loc_h, -2.f), (float)g.H + 1.f), fminf(fmaxf(loc_w, -2.f), (float)g.W + 1.f), hc, wc, R);
+                f[p] = take ? loc_w : -1e9f;
+                f[9 + p] = take ? loc_h : -1e9f;
+                f[18 + p] = take ? m : 0.f;
+                ++p;
+            }
+        for (; p < 9; ++p) {
+            f[p] = -1e9f;
+            f[9 + p] = -1e9f;
+            f[18 + p] = 0.f;
+        }
+        f[27] = 0.f;
+        const T* gp = grad_out + pix * C + gi * 16;
+        uint4* dst = reinterpret_cast<uint4*>(dt_sm + w * PITCH + 112);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int c = 0; c < (int)sizeof(T) * 16 / 16; ++c) dst[c] = inmap ? ldg16(reinterpret_cast<const char*>(gp) + 16 * c) : z;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    const int iy = ty0 + ty, ix = tx0 + tx;
+    const float fy = (float)iy, fx = (float)ix;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    const char* base = dt_sm + (ty * WW + tx) * PITCH;
+#pragma unroll 1
+    for (int dy = 0; dy <= 2 * R; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx <= 2 * R; ++dx) {
+            const char* e = base + (dy * WW + dx) * PITCH;
+            float q[28];
+#pragma unroll
+            for (int v = 0; v < 7; ++v) {
+                const float4 t = *reinterpret_cast<const float4*>(e + 16 * v);
+                q[4 * v] = t.x; q[4 * v + 1] = t.y; q[4 * v + 2] = t.z; q[4 * v + 3] = t.w;
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                const float wx = fmaxf(1.f - fabsf(q[p] - fx), 0.f), wy = fmaxf(1.f - fabsf(q[9 + p] - fy), 0.f);
+                s = fmaf(wx * wy, q[18 + p], s);
+            }
+            if (__builtin_amdgcn_ballot_w64(s != 0.f) == 0) continue;      // (wave-uniform) no sample of these 64 output pixels reaches its lane's pixel
+            float d[16];
+            if constexpr (sizeof(T) == 2) {
+                load8(reinterpret_cast<const bf16_t*>(e + 112), reinterpret_cast<float(&)[8]>(d[0]));
+                load8(reinterpret_cast<const bf16_t*>(e + 128), reinterpret_cast<float(&)[8]>(d[8]));
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 t = *reinterpret_cast<const float4*>(e + 112 + 16 * v);
+                    d[4 * v] = t.x; d[4 * v + 1] = t.y; d[4 * v + 2] = t.z; d[4 * v + 3] = t.w;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = fmaf(s, d[c], acc[c]);
+        }
+    }
+    if (iy < g.H && ix < g.W) {
+        float* dst = grad_input + (((int64_t)n * g.H + iy) * g.W + ix) * C + gi * 16;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(dst + 4 * v) = make_float4(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
+    }
+}
+
+// d(offset), d(mask): one lane = (output pixel, group), the 16 channels in registers -- the sample location is computed once (not once per
+// channel lane), the channel sums are in-lane (no butterflies), the four corner rows are 2 (bf16) / 4 (f32) 16-byte loads each.
+// Far samples (see above) scatter their data gradient here, the whole wave working on one sample at a time: lane = (corner, channel), so
+// that a sample costs one atomic instruction of four 64-byte requests -- what the scatter kernel issues per sample, without its 16 lanes
+// per (pixel, group).  The sample's owner passes location / weights through readlane, its 16 grad_out values through LDS.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
+                                                           float* __restrict__ grad_input, float* __restrict__ grad_offset, float* __restrict__ grad_mask, DcnGeom g, int64_t total) {
+    __shared__ float tops[4][64][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t item_raw = block_index(g) * 256 + threadIdx.x;
+    const bool live = item_raw < total;                  // (no early return: the far-sample scatter below needs all 64 lanes)
+    const int64_t item = live ? item_raw : total - 1;
+    const int gi = (int)(item % g.G);
+    const int64_t pix = item / g.G;
+    const int wo = (int)(pix % g.Wo);
+    const int64_t t = pix / g.Wo;
+    const int ho = (int)(t % g.Ho), n = (int)(t / g.Ho);
+    const int C = g.G * 16;
+    const int64_t img = (int64_t)n * g.H * g.W * C + gi * 16;
+    const T* in_n = input + img;
+    const T* offp = offset + item * (2 * g.P);
+    const T* mp = mask + item * g.P;
+    float* goffp = grad_offset + item * (2 * g.P);
+    float* gmp = grad_mask + item * g.P;
+    float top[16];
+    load8(grad_out + pix * C + gi * 16, reinterpret_cast<float(&)[8]>(top[0]));
+    load8(grad_out + pix * C + gi * 16 + 8, reinterpret_cast<float(&)[8]>(top[8]));
+#pragma unroll
+    for (int c = 0; c < 16; ++c) tops[wave][lane][c] = top[c];      // (read by this wave only: LDS operations of one wave execute in order)
+    const int halfw = (g.dw * (g.kw - 1)) >> 1, halfh = (g.dh * (g.kh - 1)) >> 1;
+    const float p0w = (float)(halfw - g.pw + wo * g.sw) - (float)halfw * g.os;
+    const float p0h = (float)(halfh - g.ph + ho * g.sh) - (float)halfh * g.os;
+    const int cw = g.kw / 2, chh = g.kh / 2;
+    int p = 0;
+    for (int i = 0; i < g.kw; ++i) {
+        for (int j = 0; j < g.kh; ++j) {
+            if (g.remove_center && i == cw && j == chh) continue;
+            const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
+            const float loc_h = p0h + ((float)(j * g.dh) + oh) * g.os, loc_w = p0w + ((float)(i * g.dw) + ow) * g.os;
+            const Point pt = make_point(g, loc_h, loc_w, C);
+            float v[4][16];
+            const int o4[4] = {pt.o00, pt.o01, pt.o10, pt.o11};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                load8(in_n + o4[k], reinterpret_cast<float(&)[8]>(v[k][0]));
+                load8(in_n + o4[k] + 8, reinterpret_cast<float(&)[8]>(v[k][8]));
+            }
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) d[k] = fmaf(top[c], v[k][c], d[k]);
+            const float d00 = d[0] * pt.k00, d01 = d[1] * pt.k01, d10 = d[2] * pt.k10, d11 = d[3] * pt.k11;
+            const float hh = 1.f - pt.lh, hw = 1.f - pt.lw;
+            if (live) {
+                gmp[p] = hh * hw * d00 + hh * pt.lw * d01 + pt.lh * hw * d10 + pt.lh * pt.lw * d11;
+                *reinterpret_cast<float2*>(goffp + 2 * p) = make_float2(g.os * m * (hh * (d01 - d00) + pt.lh * (d11 - d10)), g.os * m * (hw * (d10 - d00) + pt.lw * (d11 - d01)));
+            }
+            if constexpr (R > 0) {
+                const bool far = live && sample_valid(g, loc_h, loc_w) &&
+                                 !sample_near(fminf(fmaxf(loc_h, -2.f), (float)g.H + 1.f), fminf(fmaxf(loc_w, -2.f), (float)g.W + 1.f), ho, wo, R);
+                uint64_t fm = __builtin_amdgcn_ballot_w64(far);
+                if (fm) {
+                    const float w00 = hh * hw * pt.k00 * m, w01 = hh * pt.lw * pt.k01 * m, w10 = pt.lh * hw * pt.k10 * m, w11 = pt.lh * pt.lw * pt.k11 * m;
+                    const int k = lane >> 4, c = lane & 15;
+                    const uint32_t img_lo = (uint32_t)((uint64_t)img & 0xffffffffu), img_hi = (uint32_t)((uint64_t)img >> 32);
+                    while (fm) {
+                        const int L = __builtin_ctzll(fm);
+                        fm &= fm - 1;
+                        const int s00 = __builtin_amdgcn_readlane(pt.o00, L), s01 = __builtin_amdgcn_readlane(pt.o01, L);
+                        const int s10 = __builtin_amdgcn_readlane(pt.o10, L), s11 = __builtin_amdgcn_readlane(pt.o11, L);
+                        const float x00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w00), L)), x01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w01), L));
+                        const float x10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w10), L)), x11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w11), L));
+                        const int64_t imgL = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)img_hi, L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)img_lo, L));
+                        const int ok = k == 0 ? s00 : k == 1 ? s01 : k == 2 ? s10 : s11;
+                        const float wk = k == 0 ? x00 : k == 1 ? x01 : k == 2 ? x10 : x11;
+                        if (wk != 0.f) atomicAdd(grad_input + imgL + ok + c, wk * tops[wave][L][c]);
+                    }
+                }
+            }
+            ++p;
+        }
+    }
+}
+
 int make_geom(const mtp_dcnv3_geom* a, DcnGeom& g) {
     MTP_CHECK_ARG(a != nullptr);
     MTP_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0 && a->group > 0 && a->group_channels > 0);
@@ -217,6 +434,7 @@ int make_geom(const mtp_dcnv3_geom* a, DcnGeom& g) {
     if ((int64_t)g.H * g.W * g.G * g.GC >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;   // 32-bit element offsets inside one image
     g.os = a->offset_scale;
     g.xcd_order = (a->variant & 1) ? 0 : 1;
+    g.scatter_bwd = (a->variant & 2) ? 1 : 0;
     return 0;
 }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -234,11 +452,37 @@ int launch_fwd(const void* input, const void* offset, const void* mask, void* ou
     return mtp_launch_status();
 }
 
+template <typename T, int R>
+int launch_bwd_gather(const void* input, const void* offset, const void* mask, const void* grad_output, float* grad_input, float* grad_offset, float* grad_mask, const DcnGeom& g,
+                      hipStream_t s, int tiles_x, int tiles_y, int64_t blocks, int64_t items) {
+    constexpr int LDS = (DT_TILE + 2 * R) * (DT_TILE + 2 * R) * DtLds<T>::kPitch;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)dcnv3_bwd_input_kernel<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dcnv3_bwd_input_kernel<T, R>), dim3((unsigned)blocks), dim3(256), LDS, s, (const T*)offset, (const T*)mask, (const T*)grad_output, grad_input, g, tiles_x, tiles_y);
+    hipLaunchKernelGGL((dcnv3_bwd_om_kernel<T, R>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (const T*)grad_output,
+                       grad_input, grad_offset, grad_mask, g, items);
+    return mtp_launch_status();
+}
+
 template <typename T>
 int launch_bwd(const void* input, const void* offset, const void* mask, const void* grad_output, float* grad_input, float* grad_offset, float* grad_mask, const DcnGeom& g,
                hipStream_t s) {
     const int64_t items = (int64_t)g.N * g.Ho * g.Wo * g.G, total = items * g.GC;
     const bool shfl = g.GC <= 64 && (g.GC & (g.GC - 1)) == 0;
+    // the gather form (no scatter): stride 1, "same" padding, 16-channel groups, <= 9 points, reach R <= 3
+    const int halfw = (g.dw * (g.kw - 1)) >> 1, halfh = (g.dh * (g.kh - 1)) >> 1;
+    const int reach = (int)ceilf((float)(halfw > halfh ? halfw : halfh) * fabsf(g.os)) + 1;
+    if (!g.scatter_bwd && g.GC == 16 && g.P <= 9 && g.sh == 1 && g.sw == 1 && g.Ho == g.H && g.Wo == g.W && g.ph == halfh && g.pw == halfw && reach <= 3 &&
+        aligned16(input) && aligned16(grad_output) && aligned16(grad_input) && (reinterpret_cast<uintptr_t>(grad_offset) & 7u) == 0) {
+        const int tiles_x = (g.W + DT_TILE - 1) / DT_TILE, tiles_y = (g.H + DT_TILE - 1) / DT_TILE;
+        const int64_t blocks = (int64_t)g.N * tiles_y * tiles_x * g.G;
+        if (blocks < ((int64_t)1 << 31)) return reach <= 2 ? launch_bwd_gather<T, 2>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s, tiles_x, tiles_y, blocks, items)
+                                                          : launch_bwd_gather<T, 3>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s, tiles_x, tiles_y, blocks, items);
+    }
     hipError_t e = hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)g.N * g.H * g.W * g.G * g.GC, s);   // the reference's at::zeros_like (dcnv3_cuda.cu:131)
     if (e != hipSuccess) return (int)e;
     if (!shfl) {

@@ -81,6 +81,31 @@ def test_internimage_sized_level_properties():
         assert torch.equal(yi, x.to(dt))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,osc,amp,rmc", [((2, 32, 32, 12), 2.0, 0.0, 0), ((2, 32, 32, 12), 2.0, 0.6, 0), ((1, 37, 21, 5), 2.0, 3.0, 0), ((2, 16, 16, 6), 1.0, 8.0, 0),
+                                               ((1, 20, 13, 3), 1.0, 1.5, 1), ((3, 7, 5, 2), 2.0, 1.0, 0), ((1, 50, 50, 4), 0.5, 2.0, 0)])
+def test_gather_form_backward_equals_the_scatter_form(shape, osc, amp, rmc, dtype, monkeypatch):
+    """the default backward on InternImage's geometry (3x3, stride 1, pad 1, 16-channel groups: grad_input summed per input pixel from the
+    output pixels around it + a wave-cooperative atomic path for samples beyond its reach) against the per-corner atomic scatter
+    (MTP_DCNV3_VARIANT=2, the kernel the fixture tests pinned in rounds 1-2): zero offsets (all samples on the fast path), small, and
+    large offsets (mostly the atomic path), map sizes that are not multiples of the 16 x 16 tile, remove_center, three offset scales"""
+    from mtp_amd.ops_dcnv3 import dcnv3_backward
+    torch.manual_seed(11)
+    N, H, W, M = shape
+    P = 9 - rmc
+    args = (3, 3, 1, 1, 1, 1, 1, 1, M, 16, osc)
+    x = torch.randn(N, H, W, M * 16, device="cuda").to(dtype)
+    off = ((torch.rand(N, H, W, M * P * 2, device="cuda") - 0.5) * 2 * amp).to(dtype)
+    m = torch.softmax(torch.randn(N, H, W, M, P, device="cuda"), -1).reshape(N, H, W, M * P).to(dtype)
+    G = torch.randn(N, H, W, M * 16, device="cuda").to(dtype)
+    monkeypatch.setenv("MTP_DCNV3_VARIANT", "2")
+    ref = dcnv3_backward(x, off, m, *args, G, 256, rmc)
+    monkeypatch.setenv("MTP_DCNV3_VARIANT", "0")
+    got = dcnv3_backward(x, off, m, *args, G, 256, rmc)
+    for a, b, name in zip(got, ref, ("grad_input", "grad_offset", "grad_mask")):
+        assert torch.isfinite(a).all() and rel(a, b) < 2e-6, name
+
+
 def test_bf16_matches_fp32_at_internimage_size():
     from mtp_amd.ops_dcnv3 import dcnv3_backward, dcnv3_forward
     torch.manual_seed(6)

@@ -15,7 +15,7 @@ from tools.bench_ops import r
 T, C = 12544, 1024
 SK = 1 << 17
 NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20
-NAMES = {512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + SK: "p8-224-streamk", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
+NAMES = {-1: "hipBLASLt(torch.addmm)", 512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + SK: "p8-224-streamk", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
          256 + (3 << 11): "p8-noprio-nostagger", 256 + (4 << 11): "p8-nostore", 256 + (8 << 11): "p8-nomfma", 256 + (12 << 11): "p8-nomfma-nostore", 256 + (15 << 11): "p8-direct-epi"}
 
 
@@ -61,8 +61,13 @@ def main():
         auxs = [kw.get("aux")] + [torch.empty_like(kw["aux"]) if (epi in ("gelu", "gelu_dg")) else kw.get("aux") for _ in range(nrot - 1)]
         rot = [0]
 
+        bias_bf = bias.to(bf)
+
         def launch(v):
             i = rot[0] = (rot[0] + 1) % nrot
+            if v == -1:                   # the library GEMM (torch -> hipBLASLt) on the same operands: a yardstick, not a product path
+                torch.addmm(bias_bf, a, w.t(), out=outs[i])
+                return
             k2 = dict(kw)
             if auxs[i] is not None:
                 k2["aux"] = auxs[i]
@@ -72,6 +77,11 @@ def main():
         okv = {}
         iters = 10 if M > T else 20
         for v in variants:
+            if v == -1:
+                if epi == "bias":
+                    okv[v] = True
+                    time_many(lambda: launch(v), 3)
+                continue
             if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + SK, 512 + NT_, 512 + SC1, 512 + PLAIN) and epi != "bias":
                 continue
             out.zero_()

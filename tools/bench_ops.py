@@ -104,21 +104,30 @@ def main():
         # also the reference's own timing case (ops_dcnv3/test.py:check_time_cost: N=512, 64x64, 4 groups x 16).
         # GB/s = algorithmic bytes (input + offset + mask + output once; backward: + grad_output, the three f32 gradients, grad_input twice)
         from mtp_amd.ops_dcnv3 import dcnv3_backward, dcnv3_forward
+        # offsets: "zero" = a freshly initialised network (the offset head is zero-initialised, ops_dcnv3/modules/dcnv3.py:176-179) -- what bench.py
+        # runs; "smooth" = +-0.25 px; "random" = +-2 px (x offset_scale 2: most samples leave the gather form's reach and take the atomic path).
+        # "scatter" = the per-corner f32-atomic backward (MTP_DCNV3_VARIANT=2), the form used for every geometry before round 3.
+        import os
         for (N, HW, M) in [(8, 128, 12), (8, 64, 24), (8, 32, 48), (8, 16, 96), (512, 64, 4)]:
             for dt in (bf, torch.float32):
                 e = 2 if dt == bf else 4
                 x = r(N, HW, HW, M * 16, dtype=dt)
-                off = ((torch.rand(N, HW, HW, M * 18, device=dev) - 0.5) * 4).to(dt)
                 m = torch.softmax(torch.randn(N, HW, HW, M, 9, device=dev), -1).reshape(N, HW, HW, M * 9).to(dt)
                 G = r(N, HW, HW, M * 16, dtype=dt)
                 a = (3, 3, 1, 1, 1, 1, 1, 1, M, 16, 2.0)
                 px = N * HW * HW
-                t = timeit(lambda: dcnv3_forward(x, off, m, *a, 256, 0), iters=10)
                 fb = px * M * (16 * e * 2 + 27 * e)
-                print("dcnv3_fwd %s N=%d %dx%d groups=%d: %.1f us  %.0f GB/s" % (str(dt)[6:], N, HW, HW, M, t * 1e6, fb / t / 1e9), flush=True)
-                t = timeit(lambda: dcnv3_backward(x, off, m, *a, G, 256, 0), iters=10)
-                bb = px * M * (16 * e * 2 + 27 * e + 16 * 4 * 2 + 27 * 4)
-                print("dcnv3_bwd %s N=%d %dx%d groups=%d: %.1f us  %.0f GB/s" % (str(dt)[6:], N, HW, HW, M, t * 1e6, bb / t / 1e9), flush=True)
+                bb = px * M * (16 * e * 2 + 27 * e + 16 * 4 + 27 * 4)
+                for kind, amp in (("zero", 0.0), ("smooth", 0.5), ("random", 4.0)):
+                    off = ((torch.rand(N, HW, HW, M * 18, device=dev) - 0.5) * amp).to(dt)
+                    t = timeit(lambda: dcnv3_forward(x, off, m, *a, 256, 0), iters=10)
+                    cells = ["fwd %.1f us %.0f GB/s" % (t * 1e6, fb / t / 1e9)]
+                    for name, var in (("bwd", "0"), ("bwd-scatter", "2")):
+                        os.environ["MTP_DCNV3_VARIANT"] = var
+                        t = timeit(lambda: dcnv3_backward(x, off, m, *a, G, 256, 0), iters=10)
+                        cells.append("%s %.1f us %.0f GB/s" % (name, t * 1e6, bb / t / 1e9))
+                    os.environ["MTP_DCNV3_VARIANT"] = "0"
+                    print("dcnv3 %s N=%d %dx%d groups=%d offsets=%s: %s" % (str(dt)[6:], N, HW, HW, M, kind, " | ".join(cells)), flush=True)
 
 
 if __name__ == "__main__":
