@@ -20,6 +20,7 @@ struct DcnGeom {
     float os;
     int xcd_order;   // 1: each of the 8 XCDs takes a contiguous range of workgroups (= of pixels), see block_index()
     int scatter_bwd; // 1: always the per-corner atomic scatter backward (A/B, variant bit 1)
+    int window_bwd;  // 1: the window form of the gather backward also where the 3 x 3 form applies (A/B, variant bit 2)
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring pixels gather from / scatter into the
@@ -228,6 +229,11 @@ __device__ __forceinline__ bool sample_near(float loc_h, float loc_w, int ho, in
     return h0 >= ho - R && h1 <= ho + R && w0 >= wo - R && w1 <= wo + R;
 }
 
+// (3 x 3 points, dilation 1, integer offset_scale) the sample lies within one pixel of its nominal position (nh, nw)
+__device__ __forceinline__ bool sample_near3x3(float loc_h, float loc_w, int nh, int nw) {
+    return fabsf(loc_h - (float)nh) < 1.f && fabsf(loc_w - (float)nw) < 1.f;
+}
+
 template <typename T, int R>
 __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input_kernel(const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
                                                                  float* __restrict__ grad_input, DcnGeom g, int tiles_x, int tiles_y) {
@@ -327,19 +333,139 @@ __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input_kernel(const T* __rest
     }
 }
 
-// d(offset), d(mask): one lane = (output pixel, group), the 16 channels in registers -- the sample location is computed once (not once per
-// channel lane), the channel sums are in-lane (no butterflies), the four corner rows are 2 (bf16) / 4 (f32) 16-byte loads each.
+// The same for InternImage's own geometry -- 3 x 3 points, dilation 1, offset_scale OS = 1 or 2 -- where point (pi, pj) of output pixel o sits
+// nominally at o + OS (pi - 1, pj - 1): a sample that stays within one pixel of its nominal position ("near" here) can only touch the input
+// pixels o + OS (pi - 1, pj - 1) + {-1, 0, 1}^2, so an input pixel has 9 x 9 = 81 candidate samples instead of the window's 9 (2R+1)^2 = 441,
+// each at a compile-time LDS offset from the lane's own window entry.  S(o, i) is collected in (2R+1)^2 registers (R = OS + 1) and applied to
+// grad_out[o] afterwards, skipping the output pixels no lane of the wave got a weight from.
+template <typename T, int OS>
+__global__ __launch_bounds__(256, 2) void dcnv3_bwd_input3x3_kernel(const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
+                                                                    float* __restrict__ grad_input, DcnGeom g, int tiles_x, int tiles_y) {
+    constexpr int R = OS + 1, D = 2 * R + 1, WW = DT_TILE + 2 * R, NWIN = WW * WW, PITCH = DtLds<T>::kPitch;
+    extern __shared__ __attribute__((aligned(16))) char dt_sm[];
+    const int tid = threadIdx.x;
+    int64_t b = block_index(g);
+    const int gi = (int)(b % g.G);
+    b /= g.G;
+    const int tx0 = (int)(b % tiles_x) * DT_TILE;
+    b /= tiles_x;
+    const int ty0 = (int)(b % tiles_y) * DT_TILE, n = (int)(b / tiles_y);
+    const int C = g.G * 16;
+    // ---- stage the window.  Entry: (loc_w, loc_h)[slot 0..8] | mask'[slot 0..8] | pad | grad_out[16]; slot = 3 pi + pj (the centre slot stays empty
+    // under remove_center)
+    for (int w = tid; w < NWIN; w += 256) {
+        const int wy = w / WW, wx = w - wy * WW;
+        const int ho = ty0 - R + wy, wo = tx0 - R + wx;
+        const bool inmap = ho >= 0 && ho < g.H && wo >= 0 && wo < g.W;
+        const int hc = min(max(ho, 0), g.H - 1), wc = min(max(wo, 0), g.W - 1);
+        const int64_t pix = ((int64_t)n * g.H + hc) * g.W + wc, item = pix * g.G + gi;
+        const T* offp = offset + item * (2 * g.P);
+        const T* mp = mask + item * g.P;
+        float* f = reinterpret_cast<float*>(dt_sm + w * PITCH);
+        const float p0w = (float)(1 - g.pw + wc) - g.os, p0h = (float)(1 - g.ph + hc) - g.os;      // (halfw = halfh = 1)
+        int p = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int q = 3 * i + j;
+                float lw = -1e9f, lh = -1e9f, mm = 0.f;
+                if (!(g.remove_center && i == 1 && j == 1)) {
+                    const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
+                    const float loc_h = p0h + ((float)j + oh) * g.os, loc_w = p0w + ((float)i + ow) * g.os;
+                    const bool take = inmap && sample_valid(g, loc_h, loc_w) && sample_near3x3(loc_h, loc_w, hc + OS * (j - 1), wc + OS * (i - 1));
+                    lw = take ? loc_w : -1e9f;
+                    lh = take ? loc_h : -1e9f;
+                    mm = take ? m : 0.f;
+                    ++p;
+                }
+                f[2 * q] = lw;
+                f[2 * q + 1] = lh;
+                f[18 + q] = mm;
+            }
+        f[27] = 0.f;
+        const T* gp = grad_out + pix * C + gi * 16;
+        uint4* dst = reinterpret_cast<uint4*>(dt_sm + w * PITCH + 112);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int c = 0; c < (int)sizeof(T) * 16 / 16; ++c) dst[c] = inmap ? ldg16(reinterpret_cast<const char*>(gp) + 16 * c) : z;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    const int iy = ty0 + ty, ix = tx0 + tx;
+    const float fy = (float)iy, fx = (float)ix;
+    const char* base = dt_sm + (ty * WW + tx) * PITCH;
+    float s[D * D];
+#pragma unroll
+    for (int d = 0; d < D * D; ++d) s[d] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = 3 * i + j;
+#pragma unroll
+            for (int ey = -1; ey <= 1; ++ey)
+#pragma unroll
+                for (int ex = -1; ex <= 1; ++ex) {
+                    const int dx = ex - OS * (i - 1) + R, dy = ey - OS * (j - 1) + R;      // window entry of the output pixel o = input pixel + (dx - R, dy - R)
+                    const char* e = base + (dy * WW + dx) * PITCH;
+                    const float2 l = *reinterpret_cast<const float2*>(e + 8 * q);
+                    const float m = *reinterpret_cast<const float*>(e + 72 + 4 * q);
+                    const float wx = __saturatef(1.f - fabsf(l.x - fx)), wy = __saturatef(1.f - fabsf(l.y - fy));
+                    s[dy * D + dx] = fmaf(wx * wy, m, s[dy * D + dx]);
+                }
+            // one point's 18 LDS reads in flight at a time: hipcc otherwise issues all 162 up front and sinks the weight arithmetic down to the
+            // per-output-pixel blocks below, keeping 243 loaded values alive (256 VGPRs + scratch)
+#pragma unroll
+            for (int d = 0; d < D * D; ++d) asm volatile("" : "+v"(s[d]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int d = 0; d < D * D; ++d) {
+        if (__builtin_amdgcn_ballot_w64(s[d] != 0.f) == 0) continue;      // (wave-uniform)
+        const char* e = base + ((d / D) * WW + (d % D)) * PITCH;
+        float v[16];
+        if constexpr (sizeof(T) == 2) {
+            load8(reinterpret_cast<const bf16_t*>(e + 112), reinterpret_cast<float(&)[8]>(v[0]));
+            load8(reinterpret_cast<const bf16_t*>(e + 128), reinterpret_cast<float(&)[8]>(v[8]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 t = *reinterpret_cast<const float4*>(e + 112 + 16 * u);
+                v[4 * u] = t.x; v[4 * u + 1] = t.y; v[4 * u + 2] = t.z; v[4 * u + 3] = t.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = fmaf(s[d], v[c], acc[c]);
+    }
+    if (iy < g.H && ix < g.W) {
+        float* dst = grad_input + (((int64_t)n * g.H + iy) * g.W + ix) * C + gi * 16;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(dst + 4 * u) = make_float4(acc[4 * u], acc[4 * u + 1], acc[4 * u + 2], acc[4 * u + 3]);
+    }
+}
+
+// d(offset), d(mask): one lane = (output pixel, group, 8-channel half) -- the sample location is computed twice (not once per channel lane as in the
+// scatter kernel), the channel sums are 8 in-lane terms + one exchange with the neighbour lane, the four corner rows are one (bf16) / two (f32)
+// 16-byte loads each, exactly the forward's gather.
 // Far samples (see above) scatter their data gradient here, the whole wave working on one sample at a time: lane = (corner, channel), so
 // that a sample costs one atomic instruction of four 64-byte requests -- what the scatter kernel issues per sample, without its 16 lanes
-// per (pixel, group).  The sample's owner passes location / weights through readlane, its 16 grad_out values through LDS.
-template <typename T, int R>
+// per (pixel, group).  The sample's owner passes location / weights through readlane, the pair's 16 grad_out values go through LDS.
+// NEAR = 1: the window test with reach R; NEAR = 2: the 3 x 3 / dilation 1 / integer offset_scale test (OS = R - 1).
+template <typename T, int NEAR>
 __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
-                                                           float* __restrict__ grad_input, float* __restrict__ grad_offset, float* __restrict__ grad_mask, DcnGeom g, int64_t total) {
-    __shared__ float tops[4][64][17];
+                                                           float* __restrict__ grad_input, float* __restrict__ grad_offset, float* __restrict__ grad_mask, DcnGeom g, int64_t total,
+                                                           int R) {
+    __shared__ float tops[4][64][9];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t item_raw = block_index(g) * 256 + threadIdx.x;
-    const bool live = item_raw < total;                  // (no early return: the far-sample scatter below needs all 64 lanes)
-    const int64_t item = live ? item_raw : total - 1;
+    const int64_t idx_raw = block_index(g) * 256 + threadIdx.x;
+    const bool live = idx_raw < 2 * total;               // (no early return: the far-sample scatter below needs all 64 lanes)
+    const int64_t idx = live ? idx_raw : 2 * total - 1;
+    const int half = (int)(idx & 1);
+    const int64_t item = idx >> 1;
     const int gi = (int)(item % g.G);
     const int64_t pix = item / g.G;
     const int wo = (int)(pix % g.Wo);
@@ -347,16 +473,15 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
     const int ho = (int)(t % g.Ho), n = (int)(t / g.Ho);
     const int C = g.G * 16;
     const int64_t img = (int64_t)n * g.H * g.W * C + gi * 16;
-    const T* in_n = input + img;
+    const T* in_n = input + img + 8 * half;
     const T* offp = offset + item * (2 * g.P);
     const T* mp = mask + item * g.P;
     float* goffp = grad_offset + item * (2 * g.P);
     float* gmp = grad_mask + item * g.P;
-    float top[16];
-    load8(grad_out + pix * C + gi * 16, reinterpret_cast<float(&)[8]>(top[0]));
-    load8(grad_out + pix * C + gi * 16 + 8, reinterpret_cast<float(&)[8]>(top[8]));
+    float top[8];
+    load8(grad_out + pix * C + gi * 16 + 8 * half, top);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) tops[wave][lane][c] = top[c];      // (read by this wave only: LDS operations of one wave execute in order)
+    for (int c = 0; c < 8; ++c) tops[wave][lane][c] = top[c];      // (read by this wave only: LDS operations of one wave execute in order)
     const int halfw = (g.dw * (g.kw - 1)) >> 1, halfh = (g.dh * (g.kh - 1)) >> 1;
     const float p0w = (float)(halfw - g.pw + wo * g.sw) - (float)halfw * g.os;
     const float p0h = (float)(halfh - g.ph + ho * g.sh) - (float)halfh * g.os;
@@ -368,44 +493,46 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
             const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
             const float loc_h = p0h + ((float)(j * g.dh) + oh) * g.os, loc_w = p0w + ((float)(i * g.dw) + ow) * g.os;
             const Point pt = make_point(g, loc_h, loc_w, C);
-            float v[4][16];
-            const int o4[4] = {pt.o00, pt.o01, pt.o10, pt.o11};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                load8(in_n + o4[k], reinterpret_cast<float(&)[8]>(v[k][0]));
-                load8(in_n + o4[k] + 8, reinterpret_cast<float(&)[8]>(v[k][8]));
-            }
+            float v[4][8];
+            load8(in_n + pt.o00, v[0]);
+            load8(in_n + pt.o01, v[1]);
+            load8(in_n + pt.o10, v[2]);
+            load8(in_n + pt.o11, v[3]);
             float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) d[k] = fmaf(top[c], v[k][c], d[k]);
+                for (int c = 0; c < 8; ++c) d[k] = fmaf(top[c], v[k][c], d[k]);
+                d[k] += __shfl_xor(d[k], 1, 64);
+            }
             const float d00 = d[0] * pt.k00, d01 = d[1] * pt.k01, d10 = d[2] * pt.k10, d11 = d[3] * pt.k11;
             const float hh = 1.f - pt.lh, hw = 1.f - pt.lw;
-            if (live) {
+            if (live && half == 0) {
                 gmp[p] = hh * hw * d00 + hh * pt.lw * d01 + pt.lh * hw * d10 + pt.lh * pt.lw * d11;
                 *reinterpret_cast<float2*>(goffp + 2 * p) = make_float2(g.os * m * (hh * (d01 - d00) + pt.lh * (d11 - d10)), g.os * m * (hw * (d10 - d00) + pt.lw * (d11 - d01)));
             }
-            if constexpr (R > 0) {
-                const bool far = live && sample_valid(g, loc_h, loc_w) &&
-                                 !sample_near(fminf(fmaxf(loc_h, -2.f), (float)g.H + 1.f), fminf(fmaxf(loc_w, -2.f), (float)g.W + 1.f), ho, wo, R);
-                uint64_t fm = __builtin_amdgcn_ballot_w64(far);
-                if (fm) {
-                    const float w00 = hh * hw * pt.k00 * m, w01 = hh * pt.lw * pt.k01 * m, w10 = pt.lh * hw * pt.k10 * m, w11 = pt.lh * pt.lw * pt.k11 * m;
-                    const int k = lane >> 4, c = lane & 15;
-                    const uint32_t img_lo = (uint32_t)((uint64_t)img & 0xffffffffu), img_hi = (uint32_t)((uint64_t)img >> 32);
-                    while (fm) {
-                        const int L = __builtin_ctzll(fm);
-                        fm &= fm - 1;
-                        const int s00 = __builtin_amdgcn_readlane(pt.o00, L), s01 = __builtin_amdgcn_readlane(pt.o01, L);
-                        const int s10 = __builtin_amdgcn_readlane(pt.o10, L), s11 = __builtin_amdgcn_readlane(pt.o11, L);
-                        const float x00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w00), L)), x01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w01), L));
-                        const float x10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w10), L)), x11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w11), L));
-                        const int64_t imgL = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)img_hi, L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)img_lo, L));
-                        const int ok = k == 0 ? s00 : k == 1 ? s01 : k == 2 ? s10 : s11;
-                        const float wk = k == 0 ? x00 : k == 1 ? x01 : k == 2 ? x10 : x11;
-                        if (wk != 0.f) atomicAdd(grad_input + imgL + ok + c, wk * tops[wave][L][c]);
-                    }
+            bool near;
+            if constexpr (NEAR == 2)
+                near = sample_near3x3(loc_h, loc_w, ho + (R - 1) * (j - 1), wo + (R - 1) * (i - 1));
+            else
+                near = sample_near(fminf(fmaxf(loc_h, -2.f), (float)g.H + 1.f), fminf(fmaxf(loc_w, -2.f), (float)g.W + 1.f), ho, wo, R);
+            const bool far = live && half == 0 && sample_valid(g, loc_h, loc_w) && !near;
+            uint64_t fm = __builtin_amdgcn_ballot_w64(far);
+            if (fm) {
+                const float w00 = hh * hw * pt.k00 * m, w01 = hh * pt.lw * pt.k01 * m, w10 = pt.lh * hw * pt.k10 * m, w11 = pt.lh * pt.lw * pt.k11 * m;
+                const int k = lane >> 4, c = lane & 15;
+                const uint32_t img_lo = (uint32_t)((uint64_t)img & 0xffffffffu), img_hi = (uint32_t)((uint64_t)img >> 32);
+                while (fm) {
+                    const int L = __builtin_ctzll(fm);      // an even lane: lanes L, L + 1 hold channels 0-7, 8-15 of the sample's grad_out
+                    fm &= fm - 1;
+                    const int s00 = __builtin_amdgcn_readlane(pt.o00, L), s01 = __builtin_amdgcn_readlane(pt.o01, L);
+                    const int s10 = __builtin_amdgcn_readlane(pt.o10, L), s11 = __builtin_amdgcn_readlane(pt.o11, L);
+                    const float x00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w00), L)), x01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w01), L));
+                    const float x10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w10), L)), x11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w11), L));
+                    const int64_t imgL = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)img_hi, L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)img_lo, L));
+                    const int ok = k == 0 ? s00 : k == 1 ? s01 : k == 2 ? s10 : s11;
+                    const float wk = k == 0 ? x00 : k == 1 ? x01 : k == 2 ? x10 : x11;
+                    if (wk != 0.f) atomicAdd(grad_input + imgL + ok + c, wk * tops[wave][L + (c >> 3)][c & 7]);
                 }
             }
             ++p;
@@ -435,6 +562,7 @@ int make_geom(const mtp_dcnv3_geom* a, DcnGeom& g) {
     g.os = a->offset_scale;
     g.xcd_order = (a->variant & 1) ? 0 : 1;
     g.scatter_bwd = (a->variant & 2) ? 1 : 0;
+    g.window_bwd = (a->variant & 4) ? 1 : 0;
     return 0;
 }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -452,19 +580,24 @@ int launch_fwd(const void* input, const void* offset, const void* mask, void* ou
     return mtp_launch_status();
 }
 
-template <typename T, int R>
+// OS3 = 0: the window form with reach R; OS3 = 1 / 2: the 3 x 3 form for offset_scale 1 / 2 (R = OS3 + 1)
+template <typename T, int R, int OS3>
 int launch_bwd_gather(const void* input, const void* offset, const void* mask, const void* grad_output, float* grad_input, float* grad_offset, float* grad_mask, const DcnGeom& g,
                       hipStream_t s, int tiles_x, int tiles_y, int64_t blocks, int64_t items) {
     constexpr int LDS = (DT_TILE + 2 * R) * (DT_TILE + 2 * R) * DtLds<T>::kPitch;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dcnv3_bwd_input_kernel<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = OS3 ? hipFuncSetAttribute((const void*)dcnv3_bwd_input3x3_kernel<T, (OS3 ? OS3 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                           : hipFuncSetAttribute((const void*)dcnv3_bwd_input_kernel<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((dcnv3_bwd_input_kernel<T, R>), dim3((unsigned)blocks), dim3(256), LDS, s, (const T*)offset, (const T*)mask, (const T*)grad_output, grad_input, g, tiles_x, tiles_y);
-    hipLaunchKernelGGL((dcnv3_bwd_om_kernel<T, R>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (const T*)grad_output,
-                       grad_input, grad_offset, grad_mask, g, items);
+    if constexpr (OS3 != 0)
+        hipLaunchKernelGGL((dcnv3_bwd_input3x3_kernel<T, (OS3 ? OS3 : 1)>), dim3((unsigned)blocks), dim3(256), LDS, s, (const T*)offset, (const T*)mask, (const T*)grad_output, grad_input, g, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((dcnv3_bwd_input_kernel<T, R>), dim3((unsigned)blocks), dim3(256), LDS, s, (const T*)offset, (const T*)mask, (const T*)grad_output, grad_input, g, tiles_x, tiles_y);
+    hipLaunchKernelGGL((dcnv3_bwd_om_kernel<T, (OS3 ? 2 : 1)>), dim3((unsigned)((2 * items + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (const T*)grad_output,
+                       grad_input, grad_offset, grad_mask, g, items, R);
     return mtp_launch_status();
 }
 
@@ -480,8 +613,15 @@ int launch_bwd(const void* input, const void* offset, const void* mask, const vo
         aligned16(input) && aligned16(grad_output) && aligned16(grad_input) && (reinterpret_cast<uintptr_t>(grad_offset) & 7u) == 0) {
         const int tiles_x = (g.W + DT_TILE - 1) / DT_TILE, tiles_y = (g.H + DT_TILE - 1) / DT_TILE;
         const int64_t blocks = (int64_t)g.N * tiles_y * tiles_x * g.G;
-        if (blocks < ((int64_t)1 << 31)) return reach <= 2 ? launch_bwd_gather<T, 2>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s, tiles_x, tiles_y, blocks, items)
-                                                          : launch_bwd_gather<T, 3>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s, tiles_x, tiles_y, blocks, items);
+        if (blocks < ((int64_t)1 << 31) && 2 * items < ((int64_t)1 << 32) - 256) {
+#define MTP_DCN_GATHER(R_, OS3_) launch_bwd_gather<T, R_, OS3_>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s, tiles_x, tiles_y, blocks, items)
+            if (g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && !g.window_bwd) {
+                if (g.os == 1.0f) return MTP_DCN_GATHER(2, 1);
+                if (g.os == 2.0f) return MTP_DCN_GATHER(3, 2);
+            }
+            return reach <= 2 ? MTP_DCN_GATHER(2, 0) : MTP_DCN_GATHER(3, 0);
+#undef MTP_DCN_GATHER
+        }
     }
     hipError_t e = hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)g.N * g.H * g.W * g.G * g.GC, s);   // the reference's at::zeros_like (dcnv3_cuda.cu:131)
     if (e != hipSuccess) return (int)e;

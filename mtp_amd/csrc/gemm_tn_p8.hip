@@ -34,6 +34,8 @@ struct TnProb {
     int M, N, K;
     int lda, ldb, ldc;
     int tile0, tiles_m, tiles_n;
+    int splits;         // the contraction in `splits` pieces of `kchunk` rows (the last one shorter), each an own tile writing its own (M, ldc)
+    int kchunk;         //   f32 image at C + piece * M * ldc: few-tile problems with a long contraction (M, N <= 256, K = 131072: InternImage level 0)
     int pad_;
 };
 struct TnGroup {
@@ -45,7 +47,7 @@ struct T8Ctx {
     lds_char_t* smem;        // LDS base (the transpose reads go through the builtin: compiler-visible LDS loads)
     uint32_t offA[2][4];     // per-lane byte offset of fragment mi (k-step 0, rows 0-3) in buffer b
     uint32_t offB[2][2];
-    uint32_t voffA, voffB;   // per-lane DMA source offsets (row in piece, swizzled 16-B chunk, current k)
+    uint32_t voffA[2], voffB[2];   // per-lane DMA source offsets of half 0 / 1 (row in piece, swizzled 16-B chunk, current k)
     uint32_t kstepA, kstepB; // bytes per K-tile: 64 rows
     const char* pA[2][2];    // wave-uniform DMA source bases [half][piece]
     const char* pB[2][2];
@@ -87,9 +89,9 @@ struct TnOps {
         constexpr int h = (SK == KA1 || SK == KB1) ? 1 : 0;
         const uint32_t l0 = c.m0base + SBUF * P8_BUF + SK * P8_HALF;
         if constexpr (SK == KA0 || SK == KA1)
-            glds2(c.voffA, c.pA[h][0], c.pA[h][1], l0, l0 + 1024);
+            glds2(c.voffA[h], c.pA[h][0], c.pA[h][1], l0, l0 + 1024);
         else
-            glds2(c.voffB, c.pB[h][0], c.pB[h][1], l0, l0 + 1024);
+            glds2(c.voffB[h], c.pB[h][0], c.pB[h][1], l0, l0 + 1024);
     }
     // the fragment reads are compiler-visible LDS loads: the asm wait below (a memory barrier for the compiler) retires them
     // before the phase's barrier, which is what lets the slot be refilled one phase later (WAR rule of gemm_p8.hip)
@@ -110,8 +112,8 @@ struct TnOps {
     }
     static __device__ __forceinline__ void retire_b(u32x4_t (&)[2][2]) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     static __device__ __forceinline__ void next_ktile(Ctx& c) {
-        c.voffA += c.kstepA;
-        c.voffB += c.kstepB;
+        c.voffA[0] += c.kstepA; c.voffA[1] += c.kstepA;
+        c.voffB[0] += c.kstepB; c.voffB[1] += c.kstepB;
     }
 };
 
@@ -130,9 +132,11 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     while (pi + 1 < grp.nprob && vt >= grp.p[pi + 1].tile0) ++pi;
     const TnProb& q = grp.p[pi];
     int tm, tn;
-    tile_coords(vt - q.tile0, q.tiles_m, q.tiles_n, grp.plain, tm, tn);
+    const int per = q.tiles_m * q.tiles_n, piece = (vt - q.tile0) / per;
+    tile_coords(vt - q.tile0 - piece * per, q.tiles_m, q.tiles_n, grp.plain, tm, tn);
     const int m0 = tm * P8_BM, n0 = tn * P8_BN;
-    const int pairs = q.K >> 7;
+    const int k0 = piece * q.kchunk, klen = q.K - k0 < q.kchunk ? q.K - k0 : q.kchunk;
+    const int pairs = klen >> 7;
 
     T8Ctx c;
     c.smem = (lds_char_t*)smem;
@@ -156,16 +160,22 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // columns [128h, 128h + 128), of which wave row wr multiplies [64 wr, 64 wr + 64); B-half j likewise with 32 columns per
         // wave column.  (Splitting the wave's columns in two strips instead of splitting each strip's lines in two: measured
         // 871 us of a 1050-us launch were the DMA / read stream alone when B-half rows were 4 x 64-B pieces.)
-        c.voffA = (uint32_t)((lane >> 4) * q.lda * 2 + ch * 16);
-        c.voffB = (uint32_t)((lane >> 4) * q.ldb * 2 + ch * 16);
+        // Edge tiles (M, N multiples of 8, not of 256): a 16-byte chunk past the last column is fetched from the half's first column instead (a
+        // valid address; its products land in accumulators the epilogue never stores); a half that starts past the edge reads half 0's columns.
+        const int cbA[2] = {m0, m0 + 128 < q.M ? m0 + 128 : m0}, cbB[2] = {n0, n0 + 128 < q.N ? n0 + 128 : n0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            c.voffA[h] = (uint32_t)((lane >> 4) * q.lda * 2 + (cbA[h] + ch * 8 < q.M ? ch * 16 : 0));
+            c.voffB[h] = (uint32_t)((lane >> 4) * q.ldb * 2 + (cbB[h] + ch * 8 < q.N ? ch * 16 : 0));
+        }
         c.kstepA = (uint32_t)(64 * q.lda * 2);
         c.kstepB = (uint32_t)(64 * q.ldb * 2);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) {
-                c.pA[h][pc] = q.A + ((int64_t)(wave * 8 + pc * 4) * q.lda + m0 + h * 128) * 2;
-                c.pB[h][pc] = q.B + ((int64_t)(wave * 8 + pc * 4) * q.ldb + n0 + h * 128) * 2;
+                c.pA[h][pc] = q.A + ((int64_t)(k0 + wave * 8 + pc * 4) * q.lda + cbA[h]) * 2;
+                c.pB[h][pc] = q.B + ((int64_t)(k0 + wave * 8 + pc * 4) * q.ldb + cbB[h]) * 2;
             }
         c.colsum = q.colsum != nullptr && tn == 0;
         c.csoff = (uint32_t)((tid >> 4) * 256 + (tid & 15) * 16);
@@ -184,9 +194,9 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
     // ---- prologue: S_0 .. S_7 = B1 A0 B0 A1 of K-tile 0 (buffer 0), B0 A0 B1 A1 of K-tile 1 (buffer 1)
     TnOps::stage<KB1, 0>(c); TnOps::stage<KA0, 0>(c); TnOps::stage<KB0, 0>(c); TnOps::stage<KA1, 0>(c);
-    c.voffA += c.kstepA; c.voffB += c.kstepB;
+    TnOps::next_ktile(c);
     TnOps::stage<KB0, 1>(c); TnOps::stage<KA0, 1>(c); TnOps::stage<KB1, 1>(c); TnOps::stage<KA1, 1>(c);
-    c.voffA += c.kstepA; c.voffB += c.kstepB;
+    TnOps::next_ktile(c);
     wait_vm<12>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -222,13 +232,13 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             float s = 0.f;
 #pragma unroll 8
             for (int r = 0; r < 32; ++r) s += red[(h * 32 + r) * 128 + x];
-            atomicAdd(q.colsum + m0 + h * 128 + x, s);
+            if (m0 + h * 128 + x < q.M) atomicAdd(q.colsum + m0 + h * 128 + x, s);
         }
         __syncthreads();
     }
 
     KArgs o = {};
-    o.C = reinterpret_cast<char*>(q.C);
+    o.C = reinterpret_cast<char*>(q.C + (int64_t)piece * q.M * q.ldc);
     o.M = q.M; o.N = q.N; o.ldc = q.ldc;
     // accumulator rows 4i .. 4i+3 = tile rows 128 i + 64 wr + ..., accumulator columns 2j, 2j+1 = tile columns 128 j + 32 wc + ...
     epilogue_lds<float, MTP_EPI_BIAS, 128, 128>(o, acc, smem + wave * P8_HALF, m0 + wr * 64, n0 + wc * 32, lane);
@@ -236,32 +246,46 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
 }  // namespace
 
-// Every problem: bf16 operands, f32 output, M and N multiples of 256, contraction a multiple of 128, 16-byte aligned rows.
+// Every problem: bf16 operands, f32 output, M and N multiples of 8 (edge tiles of the 256 x 256 grid are clamped / masked), contraction a
+// multiple of 128, 16-byte aligned rows.  split_k > 1 with `aux` (f32, split_k * M * ldc elements): the contraction is cut into split_k pieces
+// (multiples of 128 rows), every (tile, piece) is an own workgroup writing its own image into aux, and -- unless defer_sum -- one
+// mtp_sum_partials_batch launch per 12 such problems adds the images up into C: for problems of a few tiles with a very long contraction.
 extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_stream_t stream) {
     if (!args || count <= 0) return MTP_ERR_ARG;
     if (count > TN_MAX_PROBLEMS) return MTP_ERR_UNSUPPORTED;
     TnGroup g = {};
-    int tiles = 0;
+    int64_t tiles = 0;
+    bool plain256 = true;
     for (int i = 0; i < count; ++i) {
         const mtp_gemm_args& a = args[i];
         if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return MTP_ERR_ARG;
         if (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15) return MTP_ERR_ARG;
         if (a.in_dtype != MTP_BF16 || a.out_dtype != MTP_F32) return MTP_ERR_UNSUPPORTED;
-        if ((a.M % P8_BM) || (a.N % P8_BN) || (a.K % 128) || (a.lda % 8) || (a.ldb % 8) || (a.ldc % 4)) return MTP_ERR_UNSUPPORTED;
+        if ((a.M % 8) || (a.N % 8) || (a.K % 128) || (a.lda % 8) || (a.ldb % 8) || (a.ldc % 4) || a.lda < a.M || a.ldb < a.N || a.ldc < a.N) return MTP_ERR_UNSUPPORTED;
         if ((uint64_t)a.K * (uint64_t)a.lda * 2 >= (1ull << 32) || (uint64_t)a.K * (uint64_t)a.ldb * 2 >= (1ull << 32)) return MTP_ERR_UNSUPPORTED;
+        int splits = a.split_k > 1 ? a.split_k : 1;
+        int64_t kchunk = a.K;
+        if (splits > 1) {
+            if (!a.aux || ((uintptr_t)a.aux & 15)) return MTP_ERR_ARG;
+            kchunk = ((a.K / 128 + splits - 1) / splits) * 128;
+            splits = (int)((a.K + kchunk - 1) / kchunk);
+        }
+        if ((a.M % P8_BM) || (a.N % P8_BN) || splits > 1) plain256 = false;
         TnProb& q = g.p[i];
-        q.A = (const char*)a.A; q.B = (const char*)a.B; q.C = (float*)a.C; q.colsum = a.colsum;
+        q.A = (const char*)a.A; q.B = (const char*)a.B; q.C = splits > 1 ? (float*)a.aux : (float*)a.C; q.colsum = a.colsum;
         q.M = (int)a.M; q.N = (int)a.N; q.K = (int)a.K;
         q.lda = (int)a.lda; q.ldb = (int)a.ldb; q.ldc = (int)a.ldc;
-        q.tiles_m = q.M / P8_BM; q.tiles_n = q.N / P8_BN;
-        q.tile0 = tiles;
-        tiles += q.tiles_m * q.tiles_n;
+        q.tiles_m = (int)((a.M + P8_BM - 1) / P8_BM); q.tiles_n = (int)((a.N + P8_BN - 1) / P8_BN);
+        q.splits = splits; q.kchunk = (int)kchunk;
+        q.tile0 = (int)tiles;
+        tiles += (int64_t)q.tiles_m * q.tiles_n * splits;
+        if (tiles >= (1 << 30)) return MTP_ERR_UNSUPPORTED;
     }
     g.nprob = count;
-    g.ntiles = tiles;
+    g.ntiles = (int)tiles;
     g.plain = (args[0].variant >> 1) & 1;
     // the 4-wave 32x32x16 form (gemm_tn_w4.hip): variant bit 5 of the first problem asks for it, bit 6 forbids it
-    if ((args[0].variant & 32) && !(args[0].variant & 64)) return mtp_gemm_tn_grouped_w4(args, count, (hipStream_t)stream);
+    if ((args[0].variant & 32) && !(args[0].variant & 64) && plain256) return mtp_gemm_tn_grouped_w4(args, count, (hipStream_t)stream);
     const int xp = (args[0].variant >> 11) & 15;   // ablation builds (tools/ab_wgrad.py): 2 = no stagger, 8 = no MFMAs
     void (*kern)(TnGroup) = xp == 2 ? gemm_tn_p8_kernel<2> : xp == 8 ? gemm_tn_p8_kernel<8> : gemm_tn_p8_kernel<0>;
     static bool attr[3] = {false, false, false};
@@ -271,6 +295,23 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
         if (e != hipSuccess) return (int)e;
         attr[ai] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);
-    return mtp_launch_status();
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);
+    int rc = mtp_launch_status();
+    // the split problems' images -> C
+    const float* parts[12];
+    float* outs[12];
+    int64_t numel[12];
+    int nsplit[12], n = 0;
+    for (int i = 0; i < count && rc == 0; ++i) {
+        if (g.p[i].splits > 1 && !args[i].defer_sum) {
+            if (args[i].ldc != args[i].N) return MTP_ERR_UNSUPPORTED;      // (the reduction treats an image as M * N contiguous floats)
+            parts[n] = (const float*)args[i].aux; outs[n] = (float*)args[i].C; numel[n] = args[i].M * args[i].N; nsplit[n] = g.p[i].splits;
+            ++n;
+        }
+        if (n == 12 || (n > 0 && i == count - 1)) {
+            rc = mtp_sum_partials_batch(parts, outs, numel, nsplit, n, stream);
+            n = 0;
+        }
+    }
+    return rc;
 }

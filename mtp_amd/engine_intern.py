@@ -108,11 +108,10 @@ class InternEngine:
         L = self._lin[wname]
         bname = wname[:-len("weight")] + "bias"
         if not L.padded:
-            ops.gemm_tn(dy, x, G[wname], colsum=G[bname])
+            self._wq.add(dy, x, G[wname], G[bname])
             return
         tw, tb = self._e(L.Rp, L.C, dtype=F32), torch.zeros(L.Rp, device=self.dev, dtype=F32)
-        ops.gemm_tn(dy, x, tw, colsum=tb)
-        ops.copy_segments([tw.view(-1)[:L.R * L.C], tb[:L.R]], [G[wname].view(-1), G[bname]])
+        self._wq.add(dy, x, tw, tb, after=lambda: ops.copy_segments([tw.view(-1)[:L.R * L.C], tb[:L.R]], [G[wname].view(-1), G[bname]]))
 
     def _ln(self, x, P, key, out_dtype=None, gelu=False):
         rows = x.shape[0]
@@ -141,8 +140,7 @@ class InternEngine:
         """dy (rows, Cout) ACT.  Weight (+ bias) gradient into G; dx (f32, strided) = / += data gradient when dx is not None"""
         w2, w2t = self._conv[name]
         dw2 = self._e(*w2.shape, dtype=F32)
-        ops.gemm_tn(dy, cols, dw2, colsum=(G[bias_name] if bias_name else None))
-        ops.conv3x3_unpack_grad(dw2, G[name])
+        self._wq.add(dy, cols, dw2, (G[bias_name] if bias_name else None), after=lambda: ops.conv3x3_unpack_grad(dw2, G[name]))
         if dx is not None:
             dcols = ops.gemm_nt(dy, w2t, self._e(dy.shape[0], w2.shape[1]))
             ops.col2im3x3(dcols, dx, strides, N, H, W, Cin, stride, accumulate=accumulate)
@@ -321,9 +319,9 @@ class InternEngine:
             for j in range(len(lv["layers"]) - 1, -1, -1):
                 dx32 = self._layer_bwd("levels.%d.blocks.%d." % (i, j), lv["layers"][j], dx32, N, Hc, Wc, C, Gr, G)
                 lv["layers"][j] = None
-                # the Linear weight gradients whose shapes the grouped TN kernel takes (multiples of 256: the 768- and 1536-channel levels)
-                # are queued and launched a few layers at a time (ops.WgradQueue); the layer is reported once they are out
-                # (levels whose shapes are not queued -- 192 / 384 channels -- have launched everything already: report layer by layer)
+                # the weight gradients are queued and launched a few layers at a time (ops.WgradQueue: edge tiles for the 192- / 384-channel
+                # levels and the offset / mask heads, the contraction of the 131072- / 32768-token levels cut into pieces inside the launch);
+                # the layer is reported once they are out
                 if j == 0 or self._wq.should_flush() or not self._wq.jobs:
                     self._wq.flush()
                     if on_block_done is not None:
@@ -338,6 +336,7 @@ class InternEngine:
         dy1 = self._ln_bwd(self._to_act(da1), y1, sm1, sr1, P, G, "patch_embed.norm1.1", gelu=True)
         dimg = self._e(N, Cin, H, W, dtype=F32) if need_input_grad else None
         self._conv_bwd(dy1, cols1, "patch_embed.conv1.weight", G, "patch_embed.conv1.bias", dimg, (Cin * H * W, W, 1, H * W), N, H, W, Cin, 2)
+        self._wq.flush()      # the stem's two weight gradients
         if on_block_done is not None:
             on_block_done(-1)
         return dimg

@@ -173,16 +173,25 @@ _NO_GROUPED = bool(int(__import__("os").environ.get("MTP_NO_GROUPED_WGRAD", "0")
 
 
 def grouped_tiles(M, N):
-    """256 x 256 output tiles of one problem in mtp_gemm_tn_grouped, or 0 when it cannot take the problem"""
-    return (M // 256) * (N // 256) if M % 256 == 0 and N % 256 == 0 else 0
+    """256 x 256 output tiles (edge tiles included) of one problem in mtp_gemm_tn_grouped, or 0 when it cannot take the problem"""
+    return -(-M // 256) * -(-N // 256) if M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 else 0
+
+
+def grouped_splits(K, tiles):
+    """pieces of the contraction for a problem of `tiles` output tiles: 1 unless the problem is a few tiles with a very long contraction
+    (InternImage's 192- / 384-channel levels: M, N <= 1536 over 131072 / 32768 tokens), then pieces of ~4096 rows, each an own workgroup"""
+    if K < 16384 or tiles > 16:
+        return 1
+    return max(1, min(64, K // 4096))
 
 
 class WgradQueue:
     """Deferred weight gradients dW = dY^T X (+ bias gradient = column sums of dY): the weight gradients of a transformer block
     depend only on tensors the backward pass has anyway, so they are collected and launched together -- ONE
     mtp_gemm_tn_grouped launch whose 256 x 256 tiles fill the 256 CUs in whole rounds (4 ViT-L blocks = 768 tiles = 3 rounds),
-    each tile with the full contraction: no split-K partials, no reduction launches.  Problems the grouped kernel cannot take
-    (f32 parity mode, sizes that are not multiples of 256 / 128) run immediately through gemm_tn."""
+    each tile with the full contraction: no split-K partials, no reduction launches.  Problems of a few tiles with a very long
+    contraction are cut into pieces inside the same launch (grouped_splits; the kernel's own split_k + one reduction launch).  Problems
+    the grouped kernel cannot take (f32 parity mode, sizes that are not multiples of 8 / 128) run immediately through gemm_tn."""
 
     def __init__(self, cus=256, variant=0, stream=None):
         self.jobs, self.tiles, self.cus, self.variant = [], 0, cus, variant or _TN_DEFAULT
@@ -191,20 +200,28 @@ class WgradQueue:
         # round) their tiles fill the idle CUs.  flush() orders the launch after everything issued so far; wait() orders the
         # current stream after the launches (call it before the gradients are consumed).
         self.stream, self.inflight = stream, []
+        self.after = []      # callables run right after the launch (on its stream): e.g. copying a padded result into the gradient buffer
 
-    def add(self, dy, x, dw, colsum=None):
+    def add(self, dy, x, dw, colsum=None, after=None):
         K, M = dy.shape
         N = x.shape[1]
         t = grouped_tiles(M, N)
         # the grouped kernel's own limits (gemm_tn_p8.hip: 32-bit DMA offsets -> K * ld * 2 < 4 GiB per operand; 16-byte aligned bases):
         # a problem outside them runs now through gemm_tn instead of failing the whole deferred launch several blocks later
-        fits = (K * M * 2 < (1 << 32) and K * N * 2 < (1 << 32) and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0)
+        fits = (K * M * 2 < (1 << 32) and K * N * 2 < (1 << 32) and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
+                and dy.is_contiguous() and x.is_contiguous())
         if _NO_GROUPED or t == 0 or K % 128 or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not fits:
             gemm_tn(dy, x, dw, colsum=colsum)
+            if after is not None:
+                after()
             return False
         assert x.shape[0] == K and dw.dtype == torch.float32 and dw.numel() == M * N and dw.is_contiguous()
-        self.jobs.append((dy, x, dw, colsum))     # (the references keep dY / X alive until the launch)
-        self.tiles += t
+        splits = grouped_splits(K, t)
+        part = torch.empty(splits, M, N, device=dw.device, dtype=torch.float32) if splits > 1 else None
+        self.jobs.append((dy, x, dw, colsum, splits, part))     # (the references keep dY / X / the partial images alive until the launch)
+        if after is not None:
+            self.after.append(after)
+        self.tiles += t * splits
         return True
 
     def should_flush(self, next_tiles=0, next_jobs=4):
@@ -221,7 +238,7 @@ class WgradQueue:
             return self._launch()
         ready = torch.cuda.Event()
         ready.record()
-        held = list(self.jobs)           # dY / X stay referenced until the current stream has waited for the launch
+        held = list(self.jobs)           # dY / X / partial images stay referenced until the current stream has waited for the launch
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
             self._launch()
@@ -239,17 +256,22 @@ class WgradQueue:
         while self.jobs:
             chunk, self.jobs = self.jobs[:MAX_GROUPED], self.jobs[MAX_GROUPED:]
             arr = (GemmArgs * len(chunk))()
-            for g, (dy, x, dw, cs) in zip(arr, chunk):
+            for g, (dy, x, dw, cs, splits, part) in zip(arr, chunk):
                 K, M = dy.shape
                 N = x.shape[1]
                 g.A, g.B, g.C = _p(dy), _p(x), _p(dw)
                 g.M, g.N, g.K = M, N, K
                 g.lda, g.ldb, g.ldc = M, N, N
                 g.in_dtype, g.out_dtype, g.variant = MTP_BF16, MTP_F32, self.variant
+                if splits > 1:
+                    g.split_k, g.aux = splits, _p(part)
                 if cs is not None:
                     assert cs.dtype == torch.float32 and cs.numel() == M and cs.is_contiguous()
                     g.colsum = _p(cs)
             check(lib().mtp_gemm_tn_grouped(arr, len(chunk), _s()), "mtp_gemm_tn_grouped")
+        after, self.after = self.after, []
+        for fn in after:
+            fn()
         self.tiles = 0
 
 

@@ -290,6 +290,24 @@ def test_gemm_tn_grouped_vs_oracle(ops, shapes, variant):
             assert rel_err(cs.cpu(), cs0 + a.sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("shapes", [
+    [(256, 192, 192, True)],                                                                   # one edge tile (InternImage level 0: 192 channels)
+    [(384, 216, 192, True), (384, 112, 192, True), (256, 768, 192, False), (256, 192, 768, True)],   # offset / mask heads, fc1 / fc2 of that level
+    [(512, 96, 32, True), (256, 8, 8, True), (128, 264, 520, True)],                           # narrower than one half tile; 1-chunk problem; tiles 2 x 3 with both edges
+    [(16384, 192, 192, True), (16384, 384, 216, True), (32768, 96, 32, False)],                # long contractions: cut into pieces inside the launch
+    [(16384 + 128, 192, 384, True)]])                                                          # ... whose last piece is shorter
+def test_gemm_tn_grouped_edge_tiles_and_pieces(ops, shapes):
+    """sizes off the 256 grid (multiples of 8: the last tile row / column is clamped on the way in and masked on the way out) and few-tile
+    problems with a long contraction (ops.grouped_splits: pieces of ~4096 rows, each an own workgroup, summed by one reduction launch)"""
+    q, refs = _wgrad_group(ops, shapes)
+    assert any(j[4] > 1 for j in q.jobs) == (shapes[0][0] >= 16384)
+    q.flush()
+    for a, b, cs0, dw, cs in refs:
+        assert rel_err(dw.cpu(), a.float().t() @ b.float()) < 3e-4
+        if cs is not None:
+            assert rel_err(cs.cpu(), cs0 + a.float().sum(0)) < 1e-4
+
+
 @pytest.mark.parametrize("variant", [0, 32])
 def test_gemm_tn_grouped_vit_l_block_repeatable(ops, variant):
     """the four weight gradients of a ViT-L block at the training size (T = 12544 tokens, 192 tiles, 98 K-tile pairs each) against
@@ -325,7 +343,7 @@ def test_gemm_tn_grouped_vit_l_block_repeatable(ops, variant):
 
 
 def test_wgrad_queue_falls_back_for_other_problems(ops):
-    """f32 parity mode and sizes off the 256 / 128 grid do not queue: they run at once through mtp_gemm_tn"""
+    """f32 parity mode and sizes off the 8 / 128 grid do not queue: they run at once through mtp_gemm_tn"""
     q = ops.WgradQueue()
     a, b = rnd(392, 384, scale=0.5), rnd(392, 128, scale=0.5, seed=1)
     dw = e(384, 128)

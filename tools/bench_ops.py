@@ -122,7 +122,7 @@ def main():
                     off = ((torch.rand(N, HW, HW, M * 18, device=dev) - 0.5) * amp).to(dt)
                     t = timeit(lambda: dcnv3_forward(x, off, m, *a, 256, 0), iters=10)
                     cells = ["fwd %.1f us %.0f GB/s" % (t * 1e6, fb / t / 1e9)]
-                    for name, var in (("bwd", "0"), ("bwd-scatter", "2")):
+                    for name, var in (("bwd", "0"), ("bwd-window", "4"), ("bwd-scatter", "2")):
                         os.environ["MTP_DCNV3_VARIANT"] = var
                         t = timeit(lambda: dcnv3_backward(x, off, m, *a, G, 256, 0), iters=10)
                         cells.append("%s %.1f us %.0f GB/s" % (name, t * 1e6, bb / t / 1e9))

@@ -15,8 +15,20 @@ import sys
 
 FAMILIES = [("gemm_nt", "gemm_nt_kernel"), ("gemm_tn_p8", "gemm_tn_kernel"), ("gemm_tn", "gemm_tn_split_kernel"), ("sum_partials", "sum_partials"), ("ln_fwd", "ln_fwd_kernel"),
             ("ln_bwd", "ln_bwd_kernel"), ("rvsa_bwd4", "rvsa_bwd4"), ("rvsa_fwd4", "rvsa_fwd4"), ("full_bwd_a", "full_bwd_a"),
-            ("full_bwd_b", "full_bwd_b"), ("full_fwd", "full_fwd"), ("adamw", "adamw"), ("weight_images", "weight_images"),
+            ("full_bwd_b", "full_bwd_b"), ("full_fwd", "full_fwd"), ("v3_bwd_a", "full_v3_bwd_a"), ("v3_bwd_b", "full_v3_bwd_b"), ("v3_fwd", "full_v3_fwd"), ("adamw", "adamw"), ("weight_images", "weight_images"),
             ("reduce_rows", "reduce_rows"), ("colsum", "colsum"), ("dkv_convert", "dkv_convert"), ("small_linear", "small_linear")]
+
+
+def csrc_sha():
+    """hash of the kernel sources (mtp_amd/csrc/*.hip, *.h): bench.py quotes a PMC file only when this matches the running tree"""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "mtp_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "mtp_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def collect(path, counter):
@@ -40,7 +52,7 @@ def main():
         commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).decode().strip()
     except Exception:
         commit = os.environ.get("MTP_COMMIT", "?")
-    out = {"_commit": commit, "_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of `bench.py --steps 1 --warmup 1` (ViT-L, B=64, bf16, "
+    out = {"_commit": commit, "_csrc_sha": csrc_sha(), "_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of `bench.py --steps 1 --warmup 1` (ViT-L, B=64, bf16, "
                     "1x MI355X); per-launch averages in KB as reported; hbm_bytes_per_launch applies the gfx950 correction of "
                     "MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request: x2) : (2*FETCH + WRITE) * 1024  [tools/pmc_hbm.py]"}
     for k in sorted(set(fetch) | set(write)):
