@@ -375,6 +375,12 @@ class BackboneEngine:
             fctx = dict(t0=t0, y1=y1, mean=mean, rstd=rstd, g1=g1, t1=t1, tap3=taps[3])
         return feats, fctx
 
+    def _convt_wgrad(self, dy, x, gw):
+        """weight gradient of a 2x2 / stride-2 ConvTranspose2d as the GEMM dy (rows, 4 C_out)^T x (rows, C_in), queued with the blocks'
+        weight gradients; the (4 C_out, C_in) image is re-laid into the parameter's (C_in, C_out, 2, 2) right after the launch"""
+        dwg = self._e(dy.shape[1], x.shape[1], dtype=F32)
+        self._wq.add(dy, x, dwg, after=lambda: ops.convt_unpack_grad(dwg, gw))
+
     def _fpn_bwd(self, dfeats, fctx, B, Hp, Wp, G):
         """returns [dtap0..dtap3] (f32 (T,C) each, or None when the feature received no gradient)."""
         P, C, T, act = self.P, self.C, B * Hp * Wp, self.act
@@ -386,23 +392,18 @@ class BackboneEngine:
 
         if dfeats[0] is not None:
             dy2 = ops.nchw_to_tokens(as_in(dfeats[0]), self._e(16 * T, C), B, Hp, Wp, 2)
-            dwg = self._e(4 * C, C, dtype=F32)
-            ops.gemm_tn(dy2.view(4 * T, 4 * C), fctx["g1"], dwg)
-            ops.convt_unpack_grad(dwg, G["fpn1.3.weight"])
+            self._convt_wgrad(dy2.view(4 * T, 4 * C), fctx["g1"], G["fpn1.3.weight"])
             self._colsum(dy2, G["fpn1.3.bias"])
             dg1 = ops.gemm_nt(dy2.view(4 * T, 4 * C), self._fpn["fpn1.3"][1], self._e(4 * T, C))
             dy1 = self._e(4 * T, C)
             self._ln_bwd(dg1, fctx["y1"].view(4 * T, C), fctx["mean"], fctx["rstd"], P["fpn1.1.ln.weight"], dy1,
                               G["fpn1.1.ln.weight"], G["fpn1.1.ln.bias"], beta=P["fpn1.1.ln.bias"], gelu=True)
-            ops.gemm_tn(dy1.view(T, 4 * C), fctx["t0"], dwg)
-            ops.convt_unpack_grad(dwg, G["fpn1.0.weight"])
+            self._convt_wgrad(dy1.view(T, 4 * C), fctx["t0"], G["fpn1.0.weight"])
             self._colsum(dy1, G["fpn1.0.bias"])
             out[0] = ops.gemm_nt(dy1.view(T, 4 * C), self._fpn["fpn1.0"][1], self._e(T, C, dtype=F32))
         if dfeats[1] is not None:
             dz = ops.nchw_to_tokens(as_in(dfeats[1]), self._e(4 * T, C), B, Hp, Wp, 1)
-            dwg = self._e(4 * C, C, dtype=F32)
-            ops.gemm_tn(dz.view(T, 4 * C), fctx["t1"], dwg)
-            ops.convt_unpack_grad(dwg, G["fpn2.0.weight"])
+            self._convt_wgrad(dz.view(T, 4 * C), fctx["t1"], G["fpn2.0.weight"])
             self._colsum(dz, G["fpn2.0.bias"])
             out[1] = ops.gemm_nt(dz.view(T, 4 * C), self._fpn["fpn2.0"][1], self._e(T, C, dtype=F32))
         if dfeats[2] is not None:
@@ -428,6 +429,8 @@ class BackboneEngine:
         P = self.P
         self.dev = ctx["cols"].device
         self._ln_parts = []
+        # weight gradients (FPN deconvolutions, the blocks' Linears, patch embed) are queued and launched in bursts (ops.WgradQueue)
+        self._wq = wq = ops.WgradQueue(stream=self._wgrad_stream())
         if ctx["fctx"].get("taps_only"):
             dtaps = [None if d is None else ops.nchw_to_tokens((d.contiguous() if d.dtype in (F32, torch.bfloat16) else d.float().contiguous()),
                                                                self._e(T, C, dtype=F32), B, Hp, Wp, 0) for d in dfeats]
@@ -458,14 +461,14 @@ class BackboneEngine:
                 else:
                     tapgrad[idx] = d
         self._ln_flush()
-        if on_block_done is not None:
-            on_block_done(self.depth)          # FPN (and final-norm) parameter gradients are complete on the stream
+        if on_block_done is not None and not wq.jobs:
+            on_block_done(self.depth)          # FPN (and final-norm) parameter gradients are complete on the stream (queued FPN weight
+                                               # gradients go out with the first burst of blocks, whose report covers them)
         if last not in tapgrad:
             tapgrad[last] = torch.zeros(T, C, device=self.dev, dtype=F32)
         dx = tapgrad[last]
         # ACT copy of the output gradient of the last block, scaled by its mlp drop-path factor
         dx_act = self._scaled_copy(dx, dps[last][1], N)
-        self._wq = wq = ops.WgradQueue(stream=self._wgrad_stream())
         waiting = []     # blocks whose weight gradients are still queued: on_block_done fires once they have been launched
         pending = None   # side-stream mode: the burst launched last (reported once the NEXT burst has been launched, after a wait)
         for i in range(last, -1, -1):
@@ -477,6 +480,8 @@ class BackboneEngine:
             dx, dx_act = self._block_bwd(i, s, dx, dx_act, B, Hp, Wp, dps[i], G, extra, prev_scale)
             saved[i] = None
             waiting.append(i)
+            if i == 0:      # the patch-embed weight gradient rides in the last burst (its input gradient is block 0's dx)
+                wq.add(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1), G["patch_embed.proj.bias"])
             # nothing queued (every weight gradient of the burst is already on the stream): report block by block -- the reducer
             # cuts its buckets by size, and a single report at the end would leave no backward to overlap the exchange with
             if i == 0 or wq.should_flush() or not wq.jobs or (split_last and i == 1):
@@ -494,8 +499,7 @@ class BackboneEngine:
         wq.wait()
         if pending is not None and on_block_done is not None:
             on_block_done(pending)
-        # ---- patch embed / pos embed
-        ops.gemm_tn(dx_act, ctx["cols"], G["patch_embed.proj.weight"].view(C, -1), colsum=G["patch_embed.proj.bias"])
+        # ---- pos embed (the patch-embed weight gradient went out with block 0's)
         if "pos_embed" in G:
             ops.reduce_rows(dx.view(B, N * C), G["pos_embed"])
         dimg = None

@@ -178,11 +178,12 @@ def grouped_tiles(M, N):
 
 
 def grouped_splits(K, tiles):
-    """pieces of the contraction for a problem of `tiles` output tiles: 1 unless the problem is a few tiles with a very long contraction
-    (InternImage's 192- / 384-channel levels: M, N <= 1536 over 131072 / 32768 tokens), then pieces of ~4096 rows, each an own workgroup"""
-    if K < 16384 or tiles > 16:
+    """pieces of the contraction for a problem of `tiles` output tiles: 1 unless the contraction is much longer than a transformer block's
+    (InternImage's 192- / 384-channel levels: M, N <= 1536 over 131072 / 32768 tokens; the ViT FPN's second deconvolution: 64 tiles over
+    4 x the tokens) -- then pieces of >= 4096 rows, at most enough of them for one round of the 256 CUs, each piece an own workgroup"""
+    if K < 16384:
         return 1
-    return max(1, min(64, K // 4096))
+    return max(1, min(64, K // 4096, 256 // tiles))
 
 
 class WgradQueue:
