@@ -453,6 +453,45 @@ def test_448_pretraining_resolution_forward_and_gradients_vs_oracle():
             assert rel_err(q.grad.cpu(), p[n].grad) < 5e-3, n
 
 
+def test_non_square_input_taller_rel_pos_table_through_autograd_and_trainer():
+    """224 x 160 input -> 14 x 10 token grid: the reference sizes BOTH full-attention tables from patch_shape[0] (VIT:81-84), so rel_pos_w has 27
+    rows of which the 10-column grid uses 19.  Both backward paths -- the autograd Function with separately allocated gradients and
+    the trainer's flat buffer -- must write rows [0, 19) only and agree with the oracle; the unused rows stay exactly zero."""
+    from mtp_amd.parallel import DataParallelTrainer
+    kw = dict(img_size=(224, 160), embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True, out_indices=[0, 1, 2, 3])
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(precision="fp32", feature_dtype=torch.float32, drop_path_rate=0.0, **kw)
+    sd = recipe.make_params({k: v.shape for k, v in net.state_dict().items() if v.dtype.is_floating_point}, seed=31)
+    net.load_state_dict(sd, strict=False)
+    assert tuple(net.state_dict()["blocks.1.attn.full_attn_rel_pos_w"].shape) == (27, 64)
+    net = net.cuda().train()
+    img = recipe.make_input(1, 224, 160, seed=9)
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in net.state_dict().items()}
+    ref = O.backbone_forward(img, p, 4, 2, 2, [0, 1, 2, 3])
+    ws = [recipe.loss_weights(f.shape, 700 + i) for i, f in enumerate(ref)]
+    sum((f * w).sum() for f, w in zip(ref, ws)).backward()
+    # ---- autograd path
+    feats = net(img.cuda())
+    for a, b in zip(feats, ref):
+        assert rel_err(a.cpu(), b) < 1e-3
+    sum((f * w.cuda()).sum() for f, w in zip(feats, ws)).backward()
+    for n, q in net.named_parameters():
+        if p[n].grad is not None:
+            assert rel_err(q.grad.cpu(), p[n].grad) < 5e-3, n
+    for blk in (1, 3):
+        g = dict(net.named_parameters())["blocks.%d.attn.full_attn_rel_pos_w" % blk].grad
+        assert float(g[19:].abs().max()) == 0.0 and float(g[:19].abs().max()) > 0
+    # ---- trainer path (flat gradient buffer: a write past row 18 would land in the next parameter's gradient)
+    tr = DataParallelTrainer(net, total_steps=10)
+
+    def loss_and_grads(fs):
+        return sum((f * w.cuda()).sum() for f, w in zip(fs, ws)), [w.cuda().to(f.dtype) for f, w in zip(fs, ws)]
+    tr.flat.grad.zero_()
+    tr.step(img.cuda(), loss_and_grads)
+    for n in ("blocks.1.attn.full_attn_rel_pos_w", "blocks.1.attn.full_attn_rel_pos_h", "blocks.3.attn.full_attn_rel_pos_w", "blocks.1.attn.qkv.weight", "fpn1.0.weight"):
+        assert rel_err(tr.flat.G[n].cpu(), p[n].grad) < 5e-3, n
+    assert float(tr.flat.G["blocks.1.attn.full_attn_rel_pos_w"][19:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("size", [448, 1024])
 def test_large_inputs_bf16_flash_attention_path_vs_oracle(size):
     """bf16 mode at 448^2 (784 tokens per image: MTP's pretraining resolution) and 1024^2 (4096 tokens: the detection fine-tunes'
