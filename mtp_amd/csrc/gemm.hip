@@ -639,11 +639,14 @@ int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k) {
     if (a->in_dtype != MTP_BF16 || (a->variant & 1024) || !mtp_nt_p8_fits(k, a->out_dtype, a->epilogue)) return 0;
     const int forced = (a->variant >> 8) & 3;
     if (forced) return forced;
-    // default: the pipelined kernel once its 256-wide tiles occupy most of the 256 CUs (one workgroup per CU); below that the
+    // default: the pipelined kernel once its 256-wide tiles occupy a good part of the 256 CUs (one workgroup per CU); below that the
     // 128-wide kernels with 4 workgroups per CU spread a small problem better.  Measured on the ViT-L shapes (tools/ab_gemm.py):
-    // +15 % (N = 3072 / 4096, K = 1024) ... +25 % (N = 1024, K = 3072 / 4096), +23 % on the FPN GEMM.
+    // +15 % (N = 3072 / 4096, K = 1024) ... +25 % (N = 1024, K = 3072 / 4096), +23 % on the FPN GEMM; on the mid-size shapes of
+    // InternImage-XL's 768- / 1536-channel levels and of ViT-B at batch 32 (tools/ab_gemm_mid.py, round 3): 96 tiles +6 % (K = 768) /
+    // +17 % (K = 3072), 75 tiles +3 % / +16 %, 48 tiles +5 % (K = 1536) / +14 % (K = 6144), but 64 tiles of which half are mostly edge
+    // (N = 432, K = 768) -19 %: from 72 tiles on, or from 40 when the contraction is long.
     const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
-    return tiles >= 160 ? 1 : 0;
+    return (tiles >= 72 || (tiles >= 40 && a->K >= 1536)) ? 1 : 0;
 }
 
 template <typename T, typename Tout, int EPI>

@@ -16,6 +16,7 @@ allocates buffers and draws the drop-path masks.
 import torch
 
 from . import ops
+from .engine import _DEFER_LN
 from .ops_dcnv3 import functions as dcn
 
 F32 = torch.float32
@@ -122,9 +123,15 @@ class InternEngine:
 
     def _ln_bwd(self, dy, x, mean, rstd, P, G, key, gelu=False):
         dx = self._e(*x.shape, dtype=x.dtype)
+        # the dgamma / dbeta partial rows wait in self._ln_parts and are reduced together with the next weight-gradient burst (_ln_flush):
+        # three LayerNorms per layer were 240 reduction launches per InternImage-XL step
         ops.layernorm_bwd(dy, x, mean, rstd, P[key + ".weight"], dx, G[key + ".weight"], G[key + ".bias"],
-                          beta=P[key + ".bias"] if gelu else None, gelu=gelu, accumulate=True)
+                          beta=P[key + ".bias"] if gelu else None, gelu=gelu, accumulate=True, defer=(self._ln_parts if _DEFER_LN else None))
         return dx
+
+    def _ln_flush(self):
+        if self._ln_parts:
+            ops.reduce_rows_deferred(self._ln_parts)
 
     def _to_act(self, t):
         return t if t.dtype == self.act else ops.cast(t, self._e(*t.shape))
@@ -291,6 +298,7 @@ class InternEngine:
         img, cols1, y1, sm1, sr1, a1, cols2, y2, sm2, sr2, (N, Cin, H, W, H1, W1, H2, W2) = ctx["stem"]
         self.dev = cols1.device
         self._wq = ops.WgradQueue()
+        self._ln_parts = []
         taps = {}
         for idx, d in zip([i for i in range(len(m.depths)) if i in m.out_indices], dfeats):
             taps[idx] = d
@@ -324,6 +332,7 @@ class InternEngine:
                 # the layer is reported once they are out
                 if j == 0 or self._wq.should_flush() or not self._wq.jobs:
                     self._wq.flush()
+                    self._ln_flush()
                     if on_block_done is not None:
                         on_block_done(sum(m.depths[:i]) + j)
         if dx32 is None:
@@ -337,6 +346,7 @@ class InternEngine:
         dimg = self._e(N, Cin, H, W, dtype=F32) if need_input_grad else None
         self._conv_bwd(dy1, cols1, "patch_embed.conv1.weight", G, "patch_embed.conv1.bias", dimg, (Cin * H * W, W, 1, H * W), N, H, W, Cin, 2)
         self._wq.flush()      # the stem's two weight gradients
+        self._ln_flush()
         if on_block_done is not None:
             on_block_done(-1)
         return dimg

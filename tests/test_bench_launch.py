@@ -51,3 +51,41 @@ def test_world_size_mismatch_is_reported_as_json():
     assert rc != 0
     out = json.loads(lines[-1])
     assert out["value"] is None and "WORLD_SIZE" in out["error"]
+
+
+def test_traffic_is_quoted_only_for_matching_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from the committed PMC passes -- and only while the hash of mtp_amd/csrc recorded in that file equals the tree's
+    (VERDICT r02 #7): another hash -> None plus the reason in traffic_source"""
+    import json
+    import bench
+    from tools.pmc_hbm import csrc_sha
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench._traffic_from_profiles("gemm_nt") == (None, None)                       # no file at all
+    (prof / "r07_pmc_hbm.json").write_text(json.dumps({"_commit": "abc", "_csrc_sha": "0" * 16, "gemm_nt_kernel": {"hbm_bytes_per_launch": 123}}))
+    val, why = bench._traffic_from_profiles("gemm_nt")
+    assert val is None and "other kernel sources" in why
+    (prof / "r08_pmc_hbm.json").write_text(json.dumps({"_commit": "def", "_csrc_sha": csrc_sha(), "gemm_nt_kernel": {"hbm_bytes_per_launch": 456}}))
+    val, why = bench._traffic_from_profiles("gemm_nt")                                   # the newest file, matching hash
+    assert val == 456 and "r08_pmc_hbm.json" in why and "def" in why
+
+
+def test_clock_sampler_without_a_device_reports_nothing(monkeypatch):
+    import glob
+    import bench
+    monkeypatch.setattr(glob, "glob", lambda pattern: [])
+    s = bench.ClockSampler(0)
+    s.start()
+    assert s.stop() is None
+
+
+def test_grouped_weight_gradient_planning():
+    """tiles and pieces of the grouped weight-gradient launches (host side of mtp_gemm_tn_grouped)"""
+    from mtp_amd import ops
+    assert ops.grouped_tiles(1024, 4096) == 64 and ops.grouped_tiles(192, 192) == 1 and ops.grouped_tiles(264, 520) == 6
+    assert ops.grouped_tiles(108, 192) == 0 and ops.grouped_tiles(4, 256) == 0                 # not multiples of 8: the split-K kernel
+    assert ops.grouped_splits(12544, 48) == 1 and ops.grouped_splits(8192, 9) == 1             # a transformer block's / InternImage level 2's problems: whole contraction
+    assert ops.grouped_splits(50176, 64) == 4                                                    # ViT FPN, second deconvolution: 4 x 64 tiles = one round
+    assert ops.grouped_splits(131072, 1) == 32 and ops.grouped_splits(32768, 4) == 8           # InternImage levels 0 / 1
+    assert ops.grouped_splits(524288, 1) == 64                                                   # the stem: capped
