@@ -20,7 +20,7 @@ struct DcnGeom {
     float os;
     int xcd_order;   // 1: each of the 8 XCDs takes a contiguous range of workgroups (= of pixels), see block_index()
     int scatter_bwd; // 1: always the per-corner atomic scatter backward (A/B, variant bit 1)
-    int window_bwd;  // 1: the window form of the gather backward also where the 3 x 3 form applies (A/B, variant bit 2)
+    int form3x3_bwd; // 1: the 3 x 3 form of the gather backward where it applies (variant bit 2): faster while offsets stay below a pixel, slower beyond
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring pixels gather from / scatter into the
@@ -207,10 +207,10 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ in
 // S does not depend on the channel: one lane = one INPUT pixel of one group (16 f32 accumulators) walks the (2R+1)^2 output pixels
 // around it, computes S from the sample locations staged once per workgroup in LDS, and adds S * grad_out[o][0..15] -- plain
 // stores, no atomics, no zero-fill (the scatter form: 36 f32 atomics per element = 67 % of the old kernel).
-// A sample whose weighted corners are not all within R pixels of its own output pixel ("far") is left out here (its mask entry is
-// staged as 0) and scattered with atomics by the offset / mask kernel below, which decides with the same predicate: together
-// every sample is counted exactly once.  R = ceil(half kernel span * offset_scale) + 1, i.e. offsets up to one pixel outwards
-// stay on the fast path (3 for InternImage's 3 x 3, offset_scale 2).
+// A lane looks at the output pixels within R of its own pixel, so exactly those corners of a sample are counted here that lie within R pixels
+// (per axis) of the sample's own output pixel; the corners beyond that reach are scattered with atomics by the offset / mask kernel below,
+// which applies the complementary test per corner: together every corner is counted exactly once.  R = ceil(half kernel span *
+// offset_scale) + 1, i.e. offsets up to one pixel outwards stay entirely on the fast path (3 for InternImage's 3 x 3, offset_scale 2).
 constexpr int DT_TILE = 16;   // input tile edge: 256 lanes = 16 x 16 pixels of one group
 
 template <typename T>
@@ -221,19 +221,6 @@ struct DtLds {   // per window pixel: loc_w[9] | loc_h[9] | mask'[9] | pad (28 f
 __device__ __forceinline__ bool sample_valid(const DcnGeom& g, float loc_h, float loc_w) {
     return loc_h > -1.f && loc_w > -1.f && loc_h < (float)g.H && loc_w < (float)g.W;
 }
-// (valid samples only) every corner that carries weight lies within R pixels of the output pixel (ho, wo)
-__device__ __forceinline__ bool sample_near(float loc_h, float loc_w, int ho, int wo, int R) {
-    const float fh = floorf(loc_h), fw = floorf(loc_w);
-    const int h0 = (int)fh, w0 = (int)fw;
-    const int h1 = h0 + (loc_h > fh ? 1 : 0), w1 = w0 + (loc_w > fw ? 1 : 0);
-    return h0 >= ho - R && h1 <= ho + R && w0 >= wo - R && w1 <= wo + R;
-}
-
-// (3 x 3 points, dilation 1, integer offset_scale) the sample lies within one pixel of its nominal position (nh, nw)
-__device__ __forceinline__ bool sample_near3x3(float loc_h, float loc_w, int nh, int nw) {
-    return fabsf(loc_h - (float)nh) < 1.f && fabsf(loc_w - (float)nw) < 1.f;
-}
-
 template <typename T, int R>
 __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input_kernel(const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
                                                                  float* __restrict__ grad_input, DcnGeom g, int tiles_x, int tiles_y) {
@@ -267,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input_kernel(const T* __rest
                 if (g.remove_center && i == cw && j == chh) continue;
                 const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
                 const float loc_h = p0h + ((float)(j * g.dh) + oh) * g.os, loc_w = p0w + ((float)(i * g.dw) + ow) * g.os;
-                const bool take = inmap && sample_valid(g, loc_h, loc_w) && sample_near(fminf(fmaxf(loc_h, -2.f), (float)g.H + 1.f), fminf(fmaxf(loc_w, -2.f), (float)g.W + 1.f), hc, wc, R);
+                const bool take = inmap && sample_valid(g, loc_h, loc_w);      // (every corner within R of (ho, wo) is picked up below; the others: dcnv3_bwd_om_kernel)
                 f[p] = take ? loc_w : -1e9f;
                 f[9 + p] = take ? loc_h : -1e9f;
                 f[18 + p] = take ? m : 0.f;
@@ -307,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input_kernel(const T* __rest
             float s = 0.f;
 #pragma unroll
             for (int p = 0; p < 9; ++p) {
-                const float wx = fmaxf(1.f - fabsf(q[p] - fx), 0.f), wy = fmaxf(1.f - fabsf(q[9 + p] - fy), 0.f);
+                const float wx = fmaxf(1.f - fabsf(q[p] - fx), 0.f), wy = fmaxf(1.f - fabsf(q[9 + p] - fy), 0.f);      // (__saturatef here: 556 -> 662 us at the 128 x 128 level)
                 s = fmaf(wx * wy, q[18 + p], s);
             }
             if (__builtin_amdgcn_ballot_w64(s != 0.f) == 0) continue;      // (wave-uniform) no sample of these 64 output pixels reaches its lane's pixel
@@ -334,8 +321,8 @@ __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input_kernel(const T* __rest
 }
 
 // The same for InternImage's own geometry -- 3 x 3 points, dilation 1, offset_scale OS = 1 or 2 -- where point (pi, pj) of output pixel o sits
-// nominally at o + OS (pi - 1, pj - 1): a sample that stays within one pixel of its nominal position ("near" here) can only touch the input
-// pixels o + OS (pi - 1, pj - 1) + {-1, 0, 1}^2, so an input pixel has 9 x 9 = 81 candidate samples instead of the window's 9 (2R+1)^2 = 441,
+// nominally at o + OS (pi - 1, pj - 1): here the reach is the corners within one pixel of that nominal position, o + OS (pi - 1, pj - 1) +
+// {-1, 0, 1}^2 (the others go through the atomics), so an input pixel has 9 x 9 = 81 candidate samples instead of the window's 9 (2R+1)^2 = 441,
 // each at a compile-time LDS offset from the lane's own window entry.  S(o, i) is collected in (2R+1)^2 registers (R = OS + 1) and applied to
 // grad_out[o] afterwards, skipping the output pixels no lane of the wave got a weight from.
 template <typename T, int OS>
@@ -373,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input3x3_kernel(const T* __r
                 if (!(g.remove_center && i == 1 && j == 1)) {
                     const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
                     const float loc_h = p0h + ((float)j + oh) * g.os, loc_w = p0w + ((float)i + ow) * g.os;
-                    const bool take = inmap && sample_valid(g, loc_h, loc_w) && sample_near3x3(loc_h, loc_w, hc + OS * (j - 1), wc + OS * (i - 1));
+                    const bool take = inmap && sample_valid(g, loc_h, loc_w);      // (corners within one pixel of the nominal position are picked up below; the others: dcnv3_bwd_om_kernel)
                     lw = take ? loc_w : -1e9f;
                     lh = take ? loc_h : -1e9f;
                     mm = take ? m : 0.f;
@@ -451,10 +438,27 @@ __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input3x3_kernel(const T* __r
 // d(offset), d(mask): one lane = (output pixel, group, 8-channel half) -- the sample location is computed twice (not once per channel lane as in the
 // scatter kernel), the channel sums are 8 in-lane terms + one exchange with the neighbour lane, the four corner rows are one (bf16) / two (f32)
 // 16-byte loads each, exactly the forward's gather.
-// Far samples (see above) scatter their data gradient here, the whole wave working on one sample at a time: lane = (corner, channel), so
-// that a sample costs one atomic instruction of four 64-byte requests -- what the scatter kernel issues per sample, without its 16 lanes
-// per (pixel, group).  The sample's owner passes location / weights through readlane, the pair's 16 grad_out values go through LDS.
-// NEAR = 1: the window test with reach R; NEAR = 2: the 3 x 3 / dilation 1 / integer offset_scale test (OS = R - 1).
+// Corners beyond the gather form's reach (see above) scatter their data gradient here, the whole wave working on one sample at a time: lane =
+// (corner, channel), so that a sample costs one atomic instruction of up to four 64-byte requests -- what the scatter kernel issues per sample,
+// without its 16 lanes per (pixel, group).  The sample's owner passes location / weights through readlane, the pair's 16 grad_out values go
+// through LDS.  NEAR = 1: the window form's reach R around the output pixel; NEAR = 2: the 3 x 3 form's reach of one pixel around the nominal
+// position (OS = R - 1).
+// eight consecutive elements as loaded (16 bytes of bf16 stay packed until they are used)
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+    struct type { float4 a, b; };
+    static __device__ __forceinline__ type load(const float* p) { return type{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
+    static __device__ __forceinline__ void cvt(const type& v, float (&o)[8]) { o[0] = v.a.x; o[1] = v.a.y; o[2] = v.a.z; o[3] = v.a.w; o[4] = v.b.x; o[5] = v.b.y; o[6] = v.b.z; o[7] = v.b.w; }
+};
+template <> struct Raw8<bf16_t> {
+    typedef uint4 type;
+    static __device__ __forceinline__ type load(const bf16_t* p) { return ldg16(reinterpret_cast<const char*>(p)); }
+    static __device__ __forceinline__ void cvt(const type& v, float (&o)[8]) {
+        o[0] = bf16_bits_to_f32(v.x & 0xffffu); o[1] = bf16_bits_to_f32(v.x >> 16); o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
+        o[4] = bf16_bits_to_f32(v.z & 0xffffu); o[5] = bf16_bits_to_f32(v.z >> 16); o[6] = bf16_bits_to_f32(v.w & 0xffffu); o[7] = bf16_bits_to_f32(v.w >> 16);
+    }
+};
+
 template <typename T, int NEAR>
 __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
                                                            float* __restrict__ grad_input, float* __restrict__ grad_offset, float* __restrict__ grad_mask, DcnGeom g, int64_t total,
@@ -478,6 +482,16 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
     const T* mp = mask + item * g.P;
     float* goffp = grad_offset + item * (2 * g.P);
     float* gmp = grad_mask + item * g.P;
+    // every offset / mask value of the (pixel, group) first: the kernel is a chain of dependent loads (offset -> location -> corner rows), and
+    // in the training step its operands are cold -- point by point it paid nine such chains one after the other (170 us even on 16 x 16 maps)
+    float ow[9], oh[9], mk[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        const int pc = p < g.P ? p : g.P - 1;
+        ow[p] = Elem<T>::load(offp + 2 * pc);
+        oh[p] = Elem<T>::load(offp + 2 * pc + 1);
+        mk[p] = Elem<T>::load(mp + pc);
+    }
     float top[8];
     load8(grad_out + pix * C + gi * 16 + 8 * half, top);
 #pragma unroll
@@ -485,48 +499,67 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
     const int halfw = (g.dw * (g.kw - 1)) >> 1, halfh = (g.dh * (g.kh - 1)) >> 1;
     const float p0w = (float)(halfw - g.pw + wo * g.sw) - (float)halfw * g.os;
     const float p0h = (float)(halfh - g.ph + ho * g.sh) - (float)halfh * g.os;
-    const int cw = g.kw / 2, chh = g.kh / 2;
-    int p = 0;
-    for (int i = 0; i < g.kw; ++i) {
-        for (int j = 0; j < g.kh; ++j) {
-            if (g.remove_center && i == cw && j == chh) continue;
-            const float ow = Elem<T>::load(offp + 2 * p), oh = Elem<T>::load(offp + 2 * p + 1), m = Elem<T>::load(mp + p);
-            const float loc_h = p0h + ((float)(j * g.dh) + oh) * g.os, loc_w = p0w + ((float)(i * g.dw) + ow) * g.os;
-            const Point pt = make_point(g, loc_h, loc_w, C);
-            float v[4][8];
-            load8(in_n + pt.o00, v[0]);
-            load8(in_n + pt.o01, v[1]);
-            load8(in_n + pt.o10, v[2]);
-            load8(in_n + pt.o11, v[3]);
-            float d[4] = {0.f, 0.f, 0.f, 0.f};
+    const int centre = (g.kw / 2) * g.kh + g.kh / 2;
+#pragma unroll
+    for (int grp = 0; grp < 3; ++grp) {
+        if (3 * grp >= g.P) break;
+        // ---- three points: locations, then all twelve corner rows in flight together
+        Point pt[3];
+        float loc_h[3], loc_w[3];
+        int pi[3], pj[3];
+        typename Raw8<T>::type raw[3][4];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int p = 3 * grp + q;
+            const int pp = p + ((g.remove_center && p >= centre) ? 1 : 0);     // index in the full kw x kh grid (i over kernel_w outer)
+            pi[q] = pp / g.kh;
+            pj[q] = pp - pi[q] * g.kh;
+            loc_h[q] = p0h + ((float)(pj[q] * g.dh) + oh[p]) * g.os;
+            loc_w[q] = p0w + ((float)(pi[q] * g.dw) + ow[p]) * g.os;
+            pt[q] = make_point(g, loc_h[q], loc_w[q], C);
+            raw[q][0] = Raw8<T>::load(in_n + pt[q].o00);
+            raw[q][1] = Raw8<T>::load(in_n + pt[q].o01);
+            raw[q][2] = Raw8<T>::load(in_n + pt[q].o10);
+            raw[q][3] = Raw8<T>::load(in_n + pt[q].o11);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int p = 3 * grp + q;
+            const bool have = p < g.P;
+            const float m = mk[p];
+            float d[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                float v[8];
+                Raw8<T>::cvt(raw[q][k], v);
+                float acc = 0.f;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) d[k] = fmaf(top[c], v[k][c], d[k]);
-                d[k] += __shfl_xor(d[k], 1, 64);
+                for (int c = 0; c < 8; ++c) acc = fmaf(top[c], v[c], acc);
+                d[k] = acc + __shfl_xor(acc, 1, 64);
             }
-            const float d00 = d[0] * pt.k00, d01 = d[1] * pt.k01, d10 = d[2] * pt.k10, d11 = d[3] * pt.k11;
-            const float hh = 1.f - pt.lh, hw = 1.f - pt.lw;
-            if (live && half == 0) {
-                gmp[p] = hh * hw * d00 + hh * pt.lw * d01 + pt.lh * hw * d10 + pt.lh * pt.lw * d11;
-                *reinterpret_cast<float2*>(goffp + 2 * p) = make_float2(g.os * m * (hh * (d01 - d00) + pt.lh * (d11 - d10)), g.os * m * (hw * (d10 - d00) + pt.lw * (d11 - d01)));
+            const float d00 = d[0] * pt[q].k00, d01 = d[1] * pt[q].k01, d10 = d[2] * pt[q].k10, d11 = d[3] * pt[q].k11;
+            const float lh = pt[q].lh, lw = pt[q].lw, hh = 1.f - lh, hw = 1.f - lw;
+            if (live && half == 0 && have) {
+                gmp[p] = hh * hw * d00 + hh * lw * d01 + lh * hw * d10 + lh * lw * d11;
+                *reinterpret_cast<float2*>(goffp + 2 * p) = make_float2(g.os * m * (hh * (d01 - d00) + lh * (d11 - d10)), g.os * m * (hw * (d10 - d00) + lw * (d11 - d01)));
             }
-            bool near;
-            if constexpr (NEAR == 2)
-                near = sample_near3x3(loc_h, loc_w, ho + (R - 1) * (j - 1), wo + (R - 1) * (i - 1));
-            else
-                near = sample_near(fminf(fmaxf(loc_h, -2.f), (float)g.H + 1.f), fminf(fmaxf(loc_w, -2.f), (float)g.W + 1.f), ho, wo, R);
-            const bool far = live && half == 0 && sample_valid(g, loc_h, loc_w) && !near;
+            // corners the gather form does not reach (per corner, not per sample: a sample astride the edge of the reach sends only its outer corners here)
+            const int h0 = (int)floorf(fminf(fmaxf(loc_h[q], -2.f), (float)g.H + 1.f)), w0 = (int)floorf(fminf(fmaxf(loc_w[q], -2.f), (float)g.W + 1.f));
+            const int ch = NEAR == 2 ? ho + (R - 1) * (pj[q] - 1) : ho, cw = NEAR == 2 ? wo + (R - 1) * (pi[q] - 1) : wo, reach = NEAR == 2 ? 1 : R;
+            const bool out_h0 = abs(h0 - ch) > reach, out_h1 = abs(h0 + 1 - ch) > reach, out_w0 = abs(w0 - cw) > reach, out_w1 = abs(w0 + 1 - cw) > reach;
+            const bool scat = live && half == 0 && have && sample_valid(g, loc_h[q], loc_w[q]);
+            const float w00 = (scat && (out_h0 || out_w0)) ? hh * hw * pt[q].k00 * m : 0.f, w01 = (scat && (out_h0 || out_w1)) ? hh * lw * pt[q].k01 * m : 0.f;
+            const float w10 = (scat && (out_h1 || out_w0)) ? lh * hw * pt[q].k10 * m : 0.f, w11 = (scat && (out_h1 || out_w1)) ? lh * lw * pt[q].k11 * m : 0.f;
+            const bool far = w00 != 0.f || w01 != 0.f || w10 != 0.f || w11 != 0.f;
             uint64_t fm = __builtin_amdgcn_ballot_w64(far);
             if (fm) {
-                const float w00 = hh * hw * pt.k00 * m, w01 = hh * pt.lw * pt.k01 * m, w10 = pt.lh * hw * pt.k10 * m, w11 = pt.lh * pt.lw * pt.k11 * m;
                 const int k = lane >> 4, c = lane & 15;
                 const uint32_t img_lo = (uint32_t)((uint64_t)img & 0xffffffffu), img_hi = (uint32_t)((uint64_t)img >> 32);
                 while (fm) {
                     const int L = __builtin_ctzll(fm);      // an even lane: lanes L, L + 1 hold channels 0-7, 8-15 of the sample's grad_out
                     fm &= fm - 1;
-                    const int s00 = __builtin_amdgcn_readlane(pt.o00, L), s01 = __builtin_amdgcn_readlane(pt.o01, L);
-                    const int s10 = __builtin_amdgcn_readlane(pt.o10, L), s11 = __builtin_amdgcn_readlane(pt.o11, L);
+                    const int s00 = __builtin_amdgcn_readlane(pt[q].o00, L), s01 = __builtin_amdgcn_readlane(pt[q].o01, L);
+                    const int s10 = __builtin_amdgcn_readlane(pt[q].o10, L), s11 = __builtin_amdgcn_readlane(pt[q].o11, L);
                     const float x00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w00), L)), x01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w01), L));
                     const float x10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w10), L)), x11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w11), L));
                     const int64_t imgL = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)img_hi, L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)img_lo, L));
@@ -535,7 +568,6 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
                     if (wk != 0.f) atomicAdd(grad_input + imgL + ok + c, wk * tops[wave][L + (c >> 3)][c & 7]);
                 }
             }
-            ++p;
         }
     }
 }
@@ -562,7 +594,7 @@ int make_geom(const mtp_dcnv3_geom* a, DcnGeom& g) {
     g.os = a->offset_scale;
     g.xcd_order = (a->variant & 1) ? 0 : 1;
     g.scatter_bwd = (a->variant & 2) ? 1 : 0;
-    g.window_bwd = (a->variant & 4) ? 1 : 0;
+    g.form3x3_bwd = (a->variant & 4) ? 1 : 0;
     return 0;
 }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -615,7 +647,10 @@ int launch_bwd(const void* input, const void* offset, const void* mask, const vo
         const int64_t blocks = (int64_t)g.N * tiles_y * tiles_x * g.G;
         if (blocks < ((int64_t)1 << 31) && 2 * items < ((int64_t)1 << 32) - 256) {
 #define MTP_DCN_GATHER(R_, OS3_) launch_bwd_gather<T, R_, OS3_>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s, tiles_x, tiles_y, blocks, items)
-            if (g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && !g.window_bwd) {
+            // default: the window form.  The 3 x 3 form is 8 % faster for offsets below a pixel (a freshly initialised network: the offset head starts at
+            // zero) but its reach is one pixel around the nominal position -- with offsets of sigma = 0.5 ... 1.6 px (bench.py re-draws the heads like
+            // fixture f12) 13 ... 77 % of the samples leave it and go through the atomics: InternImage-XL step 72.7 vs 69.1 ms (same box).
+            if (g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.form3x3_bwd) {
                 if (g.os == 1.0f) return MTP_DCN_GATHER(2, 1);
                 if (g.os == 2.0f) return MTP_DCN_GATHER(3, 2);
             }

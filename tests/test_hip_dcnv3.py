@@ -100,7 +100,7 @@ def test_gather_form_backward_equals_the_scatter_form(shape, osc, amp, rmc, dtyp
     G = torch.randn(N, H, W, M * 16, device="cuda").to(dtype)
     monkeypatch.setenv("MTP_DCNV3_VARIANT", "2")
     ref = dcnv3_backward(x, off, m, *args, G, 256, rmc)
-    for variant in ("0", "4"):       # 0: the 3 x 3 form where offset_scale is 1 or 2 (else the window form); 4: the window form everywhere
+    for variant in ("0", "4"):       # 0: the window form; 4: the 3 x 3 form where offset_scale is 1 or 2 (else the window form)
         monkeypatch.setenv("MTP_DCNV3_VARIANT", variant)
         got = dcnv3_backward(x, off, m, *args, G, 256, rmc)
         for a, b, name in zip(got, ref, ("grad_input", "grad_offset", "grad_mask")):

@@ -106,7 +106,8 @@ def main():
         from mtp_amd.ops_dcnv3 import dcnv3_backward, dcnv3_forward
         # offsets: "zero" = a freshly initialised network (the offset head is zero-initialised, ops_dcnv3/modules/dcnv3.py:176-179) -- what bench.py
         # runs; "smooth" = +-0.25 px; "random" = +-2 px (x offset_scale 2: most samples leave the gather form's reach and take the atomic path).
-        # "scatter" = the per-corner f32-atomic backward (MTP_DCNV3_VARIANT=2), the form used for every geometry before round 3.
+        # "scatter" = the per-corner f32-atomic backward (MTP_DCNV3_VARIANT=2), the form used for every geometry before round 3; "3x3" = the narrow-reach
+        # form of the gather backward (MTP_DCNV3_VARIANT=4); plus offsets drawn like bench.py's heads (sigma 0.55 ... 1.57 px after the offset scale).
         import os
         for (N, HW, M) in [(8, 128, 12), (8, 64, 24), (8, 32, 48), (8, 16, 96), (512, 64, 4)]:
             for dt in (bf, torch.float32):
@@ -118,11 +119,14 @@ def main():
                 px = N * HW * HW
                 fb = px * M * (16 * e * 2 + 27 * e)
                 bb = px * M * (16 * e * 2 + 27 * e + 16 * 4 + 27 * 4)
-                for kind, amp in (("zero", 0.0), ("smooth", 0.5), ("random", 4.0)):
-                    off = ((torch.rand(N, HW, HW, M * 18, device=dev) - 0.5) * amp).to(dt)
+                for kind, amp in (("zero", 0.0), ("smooth", 0.5), ("bench", -1.0), ("random", 4.0)):
+                    if amp < 0:      # what bench.py's re-drawn heads produce: N(0, (0.02 sqrt(C))^2) before the offset scale
+                        off = (torch.randn(N, HW, HW, M * 18, device=dev) * 0.02 * (M * 16) ** 0.5).to(dt)
+                    else:
+                        off = ((torch.rand(N, HW, HW, M * 18, device=dev) - 0.5) * amp).to(dt)
                     t = timeit(lambda: dcnv3_forward(x, off, m, *a, 256, 0), iters=10)
                     cells = ["fwd %.1f us %.0f GB/s" % (t * 1e6, fb / t / 1e9)]
-                    for name, var in (("bwd", "0"), ("bwd-window", "4"), ("bwd-scatter", "2")):
+                    for name, var in (("bwd", "0"), ("bwd-3x3", "4"), ("bwd-scatter", "2")):
                         os.environ["MTP_DCNV3_VARIANT"] = var
                         t = timeit(lambda: dcnv3_backward(x, off, m, *a, G, 256, 0), iters=10)
                         cells.append("%s %.1f us %.0f GB/s" % (name, t * 1e6, bb / t / 1e9))
