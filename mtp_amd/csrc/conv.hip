@@ -103,13 +103,15 @@ __global__ __launch_bounds__(256) void pack_rows_padded_kernel(const float* __re
 template <typename T, typename To, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, To* __restrict__ y,
                                                        int H, int W, int C, int accumulate, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int c4 = C >> 2;
-    const int c = 4 * (int)(idx % c4);
-    const int64_t pix = idx / c4;
-    const int wx = (int)(pix % W), h = (int)((pix / W) % H);
-    const int64_t n = pix / ((int64_t)W * H);
+    // 32-bit index arithmetic (the host checks total < 2^31): five 64-bit divisions were ~600 of this thread's ~700 instructions
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (uint32_t)total) return;
+    const uint32_t c4 = (uint32_t)C >> 2;
+    const uint32_t pix32 = idx / c4;
+    const int c = 4 * (int)(idx - pix32 * c4);
+    const uint32_t row = pix32 / (uint32_t)W, n32 = row / (uint32_t)H;
+    const int wx = (int)(pix32 - row * (uint32_t)W), h = (int)(row - n32 * (uint32_t)H);
+    const int64_t pix = pix32, n = n32;
     float4 acc = (bias && !FLIP) ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -151,8 +153,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_dw_kernel(const T* __restrict__
     const int64_t p0 = (int64_t)blockIdx.y * pix_per_block;
     int64_t p1 = p0 + pix_per_block;
     p1 = p1 < pixels ? p1 : pixels;
-    for (int64_t pix = p0 + pl; pix < p1; pix += 4) {
-        const int wx = (int)(pix % W), h = (int)((pix / W) % H);
+    // (wx, h) of the lane's first pixel once, then stepped: two 64-bit divisions per pixel were most of the loop's instructions
+    int wx = (int)((p0 + pl) % W), h = (int)(((p0 + pl) / W) % H);
+    for (int64_t pix = p0 + pl; pix < p1; pix += 4, wx += 4) {
+        while (wx >= W) {
+            wx -= W;
+            h = h + 1 == H ? 0 : h + 1;
+        }
         const float4 g = load4(dy + pix * C + cc);
         acc[36] += g.x; acc[37] += g.y; acc[38] += g.z; acc[39] += g.w;
 #pragma unroll
@@ -185,45 +192,56 @@ __global__ __launch_bounds__(256) void dwconv3x3_dw_kernel(const T* __restrict__
 
 // ---------------------------------------------------------------------------------------------------------------------
 // softmax over the P points of each (row, group): logits [rows][ld] -> probabilities [rows][G * P]; thread = (row, group)
-template <typename T>
-__global__ __launch_bounds__(256) void softmax_groups_fwd_kernel(const T* __restrict__ logits, int64_t ld, T* __restrict__ prob, int G, int P, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % G);
-    const int64_t row = idx / G;
-    const T* in = logits + row * ld + g * P;
-    float v[32];
+// PC = the point count at compile time (9 / 8: InternImage's 3 x 3 with / without the centre; 0 = run-time P <= 32): with a run-time P the
+// per-thread array is indexed dynamically and lives in scratch memory
+template <typename T, int PC>
+__global__ __launch_bounds__(256) void softmax_groups_fwd_kernel(const T* __restrict__ logits, int64_t ld, T* __restrict__ prob, int G, int P_, int64_t total) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;      // (total < 2^31, checked by the host)
+    if (idx >= (uint32_t)total) return;
+    const int P = PC ? PC : P_;
+    const uint32_t row = idx / (uint32_t)G;
+    const int g = (int)(idx - row * (uint32_t)G);
+    const T* in = logits + (int64_t)row * ld + g * P;
+    float v[PC ? PC : 32];
     float m = -INFINITY;
+#pragma unroll
     for (int i = 0; i < P; ++i) {
         v[i] = ld1(in + i);
         m = fmaxf(m, v[i]);
     }
     float s = 0.f;
+#pragma unroll
     for (int i = 0; i < P; ++i) {
         v[i] = __expf(v[i] - m);
         s += v[i];
     }
     const float inv = 1.f / s;
-    T* out = prob + idx * P;
+    T* out = prob + (int64_t)idx * P;
+#pragma unroll
     for (int i = 0; i < P; ++i) Elem<T>::store(out + i, v[i] * inv);
 }
 // dlogits[rows][ld] = p (dprob - sum p dprob); columns G * P .. ld are zeroed (they feed a GEMM as padded contraction columns)
-template <typename T>
+template <typename T, int PC>
 __global__ __launch_bounds__(256) void softmax_groups_bwd_kernel(const T* __restrict__ prob, const float* __restrict__ dprob, T* __restrict__ dlogits, int64_t ld,
-                                                                int G, int P, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % G);
-    const int64_t row = idx / G;
-    const T* p = prob + idx * P;
-    const float* d = dprob + idx * P;
-    float pv[32], dot = 0.f;
+                                                                int G, int P_, int64_t total) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (uint32_t)total) return;
+    const int P = PC ? PC : P_;
+    const uint32_t row32 = idx / (uint32_t)G;
+    const int g = (int)(idx - row32 * (uint32_t)G);
+    const int64_t row = row32;
+    const T* p = prob + (int64_t)idx * P;
+    const float* d = dprob + (int64_t)idx * P;
+    float pv[PC ? PC : 32], dv[PC ? PC : 32], dot = 0.f;
+#pragma unroll
     for (int i = 0; i < P; ++i) {
         pv[i] = ld1(p + i);
-        dot += pv[i] * d[i];
+        dv[i] = d[i];
+        dot += pv[i] * dv[i];
     }
     T* out = dlogits + row * ld + g * P;
-    for (int i = 0; i < P; ++i) Elem<T>::store(out + i, pv[i] * (d[i] - dot));
+#pragma unroll
+    for (int i = 0; i < P; ++i) Elem<T>::store(out + i, pv[i] * (dv[i] - dot));
     if (g == G - 1)
         for (int i = G * P; i < ld; ++i) Elem<T>::store(dlogits + row * ld + i, 0.f);
 }
@@ -234,12 +252,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const float* __restrict__ x, const T* __restrict__ z, const float* __restrict__ gamma,
                                                                 const float* __restrict__ sample_scale, int rows_per_sample, float* __restrict__ out,
                                                                 T* __restrict__ out_act, int C, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int c4 = C >> 2;
-    const int c = 4 * (int)(idx % c4);
-    const int64_t row = idx / c4;
-    const float s = sample_scale ? sample_scale[row / rows_per_sample] : 1.f;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;        // 32-bit index arithmetic (the host checks total < 2^31): 64-bit divisions cost ~150 instructions each
+    if (idx >= (uint32_t)total) return;
+    const uint32_t c4 = (uint32_t)C >> 2, row32 = idx / c4;
+    const int c = 4 * (int)(idx - row32 * c4);
+    const int64_t row = row32;
+    const float s = sample_scale ? sample_scale[row32 / (uint32_t)rows_per_sample] : 1.f;
     const float4 xv = *reinterpret_cast<const float4*>(x + row * C + c), zv = load4(z + row * C + c), gv = *reinterpret_cast<const float4*>(gamma + c);
     const float4 o = make_float4(xv.x + s * gv.x * zv.x, xv.y + s * gv.y * zv.y, xv.z + s * gv.z * zv.z, xv.w + s * gv.w * zv.w);
     *reinterpret_cast<float4*>(out + row * C + c) = o;
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const float* __
     int64_t r1 = r0 + rows_per_block;
     r1 = r1 < rows ? r1 : rows;
     for (int64_t row = r0 + rl; row < r1; row += 4) {
-        const float s = sample_scale ? sample_scale[row / rows_per_sample] : 1.f;
+        const float s = sample_scale ? sample_scale[(uint32_t)row / (uint32_t)rows_per_sample] : 1.f;      // (rows < 2^31, checked by the host)
         const float4 d = *reinterpret_cast<const float4*>(dout + row * C + cc), zv = load4(z + row * C + cc);
         acc.x += s * d.x * zv.x; acc.y += s * d.y * zv.y; acc.z += s * d.z * zv.z; acc.w += s * d.w * zv.w;
         if (cok) store4(dz + row * C + c, make_float4(s * gv.x * d.x, s * gv.y * d.y, s * gv.z * d.z, s * gv.w * d.w));
@@ -357,6 +375,7 @@ extern "C" int mtp_pack_rows_padded(const float* w, void* wp, void* wpt, int dty
 extern "C" int mtp_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int dtype, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream) {
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4)) return MTP_ERR_ARG;
     const int64_t total = N * H * W * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;      // 32-bit index arithmetic in the kernel
     const dim3 grid(blocks_for(total)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, bf16_t, false>), grid, block, 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, (int)H, (int)W, (int)C, 0, total);
@@ -368,6 +387,7 @@ extern "C" int mtp_dwconv3x3_fwd(const void* x, const float* w, const float* bia
 extern "C" int mtp_dwconv3x3_bwd_dx(const void* dy, int dtype, const float* w, float* dx, int accumulate, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream) {
     if (!dy || !w || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4)) return MTP_ERR_ARG;
     const int64_t total = N * H * W * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;      // 32-bit index arithmetic in the kernel
     const dim3 grid(blocks_for(total)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, float, true>), grid, block, 0, s, (const bf16_t*)dy, w, (const float*)nullptr, dx, (int)H, (int)W, (int)C, accumulate, total);
@@ -400,9 +420,12 @@ extern "C" int mtp_softmax_groups_fwd(const void* logits, int64_t ld, void* prob
     const int64_t total = rows * G;
     const dim3 grid(blocks_for(total)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MTP_BF16) hipLaunchKernelGGL((softmax_groups_fwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)logits, ld, (bf16_t*)prob, (int)G, (int)P, total);
-    else if (dtype == MTP_F32) hipLaunchKernelGGL((softmax_groups_fwd_kernel<float>), grid, block, 0, s, (const float*)logits, ld, (float*)prob, (int)G, (int)P, total);
+    if (total >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;
+#define MTP_SMX_FWD(T_, PC_) hipLaunchKernelGGL((softmax_groups_fwd_kernel<T_, PC_>), grid, block, 0, s, (const T_*)logits, ld, (T_*)prob, (int)G, (int)P, total)
+    if (dtype == MTP_BF16) { if (P == 9) MTP_SMX_FWD(bf16_t, 9); else if (P == 8) MTP_SMX_FWD(bf16_t, 8); else MTP_SMX_FWD(bf16_t, 0); }
+    else if (dtype == MTP_F32) { if (P == 9) MTP_SMX_FWD(float, 9); else if (P == 8) MTP_SMX_FWD(float, 8); else MTP_SMX_FWD(float, 0); }
     else return MTP_ERR_UNSUPPORTED;
+#undef MTP_SMX_FWD
     return mtp_launch_status();
 }
 
@@ -411,9 +434,12 @@ extern "C" int mtp_softmax_groups_bwd(const void* prob, const float* dprob, void
     const int64_t total = rows * G;
     const dim3 grid(blocks_for(total)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MTP_BF16) hipLaunchKernelGGL((softmax_groups_bwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)prob, dprob, (bf16_t*)dlogits, ld, (int)G, (int)P, total);
-    else if (dtype == MTP_F32) hipLaunchKernelGGL((softmax_groups_bwd_kernel<float>), grid, block, 0, s, (const float*)prob, dprob, (float*)dlogits, ld, (int)G, (int)P, total);
+    if (total >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;
+#define MTP_SMX_BWD(T_, PC_) hipLaunchKernelGGL((softmax_groups_bwd_kernel<T_, PC_>), grid, block, 0, s, (const T_*)prob, dprob, (T_*)dlogits, ld, (int)G, (int)P, total)
+    if (dtype == MTP_BF16) { if (P == 9) MTP_SMX_BWD(bf16_t, 9); else if (P == 8) MTP_SMX_BWD(bf16_t, 8); else MTP_SMX_BWD(bf16_t, 0); }
+    else if (dtype == MTP_F32) { if (P == 9) MTP_SMX_BWD(float, 9); else if (P == 8) MTP_SMX_BWD(float, 8); else MTP_SMX_BWD(float, 0); }
     else return MTP_ERR_UNSUPPORTED;
+#undef MTP_SMX_BWD
     return mtp_launch_status();
 }
 
@@ -421,6 +447,7 @@ extern "C" int mtp_scale_residual_fwd(const float* x, const void* z, int dtype, 
                                       float* out, void* out_act, int64_t rows, int64_t C, mtp_stream_t stream) {
     if (!x || !z || !gamma || !out || rows <= 0 || C <= 0 || (C % 4) || (sample_scale && rows_per_sample <= 0)) return MTP_ERR_ARG;
     const int64_t total = rows * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;      // 32-bit index arithmetic in the kernel
     const dim3 grid(blocks_for(total)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int rps = (int)(rows_per_sample > 0 ? rows_per_sample : 1);
@@ -439,6 +466,7 @@ extern "C" int64_t mtp_scale_residual_bwd_partial_rows(int64_t rows) {
 extern "C" int mtp_scale_residual_bwd(const float* dout, const void* z, int dtype, const float* gamma, const float* sample_scale, int64_t rows_per_sample,
                                       void* dz, float* part, int64_t rows, int64_t C, mtp_stream_t stream) {
     if (!dout || !z || !gamma || !dz || !part || rows <= 0 || C <= 0 || (C % 4) || (sample_scale && rows_per_sample <= 0)) return MTP_ERR_ARG;
+    if (rows >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;
     const int64_t nb = mtp_scale_residual_bwd_partial_rows(rows);
     const int64_t rpb = (rows + nb - 1) / nb;
     const dim3 grid((unsigned)((C / 4 + 63) / 64), (unsigned)nb), block(256);
