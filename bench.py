@@ -325,9 +325,11 @@ def main():
                          "`value` a measurement of the instrumentation (20 steps, same box: every 4th 36.66 ms, every 10th 36.45, none 36.29); 1 = every step")
     ap.add_argument("--host-input", action="store_true", help="additionally time the step fed from HOST uint8 batches (pinned staging, side-stream H2D, "
                                                               "fused preprocess): reported as `host_input`, never as `value`")
-    ap.add_argument("--heads", default="mean", choices=["mean", "standin3"],
+    ap.add_argument("--heads", default="mean", choices=["mean", "standin3", "standin_seg"],
                     help="what consumes the four feature maps: `mean` = sum_i mean(f_i) (the headline line); `standin3` = three labelled stand-in task "
-                         "heads (BASELINE configs[1]: 'ViT-B/16 + 3 MTP decoder heads'; the real decoders live in un-vendored mmseg / mmdet / mmrotate)")
+                         "heads (BASELINE configs[1]: 'ViT-B/16 + 3 MTP decoder heads'; the real decoders live in un-vendored mmseg / mmdet / mmrotate); `standin_seg` = one "
+                         "labelled stand-in segmentation head (BASELINE configs[4]: 'InternImage-XL ... segmentation decoder'): per-map 1x1 class projection + "
+                         "cross-entropy against fixed random labels, through torch autograd")
     ap.add_argument("--image-size", type=int, default=224, help="224 = the headline metric; 448 = what MTP actually pretrains at (use --batch 16)")
     ap.add_argument("--comm-mode", default=os.environ.get("MTP_COMM_MODE", "allreduce"), choices=["allreduce", "rs_ag"],
                     help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (mtp_amd.parallel.GradReducer)")
@@ -399,8 +401,8 @@ def main():
         # 1x1 projection w[t][i] (C -> 1) and averages -- three consumers of the four maps with their own parameters and a
         # per-channel cotangent, nothing more.  Labelled as stand-ins in `config`.
         gh = torch.Generator(device="cuda").manual_seed(7)
-        C_ = net.embed_dim
-        head_w = [[torch.randn(C_, device="cuda", generator=gh) / C_ ** 0.5 for _ in range(4)] for _ in range(3)]
+        chans = [net.embed_dim] * 4 if hasattr(net, "embed_dim") else list(net.out_channels)      # (InternImage: 192 / 384 / 768 / 1536)
+        head_w = [[torch.randn(c, device="cuda", generator=gh) / c ** 0.5 for c in chans] for _ in range(3)]
 
         def loss_and_grads(feats):
             loss, grads = 0.0, []
@@ -410,6 +412,27 @@ def main():
                 loss = loss + (f.sum(dim=(0, 2, 3), dtype=torch.float32) * wsum).sum() / pix
                 grads.append((wsum / pix).to(f.dtype).view(1, -1, 1, 1).expand_as(f).contiguous())
             return loss, grads
+    elif args.heads == "standin_seg":
+        # ONE stand-in segmentation head (the UperNet decoder of FT/Semantic_Segmentation/configs/mtp/loveda/*.py lives in un-vendored mmseg): every map gets
+        # its own 1x1 projection to 7 classes (LoveDA) and a per-pixel cross-entropy against fixed random labels at its own resolution; the cotangents
+        # of the maps come from torch autograd, so -- unlike `mean` -- they differ from pixel to pixel.  Labelled as a stand-in in `config`.
+        gh = torch.Generator(device="cuda").manual_seed(11)
+        seg = {}
+
+        def loss_and_grads(feats):
+            loss, leaves = 0.0, []
+            for i, f in enumerate(feats):
+                if i not in seg:
+                    c = f.shape[1]
+                    seg[i] = (torch.randn(7, c, device="cuda", generator=gh) / c ** 0.5,
+                              torch.randint(0, 7, (f.shape[0], f.shape[2], f.shape[3]), device="cuda", generator=gh))
+                w, y = seg[i]
+                fl = f.detach().requires_grad_(True)
+                logits = torch.einsum("bchw,kc->bkhw", fl.float(), w)
+                loss = loss + torch.nn.functional.cross_entropy(logits, y)
+                leaves.append(fl)
+            grads = torch.autograd.grad(loss, leaves)
+            return loss.detach(), [g.to(f.dtype).contiguous() for g, f in zip(grads, feats)]
     else:
         def loss_and_grads(feats):
             # stand-in for the three task decoders: loss = sum_i mean(f_i), d loss / d f_i = 1 / numel(f_i), written out by hand
@@ -544,7 +567,8 @@ def main():
                                       if args.image_size == 224 else " (not the headline configuration)"),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss),
                        "heads": ("3 stand-in task heads (per-map 1x1 projection + mean each; the mm* decoders are not vendored)" if args.heads == "standin3"
-                                 else "sum_i mean(f_i)")},
+                                 else "1 stand-in segmentation head (per-map 1x1 projection to 7 classes + per-pixel cross-entropy vs fixed random labels, torch autograd; "
+                                      "mmseg's UperNet is not vendored)" if args.heads == "standin_seg" else "sum_i mean(f_i)")},
             "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if (args.image_size == 224 and gf) else None,
             "roofline": roof,
         }
