@@ -339,6 +339,7 @@ def main():
                     help="TEST ONLY: gloo ranks on CPU exercising the launcher / rendezvous / comm-report plumbing without kernels (prints `standin: true`)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver (read when HIP initialises)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
