@@ -318,6 +318,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="additionally time the forward pass alone (inference mode, no saved activations): SURVEY 8d asks for "
+                    "forward-only numbers next to the step; reported as `forward_only`, never as `value`")
     ap.add_argument("--gemm-shapes", action="store_true", help="print the per-shape table of the instrumented GEMM launches to stderr")
     ap.add_argument("--timer-every", type=int, default=10,
                     help="the per-launch HIP events behind `roofline` are recorded on every N-th timed step (step 0, N, 2N, ...): two events per "
@@ -505,6 +507,25 @@ def main():
                     note="all-reduce time = HIP events on the side stream around each collective (its own duration, overlapped with the "
                          "backward); exposed = step time with minus without collectives; bus GB/s = bytes x 2(N-1)/N / all-reduce time")
 
+    forward_only = None
+    if args.forward_only:
+        eng = trainer.engine
+        for _ in range(args.warmup):
+            eng.forward(img, training=False, need_grad=False, feature_dtype=fdt)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.forward(img, training=False, need_grad=False, feature_dtype=fdt)
+        sync()
+        tf = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        dtf = float(tf.item())
+        gff = FWD_GF_PER_IMAGE.get(args.model, 0.0)
+        forward_only = dict(value=round(world * B * args.steps / dtf, 2), unit="images/sec", ms_per_pass=round(dtf / args.steps * 1e3, 3),
+                            mfma_frac=(round(B * args.steps / dtf * gff * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if (args.image_size == 224 and gff) else None),
+                            note="forward pass alone (inference mode: no activations saved, no drop path), same weights / input / feature dtype as the step")
+
     host_input = None
     if args.host_input:
         # PCIe-inclusive variant of the same step: raw uint8 HWC batches start in pageable HOST memory, are staged
@@ -582,6 +603,8 @@ def main():
             out["comm"] = comm
         if host_input is not None:
             out["host_input"] = host_input
+        if forward_only is not None:
+            out["forward_only"] = forward_only
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model)
     if dist.is_initialized():
