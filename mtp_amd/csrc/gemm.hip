@@ -664,6 +664,9 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     // when the problem does not fit it
     if constexpr (sizeof(T) == 2) {
         const int p8 = nt_p8_mode(a, k);
+        // variant bit 22: the co-resident 4-wave form (gemm_c2.hip: 256 x 128 tiles, two workgroups per CU) wherever the pipelined kernel fits
+        if (p8 && (a->variant & (1 << 22)))
+            return mtp_nt_c2_launch(k, a->out_dtype, EPI, ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 20) & 3) << 13), stream);
         if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 17) & 7) << 10) | (((a->variant >> 20) & 3) << 13), stream);
     }
     const int tiles_m = (k.M + BM - 1) / BM;

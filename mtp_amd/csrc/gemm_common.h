@@ -44,6 +44,10 @@ int mtp_nt_p8_launch(const KArgs& k, int out_dtype, int epilogue, int flags, hip
 int mtp_nt_p8_fits(const KArgs& k, int out_dtype, int epilogue);   // 1 when mtp_nt_p8_launch would run the problem
 size_t mtp_nt_p8_workspace_bytes();                                // what the stream-K form of the kernel needs in KArgs::sk_ws
 
+// gemm_c2.hip: the same pipeline on 256 x 128 tiles with 4 waves, two co-resident workgroups per CU (same preconditions and flags bits 1,
+// 13-14 as mtp_nt_p8_launch)
+int mtp_nt_c2_launch(const KArgs& k, int out_dtype, int epilogue, int flags, hipStream_t stream);
+
 // gemm_tn_w4.hip: the grouped weight-gradient GEMM on 4 waves x (128 x 128) of 32x32x16 MFMAs; arguments already validated by
 // mtp_gemm_tn_grouped (gemm_tn_p8.hip)
 int mtp_gemm_tn_grouped_w4(const mtp_gemm_args* args, int count, hipStream_t stream);

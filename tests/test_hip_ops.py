@@ -116,9 +116,10 @@ P8_SHAPES = [(256, 256, 128),      # one tile, the shortest pipeline (one K-tile
 
 
 PS = 32768       # variant bit 15: persistent tiles (the next tile's first K-tiles are issued before the epilogue of the current one)
+C2 = 256 + (1 << 22)   # variant bit 22: the co-resident 4-wave form (gemm_c2.hip: 256 x 128 tiles, two workgroups per CU)
 
 
-@pytest.mark.parametrize("variant", [256, 512, 768, 514, 512 + PS, 768 + PS])
+@pytest.mark.parametrize("variant", [256, 512, 768, 514, 512 + PS, 768 + PS, C2, C2 + 2])
 @pytest.mark.parametrize("M,N,K", P8_SHAPES)
 def test_gemm_nt_p8_vs_oracle(ops, variant, M, N, K):
     dtype = torch.bfloat16
@@ -134,7 +135,7 @@ def test_gemm_nt_p8_asymmetric_identity(ops):
     M = N = K = 512
     w = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :]) % 251).float()     # exact in bf16, no two rows alike
     a = torch.eye(M)
-    for variant in (512, 768):
+    for variant in (512, 768, C2):
         out = ops.gemm_nt(dev(a, torch.bfloat16), dev(w, torch.bfloat16), e(M, N), variant=variant)
         assert torch.equal(out.cpu(), w.t().contiguous()), variant
 
@@ -161,7 +162,7 @@ def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
     ref = run(1024)
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
     NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20          # store policy of the epilogue: nt / sc1 (write-through) / plain stores (0 = picked per epilogue)
-    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN):
+    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN, C2, C2 + NT_, C2 + SC1, C2 + PLAIN):
         for rep in range(4):
             for x, y in zip(ref, run(v)):
                 assert torch.equal(x, y), (v, rep)
@@ -175,7 +176,7 @@ def test_gemm_nt_p8_vit_l_shapes_race_screen(ops):
     for (N, K) in [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C), (C, 3 * C)]:
         a, w, b = dev(rnd(T, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.05), dtype), dev(rnd(N, seed=2))
         ref = ops.gemm_nt(a, w, e(T, N, dtype=dtype), bias=b, variant=1024)
-        for v in (512, 768, 512 + PS, 768 + PS):
+        for v in (512, 768, 512 + PS, 768 + PS, C2):
             out = e(T, N, dtype=dtype)
             for rep in range(6):
                 out.zero_()
