@@ -37,7 +37,8 @@ struct C2Ctx {
     uint32_t ra, rb, wa, wb;   // byte offsets of the next slot to read / to fill in each ring (wave-uniform)
 };
 
-// LDS-DMA pieces (1 KiB each per wave): LDS[l + 16 * lane] <- global[p + voff + OFF]
+// LDS-DMA pieces (1 KiB each per wave): LDS[l + 16 * lane] <- global[p + voff + OFF]  (OFF is added to the VGPR offset: the
+// instruction's immediate offset also moves the LDS destination -- measured, round 4: every result wrong with `offset:128`)
 template <int OFF>
 __device__ __forceinline__ void c2_glds2(uint32_t voff, const char* p0, const char* p1, uint32_t l0) {
     uint32_t keep;
@@ -45,13 +46,13 @@ __device__ __forceinline__ void c2_glds2(uint32_t voff, const char* p0, const ch
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %4 offset:%6\n\t"
+        "global_load_lds_dwordx4 %1, %4 \n\t"
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %5 offset:%6\n\t"
+        "global_load_lds_dwordx4 %1, %5 \n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff), "s"(l0), "s"(l0 + 1024u), "s"(p0), "s"(p1), "i"(OFF)
+        : "v"(voff + (uint32_t)OFF), "s"(l0), "s"(l0 + 1024u), "s"(p0), "s"(p1)
         : "memory");
 }
 template <int OFF>
@@ -61,19 +62,19 @@ __device__ __forceinline__ void c2_glds4(uint32_t voff, const char* p0, const ch
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %6 offset:%10\n\t"
+        "global_load_lds_dwordx4 %1, %6 \n\t"
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %7 offset:%10\n\t"
+        "global_load_lds_dwordx4 %1, %7 \n\t"
         "s_mov_b32 m0, %4\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %8 offset:%10\n\t"
+        "global_load_lds_dwordx4 %1, %8 \n\t"
         "s_mov_b32 m0, %5\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %9 offset:%10\n\t"
+        "global_load_lds_dwordx4 %1, %9 \n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff), "s"(l0), "s"(l0 + 1024u), "s"(l0 + 2048u), "s"(l0 + 3072u), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "i"(OFF)
+        : "v"(voff + (uint32_t)OFF), "s"(l0), "s"(l0 + 1024u), "s"(l0 + 2048u), "s"(l0 + 3072u), "s"(p0), "s"(p1), "s"(p2), "s"(p3)
         : "memory");
 }
 
