@@ -134,6 +134,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// opt-in for more than 64 KiB of dynamic LDS, once per (kernel, device): `mask` is the call site's static bit set of devices already done
+// (a process-wide bool would skip a second device of the same process; setting the attribute twice in a race is harmless)
+static inline int mtp_optin_lds(const void* kern, int bytes, unsigned long long& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+    if (dev < 64 && ((mask >> dev) & 1ull)) return 0;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 64) mask |= 1ull << dev;
+    return 0;
+}
+
 #define MTP_CHECK_ARG(cond) \
     do {                    \
         if (!(cond)) return MTP_ERR_ARG; \

@@ -617,13 +617,8 @@ template <typename T, int R, int OS3>
 int launch_bwd_gather(const void* input, const void* offset, const void* mask, const void* grad_output, float* grad_input, float* grad_offset, float* grad_mask, const DcnGeom& g,
                       hipStream_t s, int tiles_x, int tiles_y, int64_t blocks, int64_t items) {
     constexpr int LDS = (DT_TILE + 2 * R) * (DT_TILE + 2 * R) * DtLds<T>::kPitch;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = OS3 ? hipFuncSetAttribute((const void*)dcnv3_bwd_input3x3_kernel<T, (OS3 ? OS3 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
-                           : hipFuncSetAttribute((const void*)dcnv3_bwd_input_kernel<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long optin = 0;     // (one per instantiation of this launcher: per kernel; the bit set inside is per device)
+    if (const int e = mtp_optin_lds(OS3 ? (const void*)dcnv3_bwd_input3x3_kernel<T, (OS3 ? OS3 : 1)> : (const void*)dcnv3_bwd_input_kernel<T, R>, LDS, optin)) return e;
     if constexpr (OS3 != 0)
         hipLaunchKernelGGL((dcnv3_bwd_input3x3_kernel<T, (OS3 ? OS3 : 1)>), dim3((unsigned)blocks), dim3(256), LDS, s, (const T*)offset, (const T*)mask, (const T*)grad_output, grad_input, g, tiles_x, tiles_y);
     else

@@ -258,8 +258,8 @@ __global__ __launch_bounds__(C2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
 template <typename Tout, int EPI, int SP>
 int launch_c2_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_c2_kernel<Tout, EPI, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);   // (cheap; per device)
-    if (e != hipSuccess) return (int)e;
+    static unsigned long long optin = 0;
+    if (const int e = mtp_optin_lds((const void*)gemm_nt_c2_kernel<Tout, EPI, SP>, C2_LDS, optin)) return e;
     hipLaunchKernelGGL((gemm_nt_c2_kernel<Tout, EPI, SP>), dim3(ntiles), dim3(C2_THREADS), C2_LDS, stream, a);
     return mtp_launch_status();
 }

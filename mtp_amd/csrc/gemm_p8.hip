@@ -445,12 +445,8 @@ int p8_cus() {
 template <typename Tout, int EPI, int MI1, int XP, int PS = 0, int SP = 0>
 int launch_p8_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
     constexpr int LDS = P8_LDS + ((PS || SP) ? 8 * 4096 : 0);
-    static bool attr = false;   // 128 / 160 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static unsigned long long optin = 0;   // 128 / 160 KiB of dynamic LDS needs the opt-in once per kernel and device
+    if (const int e = mtp_optin_lds((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>, LDS, optin)) return e;
     const int grid = PS ? (ntiles < p8_cus() ? ntiles : p8_cus()) : ntiles;
     hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>), dim3(grid), dim3(P8_THREADS), LDS, stream, a);
     return mtp_launch_status();
@@ -477,12 +473,8 @@ void p8_sk_plan(KArgs& a, int ntiles) {
 template <typename Tout, int EPI, int MI1>
 int launch_p8_sk_kernel(const KArgs& a, hipStream_t stream) {
     constexpr int LDS = P8_LDS + 8 * 4096;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_sk_kernel<Tout, EPI, MI1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static unsigned long long optin = 0;
+    if (const int e = mtp_optin_lds((const void*)gemm_nt_p8_sk_kernel<Tout, EPI, MI1>, LDS, optin)) return e;
     hipLaunchKernelGGL((gemm_nt_p8_sk_kernel<Tout, EPI, MI1>), dim3(p8_cus()), dim3(P8_THREADS), LDS, stream, a);
     return mtp_launch_status();
 }

@@ -267,6 +267,7 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
         int64_t kchunk = a.K;
         if (splits > 1) {
             if (!a.aux || ((uintptr_t)a.aux & 15)) return MTP_ERR_ARG;
+            if (!a.defer_sum && a.ldc != a.N) return MTP_ERR_UNSUPPORTED;      // (the reduction treats an image as M * N contiguous floats; checked BEFORE anything is launched)
             kchunk = ((a.K / 128 + splits - 1) / splits) * 128;
             splits = (int)((a.K + kchunk - 1) / kchunk);
         }
@@ -288,13 +289,8 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     if ((args[0].variant & 32) && !(args[0].variant & 64) && plain256) return mtp_gemm_tn_grouped_w4(args, count, (hipStream_t)stream);
     const int xp = (args[0].variant >> 11) & 15;   // ablation builds (tools/ab_wgrad.py): 2 = no stagger, 8 = no MFMAs
     void (*kern)(TnGroup) = xp == 2 ? gemm_tn_p8_kernel<2> : xp == 8 ? gemm_tn_p8_kernel<8> : gemm_tn_p8_kernel<0>;
-    static bool attr[3] = {false, false, false};
-    const int ai = xp == 2 ? 1 : xp == 8 ? 2 : 0;
-    if (!attr[ai]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr[ai] = true;
-    }
+    static unsigned long long optin[3] = {0, 0, 0};     // 128 KiB of dynamic LDS: opt-in once per kernel and device
+    if (const int e = mtp_optin_lds((const void*)kern, P8_LDS, optin[xp == 2 ? 1 : xp == 8 ? 2 : 0])) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);
     int rc = mtp_launch_status();
     // the split problems' images -> C
@@ -304,7 +300,6 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     int nsplit[12], n = 0;
     for (int i = 0; i < count && rc == 0; ++i) {
         if (g.p[i].splits > 1 && !args[i].defer_sum) {
-            if (args[i].ldc != args[i].N) return MTP_ERR_UNSUPPORTED;      // (the reduction treats an image as M * N contiguous floats)
             parts[n] = (const float*)args[i].aux; outs[n] = (float*)args[i].C; numel[n] = args[i].M * args[i].N; nsplit[n] = g.p[i].splits;
             ++n;
         }
