@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N > 1 path of mtp_amd.parallel -- flat reverse-execution-order layout, bucket partition,
+"""CPU, world_size 2 / 3 / 8, gloo: the N > 1 path of mtp_amd.parallel -- flat reverse-execution-order layout, bucket partition,
 bucketed all-reduce == one big all-reduce, unused parameters excluded statically, optimizer schedule/segments."""
 import math
 import os
@@ -86,13 +86,17 @@ def _worker(rank, world, port, q):
         local = flat.grad.clone()
         ref = local.clone()
         dist.all_reduce(ref)                                   # the single-tensor reference
+        # power-of-two worlds: gloo's halving-doubling pairs the ranks the same way whatever the bucket boundaries -> bit-identical sums;
+        # a ring (world 3) adds each chunk in an order that depends on its position: equal to f32 rounding only
+        def same(x, y):
+            return torch.equal(x, y) if world & (world - 1) == 0 else torch.allclose(x, y, rtol=2e-6, atol=2e-6)
         red = GradReducer(flat, bucket_bytes=1 << 20)
         assert red.world == world and len(red.buckets) > 2
         order = [6] + list(range(5, -1, -1)) + [-1]             # the engine's completion order, one group at a time
         for gid in order:
             red.on_block_done(gid)
         red.finish()
-        ok = torch.equal(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        ok = same(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
         ok = ok and red.collectives == len(red.buckets)
         # ... and in bursts, as the engine reports them when the weight gradients of several blocks are launched together
         flat.grad.copy_(local)
@@ -103,7 +107,7 @@ def _worker(rank, world, port, q):
         for gid in (2, 1, 0, -1):
             red.on_block_done(gid)
         red.finish()
-        ok = ok and torch.equal(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        ok = ok and same(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
         ok = ok and n_after_burst >= 1 and red.start == flat.reduced
         # ... and as reduce-scatter + all-gather of the same buckets (the direct form for xGMI): bit for bit the all-reduce's sums
         flat.grad.copy_(local)
@@ -111,35 +115,54 @@ def _worker(rank, world, port, q):
         for gid in order:
             rs.on_block_done(gid)
         rs.finish()
-        ok = ok and torch.equal(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
-        ok = ok and rs.collectives == 2 * len(rs.buckets) and rs.wire_bytes == flat.reduced * 4
-        # ... and with bf16 on the wire: the sum of the bf16-rounded local gradients, rounded to bf16 (world 2: one addition)
+        ok = ok and same(flat.grad[:flat.reduced], ref[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        ok = ok and rs.wire_bytes == flat.reduced * 4
+        # ... and with bf16 on the wire: the sum of the bf16-rounded local gradients, rounded to bf16
         flat.grad.copy_(local)
-        other = torch.randn(flat.total, generator=torch.Generator().manual_seed(100 + (1 - rank)))
-        want = (local.bfloat16() + other.bfloat16()).float()       # bf16 + bf16 -> bf16, as gloo / RCCL reduce in the wire dtype
+        others = [torch.randn(flat.total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
         hb = GradReducer(flat, bucket_bytes=1 << 20, mode="rs_ag", bf16=True)
         for gid in order:
             hb.on_block_done(gid)
         hb.finish()
-        ok = ok and torch.equal(flat.grad[:flat.reduced], want[:flat.reduced]) and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
+        if world == 2:      # one addition: bf16 + bf16 -> bf16 exactly, as gloo / RCCL reduce in the wire dtype
+            want = (others[0].bfloat16() + others[1].bfloat16()).float()
+            ok = ok and torch.equal(flat.grad[:flat.reduced], want[:flat.reduced])
+        else:               # world - 1 bf16 additions in the backend's order: every partial sum is rounded to 8 bits of mantissa
+            want = sum(o.bfloat16().float() for o in others)
+            err = (flat.grad[:flat.reduced] - want[:flat.reduced]).abs()
+            bound = 2.0 ** -8 * (world - 1) * sum(o.abs() for o in others)[:flat.reduced]
+            ok = ok and bool((err <= bound + 1e-6).all()) and float(err.mean()) < 0.05
+            ok = ok and torch.equal(flat.grad[:flat.reduced], flat.grad[:flat.reduced].bfloat16().float())      # values came back through bf16
+        ok = ok and torch.equal(flat.grad[flat.reduced:], local[flat.reduced:])
         ok = ok and hb.wire_bytes == flat.reduced * 2 and hb.bytes_reduced == flat.reduced * 4
+        # every rank holds the same averaged-gradient bits after each mode (the optimizer step must not drift the replicas apart)
+        chk = torch.tensor([float(flat.grad[:flat.reduced].double().sum())], dtype=torch.float64)
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        ok = ok and all(torch.equal(c, allc[0]) for c in allc)
+        # a world size that does not divide the bucket lengths: rs_ag must fall back to the all-reduce bucket by bucket, same sums
+        if flat.reduced % world or any((b[2] - b[1]) % world for b in rs.buckets):
+            ok = ok and rs.collectives < 2 * len(rs.buckets)
+        else:
+            ok = ok and rs.collectives == 2 * len(rs.buckets)
         q.put((rank, bool(ok), red.bytes_reduced == flat.reduced * 4))
     finally:
         dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_equals_single_allreduce_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 3, 8])      # 8 = the node BASELINE's headline names; 3 does not divide the bucket lengths (rs_ag falls back per bucket)
+def test_bucketed_allreduce_equals_single_allreduce(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True, True), (1, True, True)]
+    assert sorted(res) == [(r, True, True) for r in range(world)]
 
 
 def _sync_worker(rank, world, port, q):
@@ -163,15 +186,16 @@ def _sync_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_trainer_synchronises_replicas_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_trainer_synchronises_replicas(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
