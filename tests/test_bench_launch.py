@@ -36,6 +36,21 @@ def test_gpus_2_self_launches_two_ranks_and_prints_one_json_line_last(mode, bf16
     assert sum(1 for ln in lines if ln.startswith("{") and '"metric"' in ln) == 1
 
 
+@pytest.mark.parametrize("mode,bf16", [("allreduce", False), ("rs_ag", True)])
+def test_gpus_8_self_launches_the_node_the_headline_names(mode, bf16):
+    """BASELINE's metric is quoted at 1 / 2 / 4 / 8 GPUs: the same self-launch at the real rank count (8 gloo ranks on CPU) -- rendezvous,
+    per-rank seeds, the bucket partition at world 8 (rs_ag needs bucket lengths divisible by 8), one JSON line, replicas identical"""
+    rc, lines, err = _run("--gpus", "8", "--steps", "2", "--warmup", "1", "--cpu-standin", "--comm-mode", mode, *(["--comm-bf16"] if bf16 else []),
+                          env={"OMP_NUM_THREADS": "1"})
+    assert rc == 0, err[-2000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 8 and out["standin"] is True and out["config"]["global_batch"] == 8 * 64 and out["config"]["parallelism"] == "dp8"
+    c = out["comm"]
+    assert c["ranks"] == 8 and c["mode"] == mode and c["bf16"] is bf16 and c["replicas_identical"] is True
+    assert c["collectives_per_step"] >= (4 if mode == "rs_ag" else 2)
+    assert sum(1 for ln in lines if ln.startswith("{") and '"metric"' in ln) == 1
+
+
 def test_too_few_devices_gives_a_json_error_line_not_a_traceback():
     if __import__("torch").cuda.is_available() and __import__("torch").cuda.device_count() >= 64:
         pytest.skip("a 64-GPU box")

@@ -86,10 +86,10 @@ def _worker(rank, world, port, q):
         local = flat.grad.clone()
         ref = local.clone()
         dist.all_reduce(ref)                                   # the single-tensor reference
-        # power-of-two worlds: gloo's halving-doubling pairs the ranks the same way whatever the bucket boundaries -> bit-identical sums;
-        # a ring (world 3) adds each chunk in an order that depends on its position: equal to f32 rounding only
+        # world 2: one addition per element, commutative -> the bucketed sums are bit-identical to the single all-reduce's; beyond that gloo's
+        # ring adds each chunk in an order that depends on its position in the buffer: equal to f32 rounding only (measured 2.9e-6 at world 8)
         def same(x, y):
-            return torch.equal(x, y) if world & (world - 1) == 0 else torch.allclose(x, y, rtol=2e-6, atol=2e-6)
+            return torch.equal(x, y) if world == 2 else torch.allclose(x, y, rtol=1e-5, atol=1e-5)
         red = GradReducer(flat, bucket_bytes=1 << 20)
         assert red.world == world and len(red.buckets) > 2
         order = [6] + list(range(5, -1, -1)) + [-1]             # the engine's completion order, one group at a time
