@@ -86,6 +86,9 @@ def stem(img, p):
     return _ln(x, p, "patch_embed.norm2.1")
 
 
+PROBE = None   # tests set this to a dict: every DCNv3 call then records how close its sampling positions come to a cell edge
+
+
 def dcnv3_module(x, p, pre, group, offset_scale, kernel_size=3):
     """DCNv3 module DCNM:187-218 (DCNv3_pytorch) == DCNM:316-353 (DCNv3): input_proj; depthwise conv -> LN -> GELU on the
     UNprojected input; offset / mask heads on that; softmax over the P points of each group; core; output_proj"""
@@ -98,6 +101,14 @@ def dcnv3_module(x, p, pre, group, offset_scale, kernel_size=3):
     mask = F.linear(x1, p[pre + "mask.weight"], p[pre + "mask.bias"]).reshape(N, H, W, group, P)
     mask = torch.softmax(mask, -1).reshape(N, H, W, group * P)
     pad = kernel_size // 2
+    if PROBE is not None:
+        # a 3 x 3 / stride 1 / dilation 1 sample sits at integer + offset * offset_scale (dcnv3_oracle._locations): bilinear interpolation is
+        # only piecewise differentiable, the kinks are where that fractional part is 0 -- record the closest approach (in pixels)
+        with torch.no_grad():
+            fr = (offset.detach().double() * offset_scale) % 1.0
+            d = float(torch.minimum(fr, 1.0 - fr).min())
+        PROBE["min_edge_distance"] = min(PROBE.get("min_edge_distance", 1.0), d)
+        PROBE["calls"] = PROBE.get("calls", 0) + 1
     y = D.dcnv3_forward(xp, offset, mask, kernel_size, kernel_size, 1, 1, pad, pad, 1, 1, group, C // group, offset_scale, 0)
     return F.linear(y, p[pre + "output_proj.weight"], p[pre + "output_proj.bias"])
 

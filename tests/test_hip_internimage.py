@@ -190,8 +190,8 @@ def _net(precision, **kw):
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_internimage_forward_and_every_gradient_vs_reference_fixture_and_oracle(precision):
     """f12's recipe: 2 x 3 x 64 x 64 image, seeded parameters (offset / mask heads randomised so the sampling really deforms),
-    loss = sum_i <f_i, g_i>.  fp32 mode: features 1e-3, gradients 5e-3 (max-abs, vs the float64 reference fixture AND the oracle's
-    autograd for all 127 parameters); bf16 mode: relative L2, features 2e-2, gradients 0.15 (values recorded in the parity table)."""
+    loss = sum_i <f_i, g_i>.  fp32 mode: features and gradients 1e-3 = north_star's bound (max-abs, vs the float64 reference fixture AND the
+    oracle's autograd for all 127 parameters; measured 3.4e-4); bf16 mode: relative L2, features 2e-2, gradients 0.15 (values recorded in the parity table)."""
     FIX = np.load(os.path.join(ROOT, "tests", "golden", "f12_internimage.npz"))
     net, shapes = _net(precision)
     assert [k for k in net.state_dict()] == [str(k) for k in FIX["keys"]]
@@ -211,14 +211,18 @@ def test_internimage_forward_and_every_gradient_vs_reference_fixture_and_oracle(
     if precision == "fp32":
         for i, f in enumerate(feats):
             assert rel_err(f.cpu(), torch.from_numpy(FIX["feat%d" % i])) < 1e-3, i
-        assert rel_err(x.grad.cpu(), torch.from_numpy(FIX["grad_img"])) < 5e-3
+        v = rel_err(x.grad.cpu(), torch.from_numpy(FIX["grad_img"]))
+        record_parity(group + "_vs_reference_f64", "grad_img", v)
+        assert v < 1e-3, v
         for k in FIX.files:
             if k.startswith("grad."):
-                assert rel_err(grads[k[5:]].grad.cpu(), torch.from_numpy(FIX[k])) < 5e-3, k
+                v = rel_err(grads[k[5:]].grad.cpu(), torch.from_numpy(FIX[k]))
+                record_parity(group + "_vs_reference_f64", k[5:], v)
+                assert v < 1e-3, (k, v)
         for n, q in grads.items():
             v = rel_err(q.grad.cpu(), p[n].grad)
             record_parity(group, n, v)
-            assert v < 5e-3, (n, v)
+            assert v < 1e-3, (n, v)
     else:
         for i, (f, r) in enumerate(zip(feats, ref)):
             v = _l2(f.detach().cpu(), r.detach())
@@ -275,19 +279,35 @@ def test_internimage_xl_one_step_shapes():
     assert float(dict(net.named_parameters())["levels.0.blocks.0.dcn.input_proj.weight"].grad.abs().max()) > 0
 
 
-def test_internimage_xl_at_512_batch_1_vs_oracle():
+@pytest.mark.parametrize("recipe", ["kink_free", "data_dependent"])
+def test_internimage_xl_at_512_batch_1_vs_oracle(recipe):
     """BASELINE configs[4] at size: InternImage-XL (models.py:92-104: 192..1536 channels, depths 5 5 24 5, 12..96 groups) on ONE 512 x 512
     tile -- DCNv3 level shapes 128^2 x 12 groups ... 16^2 x 96 groups, 16384 ... 256 rows per level, exactly what the segmentation
     fine-tune runs per device (intern-xl-upernet-512-imp-mtp-loveda.py: batch 1).  fp32 mode against the oracle's forward AND autograd at
-    this size (features 1e-3, input gradient and a spread of parameter gradients 5e-3); bf16 mode against the same oracle run as
+    this size (features 1e-3, input gradient and a spread of parameter gradients 1e-3 or 5e-3 by recipe, below); bf16 mode against the same oracle run as
     relative L2 (the throughput mode the benchmark times).  Offset / mask heads are re-drawn (they are zero at init, which would put
-    every sample exactly on a pixel centre -- a kink of the bilinear interpolation)."""
+    every sample exactly on a pixel centre -- a kink of the bilinear interpolation).
+
+    Two recipes for the offset heads.  Bilinear sampling is only piecewise differentiable: a sample within f32 rounding of a
+    cell edge gets one of two one-sided derivatives depending on the last bit of its position, and at this size (~70 M samples, positions
+    up to 128 px where one f32 ulp is 1.5e-5 px) hundreds of samples are that close for ANY continuous draw -- one flipped sample of level 0
+    moves `levels.0.blocks.0.dcn.offset.weight` by ~4e-3 of its maximum (one position in 16384, summed with random signs).
+      kink_free:       offset.bias puts every point at integer + [0.3, 0.7] px, offset.weight is scaled so that the data-dependent part stays
+                       below ~0.1 px: no sample within 0.05 px of an edge (asserted on the oracle's own offsets) -> north_star's 1e-3 on every
+                       fp32 gradient.  Deformation by up to 1.7 px and the whole offset / mask gradient path are still exercised.
+      data_dependent:  round 3's draw (weights N(0, 0.02), zero bias): offsets driven by the features, samples arbitrarily close to edges;
+                       features 1e-3, gradients held to 5e-3 (measured 4.0e-3 / 1.7e-3 on the two tensors upstream of the flipped samples)."""
     torch.manual_seed(11)
     ref_net = mtp_amd.internimage_xl(drop_path_rate=0.0, precision="fp32", feature_dtype=torch.float32)
     with torch.no_grad():
         for n, q in ref_net.named_parameters():
-            if ".dcn.offset.weight" in n or ".dcn.mask.weight" in n:
+            if ".dcn.mask.weight" in n:
                 q.normal_(0, 0.02)
+            if ".dcn.offset.weight" in n:
+                q.normal_(0, 0.02 if recipe == "data_dependent" else 0.012 / q.shape[1] ** 0.5)
+            if ".dcn.offset.bias" in n and recipe == "kink_free":
+                # pixel offset = offset_scale * bias = i + f, i in {-1, 0, 1}, f in [0.3, 0.7]
+                q.copy_((torch.randint(-1, 2, q.shape).float() + 0.3 + 0.4 * torch.rand(q.shape)) / 2.0)
             if n.endswith("gamma1") or n.endswith("gamma2"):
                 q.fill_(0.1)          # layer scale 1e-5 at init would hide the 39 DCNv3 layers behind the residual stream
     sd = {k: v.detach().clone() for k, v in ref_net.state_dict().items()}
@@ -296,11 +316,21 @@ def test_internimage_xl_at_512_batch_1_vs_oracle():
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     xr = img.clone().requires_grad_(True)
     torch.set_num_threads(min(64, os.cpu_count() or 1))
-    ref = IO.backbone_forward(xr, p, [5, 5, 24, 5], [12, 24, 48, 96], 2.0)
+    IO.PROBE = {}
+    try:
+        ref = IO.backbone_forward(xr, p, [5, 5, 24, 5], [12, 24, 48, 96], 2.0)
+        probe = dict(IO.PROBE)
+    finally:
+        IO.PROBE = None
+    assert probe["calls"] == 39
+    record_parity("internimage_xl_512_" + recipe, "min_edge_distance_px", probe["min_edge_distance"])
+    if recipe == "kink_free":
+        assert probe["min_edge_distance"] > 0.05, probe
+    gtol = 1e-3 if recipe == "kink_free" else 5e-3
     assert [tuple(f.shape) for f in ref] == [(1, 192, 128, 128), (1, 384, 64, 64), (1, 768, 32, 32), (1, 1536, 16, 16)]
     gs = [torch.randn(f.shape, generator=torch.Generator().manual_seed(300 + i)) / f[0].numel() ** 0.5 for i, f in enumerate(ref)]
     sum((f * g).sum() for f, g in zip(ref, gs)).backward()
-    names = ["patch_embed.conv1.weight", "levels.0.blocks.0.dcn.offset.weight", "levels.0.blocks.4.dcn.input_proj.weight", "levels.0.blocks.2.gamma1",
+    names = ["patch_embed.conv1.weight", "levels.0.blocks.0.dcn.offset.weight", "levels.0.blocks.0.dcn.offset.bias", "levels.2.blocks.7.dcn.offset.weight", "levels.0.blocks.4.dcn.input_proj.weight", "levels.0.blocks.2.gamma1",
              "levels.1.blocks.3.dcn.mask.weight", "levels.1.downsample.conv.weight", "levels.2.blocks.0.mlp.fc1.weight", "levels.2.blocks.23.dcn.output_proj.weight",
              "levels.2.blocks.11.dcn.dw_conv.0.weight", "levels.3.blocks.4.mlp.fc2.weight", "levels.3.blocks.0.norm1.0.weight"]
     for precision in ("fp32", "bf16"):
@@ -313,7 +343,7 @@ def test_internimage_xl_at_512_batch_1_vs_oracle():
         grads = dict(net.named_parameters())
         for n, q in grads.items():
             assert q.grad is not None and torch.isfinite(q.grad).all(), n
-        group = "internimage_xl_512_" + precision
+        group = "internimage_xl_512_%s_%s" % (recipe, precision)
         for i, (f, r) in enumerate(zip(feats, ref)):
             assert tuple(f.shape) == tuple(r.shape)
             v = rel_err(f.cpu(), r.detach()) if precision == "fp32" else _l2(f.cpu(), r)
@@ -321,12 +351,12 @@ def test_internimage_xl_at_512_batch_1_vs_oracle():
             assert v < (1e-3 if precision == "fp32" else 2e-2), (precision, i, v)
         v = rel_err(x.grad.cpu(), xr.grad) if precision == "fp32" else _l2(x.grad.cpu(), xr.grad)
         record_parity(group, "grad_img", v)
-        assert v < (5e-3 if precision == "fp32" else 0.15), (precision, v)
+        assert v < (gtol if precision == "fp32" else 0.15), (precision, v)
         for n in names:
             assert n in grads, n
             v = rel_err(grads[n].grad.cpu(), p[n].grad) if precision == "fp32" else _l2(grads[n].grad.cpu(), p[n].grad)
             record_parity(group, n, v)
-            assert v < (5e-3 if precision == "fp32" else 0.3), (precision, n, v)
+            assert v < (gtol if precision == "fp32" else 0.3), (precision, n, v)
         del net, feats, x
         torch.cuda.empty_cache()
 
