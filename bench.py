@@ -318,8 +318,13 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
-    ap.add_argument("--forward-only", action="store_true", help="additionally time the forward pass alone (inference mode, no saved activations): SURVEY 8d asks for "
-                    "forward-only numbers next to the step; reported as `forward_only`, never as `value`")
+    ap.add_argument("--no-forward-only", dest="forward_only", action="store_false",
+                    help="skip the extra pass that times the forward alone (inference mode, no saved activations; SURVEY 8d asks for forward-only "
+                         "numbers next to the step).  It runs AFTER the timed region and is reported as `forward_only`, never as `value`")
+    ap.add_argument("--forward-only", dest="forward_only", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.set_defaults(forward_only=True)
+    ap.add_argument("--use-ckpt", action="store_true", help="activation checkpointing (`use_ckpt='True'`, VIT:799-800): every block's forward is recomputed in the "
+                    "backward -- the recipe MTP pretrains with at 448^2 (Readme.md:233-240).  The recomputation is NOT counted in the step's flops")
     ap.add_argument("--gemm-shapes", action="store_true", help="print the per-shape table of the instrumented GEMM launches to stderr")
     ap.add_argument("--timer-every", type=int, default=10,
                     help="the per-launch HIP events behind `roofline` are recorded on every N-th timed step (step 0, N, 2N, ...): two events per "
@@ -375,7 +380,7 @@ def main():
 
     class A:
         image_size = args.image_size
-        use_ckpt = "False"
+        use_ckpt = "True" if args.use_ckpt else "False"
         precision = args.precision
     torch.manual_seed(2023)    # identical initial replicas (main_pretrain.py:107)
     if args.model == "internimage_xl":
@@ -588,6 +593,7 @@ def main():
                                       else (" (BASELINE configs[2]/[3])" if args.model == "vit_l" and B == 64 else " (BASELINE configs[1])" if args.model == "vit_b" and B == 32 else "")
                                       if args.image_size == 224 else " (not the headline configuration)"),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss),
+                       "activation_checkpointing": bool(args.use_ckpt),
                        "heads": ("3 stand-in task heads (per-map 1x1 projection + mean each; the mm* decoders are not vendored)" if args.heads == "standin3"
                                  else "1 stand-in segmentation head (per-map 1x1 projection to 7 classes + per-pixel cross-entropy vs fixed random labels, torch autograd; "
                                       "mmseg's UperNet is not vendored)" if args.heads == "standin_seg" else "sum_i mean(f_i)")},

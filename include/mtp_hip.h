@@ -66,23 +66,20 @@ typedef struct {
                          * summed into C by the callee (deterministic); NULL = f32 atomicAdd into zeroed C  */
     int64_t aux_ld;
     int split_k;        /* TN only: >1 = split the contraction over gridDim.y                               */
-    int variant;        /* 0 = default kernels and heuristics; other values force A/B choices (debug): bit0 NT register-
-                         * staged loads; bits1-2 tile order (1 plain, 2 grouped / M-fastest, 3 row-major); bit3 NT
-                         * double-buffered / TN single-stage; bit4 TN register-transposing; bit5 / bit6 force / forbid
-                         * the 256x128 8-wave NT tile; bit7 NT at 5 workgroups per CU (complete tiles only); bits8-9 the
-                         * 8-wave pipelined NT kernel (1 = tile height picked per problem, 2 = 224 x 256 tiles, 3 = 256 x 256 tiles),
-                         * bit10 forbids it; bits11-14 ablation builds of it (tools/ab_gemm.py); bit15 / bit16 force / forbid its
-                         * persistent-tile form; bit17 / bit18 force / forbid its stream-K form (needs `workspace`), bit19 = use it where
-                         * the built-in heuristic expects a gain; bits20-21 store policy of its epilogue (0 = by epilogue: nt, sc1 for the f32 residual form; 1 = nt, 2 = sc1 write-through, 3 = plain).  All variants of one problem give bit-identical results. */
+    int variant;        /* 0 = default kernels and heuristics; other values force A/B choices (debug / tests): bit0 NT register-
+                         * staged loads; bits1-2 tile order (1 plain, 2 grouped / M-fastest, 3 row-major); bit3 TN single-stage;
+                         * bit4 TN register-transposing; bit5 / bit6 force / forbid the 256x128 8-wave NT tile; bits8-9 the 8-wave
+                         * pipelined NT kernel (1 = tile height picked per problem, 2 = 224 x 256 tiles, 3 = 256 x 256 tiles), bit10
+                         * forbids it; bit15 / bit16 force / forbid its persistent-tile form; bits20-21 store policy of its epilogue
+                         * (0 = by epilogue: nt, sc1 for the f32 residual form; 1 = nt, 2 = sc1 write-through, 3 = plain).  All variants
+                         * of one problem give bit-identical results.  (Bits 7, 11-14, 17-19 selected kernels that were removed in
+                         * round 4 -- tools/ablation/ -- and are ignored.) */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
     int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them
                          * later with mtp_sum_partials_batch (one launch for the weight gradients of a whole block) */
     int pad_;
-    void* workspace;    /* NT only, optional: >= mtp_gemm_nt_workspace_bytes() of device memory, 256-byte aligned, ZERO when first
-                         * used and then left to the callee (flags of the stream-K form of the pipelined kernel: work cut along K per
-                         * XCD instead of rounded up to whole tiles; partial sums handed from one workgroup to another through it).
-                         * One workspace per stream: launches that may overlap must not share it.  NULL = that form is not used. */
+    void* workspace;    /* reserved (rounds 3: scratch of the stream-K form of the pipelined NT kernel, removed in round 4); ignored.   */
     int64_t workspace_bytes;
 } mtp_gemm_args;
 
@@ -93,7 +90,7 @@ int mtp_gemm_nt(const mtp_gemm_args* args, mtp_stream_t stream);
  * 256 x 256 x 64 kernel (bf16, K % 128 == 0, M % 8 == 0, N % 8 == 0), 128 = the 128-wide kernels (every other case, and f32).
  * Both families accumulate in the same k order: results are bit-identical. */
 int mtp_gemm_nt_tile(const mtp_gemm_args* args);
-/* bytes of `workspace` the stream-K form needs on this device (flags + one 256-KiB slot of partial sums per CU; 64.1 MB on MI355X) */
+/* bytes of `workspace` mtp_gemm_nt wants: 0 since round 4 (kept in the ABI for callers compiled against 0.3) */
 int64_t mtp_gemm_nt_workspace_bytes(void);
 /* weight gradient: C[m][n] = sum_k A[k][m] * B[k][n]  (dW = dY^T X), f32 output. */
 int mtp_gemm_tn(const mtp_gemm_args* args, mtp_stream_t stream);
@@ -123,6 +120,15 @@ int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
                       const float* dres, const float* extra, void* dx, int dx_dtype,
                       void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
                       float* dgamma_part, float* dbeta_part, int64_t part_ld, int64_t rows, int64_t C, mtp_stream_t stream);
+/* The same with a per-window addend of the incoming gradient: dy_eff[row] = dy[row] + win_add[window(row)] where the rows are the tokens
+ * (b, y, x) of a (B, Hp, Wp) grid and window(row) its 7 x 7 RVSA window (padding split as VIT:298-303; B * Hp * Wp == rows).  win_add:
+ * (B * nh * nw, C) f32 from mtp_rvsa_sampling_bwd_win -- norm1's backward then adds the sampling heads' input gradient while it reads the
+ * row anyway, instead of mtp_rvsa_sampling_bwd's read-modify-write pass over (T, C) (round 4).  No GELU form; f32 residual stream. */
+int mtp_layernorm_bwd_win(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                          const float* gamma, const float* dres, const float* extra, void* dx, int dx_dtype,
+                          void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
+                          float* dgamma_part, float* dbeta_part, int64_t part_ld, int64_t rows, int64_t C,
+                          const float* win_add, int64_t B, int64_t Hp, int64_t Wp, mtp_stream_t stream);
 /* out[c] (+)= sum_r part[r * ld + c], c < C   (per-workgroup partials -> parameter gradient; ld >= C lets one
  * partial buffer feed several parameters) */
 int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);
@@ -251,6 +257,8 @@ int mtp_rvsa_sampling_fwd(const void* x, int dtype, const float* w, const float*
                           int64_t B, int64_t Hp, int64_t Wp, int64_t C, int64_t N, mtp_stream_t stream);
 int mtp_rvsa_sampling_bwd(const float* dsamp, const float* w, const float* avg, void* dx, int dtype,
                           int64_t B, int64_t Hp, int64_t Wp, int64_t C, int64_t N, mtp_stream_t stream);
+/* the per-window factor of that update alone: g (windows, C) f32 = (dsamp . w) * leaky'(avg) / 49, for mtp_layernorm_bwd_win */
+int mtp_rvsa_sampling_bwd_win(const float* dsamp, const float* w, const float* avg, float* g, int64_t windows, int64_t C, int64_t N, mtp_stream_t stream);
 /* small f32 linear for the three 1x1 conv heads (VIT:231,236,242): y (R,N) = x (R,K) W(N,K)^T + b; and its backward */
 int mtp_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int64_t R, int64_t N, int64_t K, mtp_stream_t stream);
 int mtp_small_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t R, int64_t N, int64_t K, mtp_stream_t stream);

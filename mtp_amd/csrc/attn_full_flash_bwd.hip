@@ -396,7 +396,7 @@ int mtp_full_bwd_flash_launch(const void* qkv, const void* o, const void* dout, 
     const int64_t N = Hp * Wp;
     // (<= 256 tokens: measured at 14 x 14, B = 64: 579 us vs 590 us for the one-workgroup-per-(image, head) kernels -- 196 = 3 x 64 + 4
     //  wastes a quarter of the query workgroups; not worth a second code path)
-    if (N <= 256 || Hp > 64 || Wp > 64 || Wp < 10 || getenv("MTP_NO_FLASH_ATTN")) return MTP_ERR_UNSUPPORTED;
+    if (N <= 256 || Hp > 64 || Wp > 64 || Wp < 10) return MTP_ERR_UNSUPPORTED;
     if (!workspace) return MTP_ERR_ARG;
     FlashGeom g;
     g.N = (int)N; g.Hp = (int)Hp; g.Wp = (int)Wp; g.heads = (int)heads;

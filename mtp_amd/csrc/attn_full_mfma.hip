@@ -657,7 +657,7 @@ int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* 
     FGeom g;
     if (!make_fgeom(Hp, Wp, heads, g)) {
         const int64_t N = Hp * Wp;
-        if (N <= 256 || Hp > 64 || Wp > 64 || getenv("MTP_NO_FLASH_ATTN")) return MTP_ERR_UNSUPPORTED;
+        if (N <= 256 || Hp > 64 || Wp > 64) return MTP_ERR_UNSUPPORTED;
         const bool big = Hp > 32 || Wp > 32;          // tables of up to 127 rows: 8 row tiles each
         const dim3 grid((unsigned)(B * heads), (unsigned)((N + 63) / 64));
         if (big) {

@@ -611,8 +611,7 @@ bool v3_geom(int64_t Hp, int64_t Wp, int64_t heads, V3Geom& g) {
 }  // namespace
 
 bool mtp_full_v3_fits(int64_t Hp, int64_t Wp) {
-    static const bool off = getenv("MTP_ATTN_V3") && getenv("MTP_ATTN_V3")[0] == '0';     // MTP_ATTN_V3=0: the round-2 kernels (A/B)
-    return !off && Hp >= 1 && Wp >= 1 && Hp <= 16 && Wp <= 16;
+    return Hp >= 1 && Wp >= 1 && Hp <= 16 && Wp <= 16;
 }
 
 int mtp_full_v3_fwd_launch(const void* qkv, void* o, float* lse, const float* rel_h, const float* rel_w, int64_t B, int64_t Hp, int64_t Wp, int64_t heads,

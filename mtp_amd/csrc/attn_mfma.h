@@ -15,7 +15,7 @@ int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* 
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
 int mtp_full_bwd_mfma_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
                              float* drel_part, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
-// token grids of at most 16 x 16 (attn_full_v3.hip: row-aligned tiles, relative-position logits as MFMA k-slots); MTP_ATTN_V3=0 turns them off
+// token grids of at most 16 x 16 (attn_full_v3.hip: row-aligned tiles, relative-position logits as MFMA k-slots)
 bool mtp_full_v3_fits(int64_t Hp, int64_t Wp);
 int mtp_full_v3_fwd_launch(const void* qkv, void* o, float* lse, const float* rel_h, const float* rel_w, int64_t B, int64_t Hp, int64_t Wp, int64_t heads,
                            float scale, hipStream_t s);
@@ -25,12 +25,6 @@ int mtp_full_v3_bwd_launch(const void* qkv, const void* o, const void* dout, con
 int mtp_full_bwd_flash_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const float* rel_h, const float* rel_w,
                               float* drel_part, float* workspace, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s);
 
-// MTP_ATTN_VALU=1 forces the f32-VALU reference kernels also for bf16 I/O (A/B and debugging)
-static inline bool mtp_use_mfma_attn() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MTP_ATTN_VALU");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v == 1;
-}
+// bf16 I/O always takes the MFMA kernels; the f32-math VALU kernels of attn.hip serve f32 I/O (parity mode) and the grids the MFMA kernels
+// do not take
+static inline bool mtp_use_mfma_attn() { return true; }

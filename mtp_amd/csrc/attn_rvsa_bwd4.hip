@@ -142,17 +142,16 @@ constexpr int SMP_F = 10;
 // key-major phase, so the problem's critical path is 4x shorter and 12 waves share a CU (3 workgroups x 4) instead of 3.
 // LDS: Ks | Vs (K_sel / V_sel rows, later P^T / dS^T) | R2 = {K^T} then {Q^T | dO^T} | QR | dQR | tab | lses | delta | smp | vsum
 // ===================================================================================================================
-// MODE: the scatter form, known at compile time for the product path (4 = rvsa_scatter_gemm_kernel takes the dK_sel / dV_sel rows; the
-// atomic forms and the phase-timing ablation stay runtime switches of the MODE = -1 instantiation): the in-kernel scatter paths cost the
-// "gemm" instantiation 40 VGPRs and ~800 instructions of code it never runs.
+// MODE: the scatter form, a compile-time choice: 4 = rvsa_scatter_gemm_kernel takes the dK_sel / dV_sel rows (token grids it fits: the default),
+// 1 = f32 atomics per token tile inside this kernel (larger grids; MTP_RVSA_SCATTER=dense forces it).  (Round 1's per-(key, corner) atomics and
+// the phase-timing ablation switches were removed in round 4; measurements in DESIGN section 4.)
 template <int MODE>
 __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ samp, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse, bf16_t* __restrict__ dqkv, float* __restrict__ dkv, float* __restrict__ dsamp,
                                                             float* __restrict__ rel_part, float* __restrict__ tab_part,
                                                             const float* __restrict__ rel_h, const float* __restrict__ rel_w, const float* __restrict__ bias_table,
-                                                            RvsaGeom g, float scale, int dense_scatter_) {
-    const int dense_scatter = MODE >= 0 ? MODE : (dense_scatter_ & 15);
-    const int stop_after = MODE >= 0 ? 0 : (dense_scatter_ >> 4);   // stop_after: phase-timing ablation (tools/ab_rvsa.py)
+                                                            RvsaGeom g, float scale) {
+    constexpr int dense_scatter = MODE;
     __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
     __shared__ __attribute__((aligned(16))) char R2[2 * 64 * TP];
@@ -273,7 +272,6 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         }
     }
     __syncthreads();
-    if (stop_after == 1) return;
 
     // ================= phase A: wave = query tile; lane (query; 4 keys) -> dQ, dQR, P^T / dS^T images ===============
     {
@@ -348,7 +346,6 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
             }
         }
         __syncthreads();   // dQR / P^T / dS^T complete
-        if (stop_after == 2) return;
         float e[8], f[8];
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
@@ -370,7 +367,6 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         }
     }
     __syncthreads();   // K^T no longer needed: R2 becomes Q^T | dO^T
-    if (stop_after == 3) return;
     {   // ---- thread = (query = lane, 16-channel quarter = wave)
         const int tok = lane < 49 ? query_token(g, lane, wi, wj) : -1;
 #pragma unroll
@@ -388,7 +384,6 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         }
     }
     __syncthreads();
-    if (stop_after == 4) return;
     {   // ---- table gradients: wave = d tile
         float* rp = rel_part + (int64_t)blockIdx.x * 26 * HD;
         const int dt = wave;
@@ -423,7 +418,6 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                                                                        // (laid out like the parameter, (169, heads), it was 169 four-byte stores 64 B apart)
         }
     }
-    if (stop_after == 5) return;
     // ================= phase B: wave = key tile; lane (key; 4 queries) -> dK_sel^T, dV_sel^T, scatter, coordinate gradients ==
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
     {
@@ -463,9 +457,9 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
             *reinterpret_cast<uint2*>(Ks + o) = make_uint2(pack_bf16x2(dks[dt][0], dks[dt][1]), pack_bf16x2(dks[dt][2], dks[dt][3]));
             *reinterpret_cast<uint2*>(Vs + o) = make_uint2(pack_bf16x2(dvs[dt][0], dvs[dt][1]), pack_bf16x2(dvs[dt][2], dvs[dt][3]));
         }
-        if (dense_scatter == 4) {
+        if constexpr (dense_scatter == 4) {
             // "gemm" scatter: the rows just written to Ks / Vs leave the kernel (below); rvsa_scatter_gemm_kernel sums them per token
-        } else if (dense_scatter) {
+        } else {
             // dK_sel^T / dV_sel^T -> bf16 [d][key] images over Q^T | dO^T; the scatter itself runs after the coordinate
             // gradients, see the end of the kernel
 #pragma unroll
@@ -474,31 +468,10 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 *reinterpret_cast<uint2*>(R2 + o) = make_uint2(pack_bf16x2(dk2[dt][0], dk2[dt][1]), pack_bf16x2(dk2[dt][2], dk2[dt][3]));
                 *reinterpret_cast<uint2*>(R2 + 64 * TP + o) = make_uint2(pack_bf16x2(dv2[dt][0], dv2[dt][1]), pack_bf16x2(dv2[dt][2], dv2[dt][3]));
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key2 = 16 * kt + 4 * gq + r, k2 = key2 < 48 ? key2 : 48;
-                const float fx2 = smp[0 * 64 + k2], fy2 = smp[1 * 64 + k2];
-                const int x02 = __float_as_int(smp[2 * 64 + k2]), y02 = __float_as_int(smp[3 * 64 + k2]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float w;
-                    const int tok = key2 < 49 ? neighbour(g, x02, y02, fx2, fy2, k, w) : -1;
-                    if (tok >= 0) {
-                        float* drow = dkv + ((int64_t)b * N + tok) * (2 * C) + h * HD + fr;
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) {
-                            atomicAdd(drow + 16 * dt, w * dk2[dt][r]);
-                            atomicAdd(drow + C + 16 * dt, w * dv2[dt][r]);
-                        }
-                    }
-                }
-            }
         }
     }
     __syncthreads();   // dK_sel / dV_sel rows complete
-    if (stop_after == 6) return;
-    if (dense_scatter == 4) {
+    if constexpr (dense_scatter == 4) {
         // dK_sel | dV_sel (49 x 64 bf16 each) of this (image, window, head) -> the scratch buffer, row-major: 98 rows x 8 chunks of 16 B
         bf16_t* out = reinterpret_cast<bf16_t*>(dkv) + (int64_t)blockIdx.x * (2 * 49 * HD);
         for (int idx = tid; idx < 2 * 49 * 8; idx += 256) {
@@ -572,7 +545,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         const float sum = (vsum[tid] + vsum[8 + tid]) + (vsum[16 + tid] + vsum[24 + tid]);
         dp[tid < 2 ? 2 * h + tid : tid < 4 ? 2 * H + 2 * h + (tid - 2) : 4 * H + h] = sum;
     }
-    if (dense_scatter && dense_scatter != 4) {
+    if constexpr (dense_scatter != 4) {
         // ================= scatter of dK_sel / dV_sel through the bilinear weights, as a product on the matrix cores =========
         // dK[token][d] += sum_key W[token][key] dK_sel[key][d],  W = hat(ix_key - X_token) hat(iy_key - Y_token) -- the same four
         // corner weights, summed per TOKEN before they leave the workgroup.  The memory side retires ~31 G 64-byte f32 atomics/s
@@ -610,7 +583,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 bk[dt][kk] = ld8x2(dKt + o, dKt + o + 8);
                 bv[dt][kk] = ld8x2(dVt + o, dVt + o + 8);
             }
-        for (int ti = t_lo + wave; ti <= t_hi && dense_scatter != 2; ti += 4) {
+        for (int ti = t_lo + wave; ti <= t_hi; ti += 4) {
             const int tok = 16 * ti + fr, tyy = tok / g.Wp, txx = tok - tyy * g.Wp;
             const float X = (float)(txx + g.pad_l), Y = (float)(tyy + g.pad_t);
             const float live = tok < N ? 1.f : 0.f;
@@ -671,7 +644,7 @@ constexpr int SCB = 224;      // tokens per workgroup (band) = samples per stage
 // touch the band's token rows is skipped before its rows are loaded (for near-identity sampling a band sees the windows of its own rows
 // only, so larger grids cost about one chunk per band, not windows x bands).  <= 224 tokens (the 14 x 14 grid): one band, one chunk.
 __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t* __restrict__ dsel, const float* __restrict__ samp, bf16_t* __restrict__ dqkv,
-                                                                  RvsaGeom g, int ablate) {     // ablate (MTP_RVSA_GEMM_ABLATE): bit0 no product loop, bit1 no stores
+                                                                  RvsaGeom g) {
     __shared__ __attribute__((aligned(16))) char Kimg[SCB * 128];
     __shared__ __attribute__((aligned(16))) char Vimg[SCB * 128];
     __shared__ __attribute__((aligned(16))) float xs[SCB];
@@ -732,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t*
             *reinterpret_cast<uint4*>(Vimg + swz(sl, ch)) = vv;
         }
         __syncthreads();
-        for (int kk = 0; kk < ((ablate & 1) ? 0 : SCB / 32); ++kk) {
+        for (int kk = 0; kk < SCB / 32; ++kk) {
             const int s0 = 32 * kk + 4 * gq;
             const float4 xa = *reinterpret_cast<const float4*>(xs + s0), xb = *reinterpret_cast<const float4*>(xs + s0 + 16);
             const float4 ya = *reinterpret_cast<const float4*>(ys + s0), yb = *reinterpret_cast<const float4*>(ys + s0 + 16);
@@ -762,7 +735,6 @@ __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t*
     // results -> bf16 rows in LDS (over the K / V images, which nobody reads any more) -> whole 128-byte rows to global: out of the MFMA
     // layout a lane holds 4 channels of one token, i.e. 8-byte stores 6 KiB apart (measured: 11.5 of the kernel's 40 us)
     __syncthreads();
-    if (ablate & 2) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int tl = 16 * (wave + 4 * i) + fr;
@@ -799,13 +771,10 @@ RvsaGeom make_geom(int64_t Hp, int64_t Wp, int64_t heads) {
 }  // namespace
 
 // 4 = the scatter runs as rvsa_scatter_gemm_kernel (the caller then skips the clearing and conversion passes of the f32 scratch),
-// 1 = f32 atomics per token tile inside the backward kernel, 0 = per (key, corner) atomics, 2 = none (ablation)
+// 1 = f32 atomics per token tile inside the backward kernel
 int mtp_rvsa_bwd_mfma_scatter_mode(int64_t Hp, int64_t Wp, int64_t heads) {
-    static const int forced = []() {
-        const char* e = getenv("MTP_RVSA_SCATTER");   // "gemm" (default where it fits) | "dense" | "corner" | "none"
-        return !e ? -1 : e[0] == 'c' ? 0 : e[0] == 'n' ? 2 : e[0] == 'd' ? 1 : -1;
-    }();
-    if (forced >= 0) return forced;
+    static const bool dense = []() { const char* e = getenv("MTP_RVSA_SCATTER"); return e && e[0] == 'd'; }();   // MTP_RVSA_SCATTER=dense: the atomic form everywhere (tests)
+    if (dense) return 1;
     const RvsaGeom g = make_geom(Hp, Wp, heads);
     const int64_t N = Hp * Wp, nW = (int64_t)g.nh * g.nw;
     const bool fits = Hp <= 64 && Wp <= 64 && nW * (2 * 49 * HD * 2) <= N * 2 * HD * 4;   // (the rows live in the caller's f32 scratch)
@@ -816,21 +785,16 @@ int mtp_rvsa_bwd_mfma_launch(const void* qkv, const float* samp, const void* o, 
                              float* rel_part, float* tab_part, const float* rel_h, const float* rel_w, const float* bias_table,
                              int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     const RvsaGeom g = make_geom(Hp, Wp, heads);
-    static const int stop = []() {
-        const char* st = getenv("MTP_RVSA_STOP");     // phase-timing ablation: return after phase 1..6
-        return st ? atoi(st) : 0;
-    }();
     const int mode = mtp_rvsa_bwd_mfma_scatter_mode(Hp, Wp, heads);
-    if (mode == 4 && !stop)
-        hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel<4>, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
-                           (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, 4);
-    else
-        hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel<-1>, dim3((unsigned)(B * g.nh * g.nw * heads)), dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
-                           (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale, mode | (stop << 4));
-    if (mode == 4 && !stop) {
-        static const int abl = []() { const char* e = getenv("MTP_RVSA_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    const dim3 grid((unsigned)(B * g.nh * g.nw * heads));
+    if (mode == 4) {
+        hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
+                           (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale);
         const int64_t N = Hp * Wp;
-        hipLaunchKernelGGL(rvsa_scatter_gemm_kernel, dim3((unsigned)(B * heads), (unsigned)((N + SCB - 1) / SCB)), dim3(256), 0, s, (const bf16_t*)dkv, samp, (bf16_t*)dqkv, g, abl);
+        hipLaunchKernelGGL(rvsa_scatter_gemm_kernel, dim3((unsigned)(B * heads), (unsigned)((N + SCB - 1) / SCB)), dim3(256), 0, s, (const bf16_t*)dkv, samp, (bf16_t*)dqkv, g);
+    } else {
+        hipLaunchKernelGGL(rvsa_bwd4_mfma_kernel<1>, grid, dim3(256), 0, s, (const bf16_t*)qkv, samp, (const bf16_t*)o, (const bf16_t*)dout, lse,
+                           (bf16_t*)dqkv, dkv, dsamp, rel_part, tab_part, rel_h, rel_w, bias_table, g, scale);
     }
     return mtp_launch_status();
 }

@@ -871,12 +871,52 @@ __global__ __launch_bounds__(256) void rvsa_sampling_bwd_kernel(const float* __r
     }
 }
 
+// The same product, left per window: g (windows, C) f32 = (dsamp . w) * leaky'(avg) / 49 -- the LayerNorm backward that consumes dx adds it to
+// every token row of the window while it reads that row anyway (mtp_layernorm_bwd_win), instead of a read-modify-write pass over (T, C).
+__global__ __launch_bounds__(256) void rvsa_sampling_bwd_win_kernel(const float* __restrict__ dsamp, const float* __restrict__ w, const float* __restrict__ avg,
+                                                                   float* __restrict__ g, int C, int N) {
+    extern __shared__ __attribute__((aligned(16))) float ds[];     // dsamp row of this window
+    __shared__ float4 part[4][64];
+    const int win = blockIdx.x;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c4 = blockIdx.y * 64 + lane;
+    const bool live = c4 < C / 4;
+    for (int n = threadIdx.x; n < N; n += 256) ds[n] = dsamp[(int64_t)win * N + n];
+    __syncthreads();
+    const int nq = (N + 3) / 4, n0 = q * nq, n1 = (n0 + nq) < N ? (n0 + nq) : N;
+    float4 d = make_float4(0, 0, 0, 0);
+    if (live) {
+#pragma unroll 4
+        for (int n = n0; n < n1; ++n) {
+            const float4 ww = load4(w + (int64_t)n * C + 4 * c4);
+            const float t = ds[n];
+            d.x += t * ww.x; d.y += t * ww.y; d.z += t * ww.z; d.w += t * ww.w;
+        }
+    }
+    part[q][lane] = d;
+    __syncthreads();
+    if (!live || q) return;
+    const float4 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];   // the order of rvsa_sampling_bwd_kernel: same bits
+    d = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+    const float4 a = load4(avg + (int64_t)win * C + 4 * c4);
+    const float k = 1.0f / 49.0f;
+    *reinterpret_cast<float4*>(g + (int64_t)win * C + 4 * c4) =
+        make_float4(d.x * (a.x > 0 ? k : 0.01f * k), d.y * (a.y > 0 ? k : 0.01f * k), d.z * (a.z > 0 ? k : 0.01f * k), d.w * (a.w > 0 ? k : 0.01f * k));
+}
+
+extern "C" int mtp_rvsa_sampling_bwd_win(const float* dsamp, const float* w, const float* avg, float* g, int64_t windows, int64_t C, int64_t N, mtp_stream_t stream) {
+    if (!dsamp || !w || !avg || !g || windows <= 0 || C <= 0 || (C % 4) || N <= 0 || N > 4096) return MTP_ERR_ARG;
+    const dim3 grid((unsigned)windows, (unsigned)((C / 4 + 63) / 64)), block(256);
+    hipLaunchKernelGGL(rvsa_sampling_bwd_win_kernel, grid, block, sizeof(float) * (size_t)N, (hipStream_t)stream, dsamp, w, avg, g, (int)C, (int)N);
+    return mtp_launch_status();
+}
+
 extern "C" int mtp_rvsa_sampling_fwd(const void* x, int dtype, const float* w, const float* bias, float* avg, float* pooled, float* samp,
                                      int64_t B, int64_t Hp, int64_t Wp, int64_t C, int64_t N, mtp_stream_t stream) {
     if (!x || !w || !avg || !pooled || !samp || B <= 0 || Hp <= 0 || Wp <= 0 || C <= 0 || (C % 4) || C > 8192 || N <= 0) return MTP_ERR_ARG;
     int pt, pl, nh, nw;
     rvsa_geom(Hp, Wp, pt, pl, nh, nw);
-    static const int ysplit = []() { const char* e = getenv("MTP_SAMPLING_SPLIT"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 8 ? 8 : v; }();   // measured 24.1 / 18.1 / 19.3 us at 1 / 2 / 4
+    constexpr int ysplit = 2;   // workgroups per window: measured 24.1 / 18.1 / 19.3 us at 1 / 2 / 4
     const dim3 grid((unsigned)(B * nh * nw), (unsigned)(N >= 16 * ysplit ? ysplit : 1)), block(256);
     const size_t lds = sizeof(float) * (size_t)C;
     if (dtype == MTP_BF16)
@@ -1027,4 +1067,6 @@ extern "C" int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, c
     return mtp_launch_status();
 }
 
-extern "C" const char* mtp_version(void) { return "mtp_hip 0.1 (gfx950)"; }
+// 0.4: round 4 -- mtp_gemm_args as of round 3 (workspace / workspace_bytes trailing fields; now ignored: the stream-K form is gone),
+// mtp_gemm_tn_grouped honours split_k / aux.  Bump whenever a struct in include/mtp_hip.h changes size or a field changes meaning.
+extern "C" const char* mtp_version(void) { return "mtp_hip 0.4 (gfx950)"; }

@@ -202,55 +202,6 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     epilogue<Tout, EPI, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
-// Same single-stage structure at FIVE workgroups per CU (5 x 32 KiB = the whole LDS, <= 96 VGPRs): the tile loads are issued as
-// `global_load_lds_dwordx4 voffset, s[base]` from inline asm -- one 32-bit per-lane offset per operand plus scalar bases,
-// instead of the eight 64-bit per-lane pointers hipcc keeps live for the builtin (which spill at 96 VGPRs).  Complete tiles,
-// operands below 4 GiB.  (A/B: variant bit 7.)
-template <typename T, typename Tout, int EPI>
-__global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void gemm_nt_sb5_kernel(KArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int E = Elem<T>::kPerChunk;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile = (p.order & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    int m0, n0;
-    if (p.order & 2) {
-        const int tiles_m = (int)gridDim.x / p.tiles_n, per = 8 * p.tiles_n;
-        const int grp = tile / per, r = tile - grp * per;
-        const int gm = (tiles_m - grp * 8) < 8 ? (tiles_m - grp * 8) : 8;
-        m0 = (grp * 8 + r % gm) * BM;
-        n0 = (r / gm) * BN;
-    } else {
-        m0 = (tile / p.tiles_n) * BM;
-        n0 = (tile % p.tiles_n) * BN;
-    }
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int row0 = wave * 32 + (lane >> 3), chunk = (lane & 7) ^ (row0 & 7);   // rows row0 + 8i share the swizzle
-    const uint32_t offA = (uint32_t)(((int64_t)(m0 + row0) * p.lda + chunk * E) * (int64_t)sizeof(T));
-    const uint32_t offB = (uint32_t)(((int64_t)(n0 + row0) * p.ldb + chunk * E) * (int64_t)sizeof(T));
-    const int64_t strA = 8 * p.lda * (int64_t)sizeof(T), strB = 8 * p.ldb * (int64_t)sizeof(T);
-    const uint32_t ldsA = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + wave * 32 * ROW_BYTES;
-    const uint32_t ldsB = ldsA + OPER_BYTES;
-    for (int kt = 0; kt < p.k_tiles; ++kt) {
-        const char* ka = p.A + (int64_t)kt * 8 * E * (int64_t)sizeof(T);
-        const char* kb = p.B + (int64_t)kt * 8 * E * (int64_t)sizeof(T);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(offA), "s"(ka + i * strA), "s"(ldsA + i * 8 * ROW_BYTES) : "memory");
-            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(offB), "s"(kb + i * strB), "s"(ldsB + i * 8 * ROW_BYTES) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        compute_stage<T>(smem, smem + OPER_BYTES, acc, wm, wn, lane);
-        __syncthreads();
-    }
-    epilogue<Tout, EPI, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
-}
-
 // 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), one 48 KiB stage, 2 workgroups per CU: same occupancy and per-wave work as
 // the kernel above with 25 % fewer L2->LDS bytes per flop (A tile shared by 2 x more columns).  Selected for wide N only
 // (the tile count of N = 1024 problems would leave CUs idle).
@@ -627,8 +578,6 @@ int fill_common(const mtp_gemm_args* a, KArgs& k) {
     k.order = (a->variant >> 1) & 3;
     k.split_stride = 0;
     k.colsum = nullptr;
-    k.sk_ws = (a->workspace && !((uintptr_t)a->workspace & 255)) ? a->workspace : nullptr;
-    k.sk_ws_bytes = k.sk_ws ? (size_t)a->workspace_bytes : 0;
     return 0;
 }
 
@@ -664,43 +613,31 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     // when the problem does not fit it
     if constexpr (sizeof(T) == 2) {
         const int p8 = nt_p8_mode(a, k);
-        // variant bit 22: the co-resident 4-wave form (gemm_c2.hip: 256 x 128 tiles, two workgroups per CU) wherever the pipelined kernel fits
-        if (p8 && (a->variant & (1 << 22)))
-            return mtp_nt_c2_launch(k, a->out_dtype, EPI, ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 20) & 3) << 13), stream);
-        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 11) & 15) << 4) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 17) & 7) << 10) | (((a->variant >> 20) & 3) << 13), stream);
+        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 20) & 3) << 13), stream);
     }
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);
     const bool glds = ((a->variant & 1) == 0) && (a->K % (8 * E) == 0);
-    // default = single-stage / 4 workgroups per CU (measured +20 % over the double-buffered 2-per-CU kernel on every ViT-L
-    // shape: 827 / 707 / 825 / 910 vs 675 / 590 / 674 / 769 TF/s); variant bit 3 selects the double-buffered kernel
+    // single-stage / 4 workgroups per CU (round 1: +20 % over a double-buffered 2-per-CU LDS-DMA kernel on every ViT-L shape; that kernel
+    // is gone since round 4 -- the register-staged form below stays for ragged K and as variant bit 0)
     // tile order of the single-stage kernel: variant bits 1-2 = 0 auto, 1 plain blockIdx, 2 grouped, 3 row-major with XCD remap.
     // Grouped (panels of 8 tile rows) measured +2..7 % at N = 3072 and +8..11 % at N = 4096, -2..3 % at N = 1024.
     const int ord = (a->variant >> 1) & 3;
     k.order = ord == 0 ? (k.tiles_n > 8 ? 2 : 0) : ord == 1 ? 1 : ord == 2 ? 2 : 0;
-    if (!(glds && !(a->variant & 8))) k.order = ord;   // the double-buffered kernels keep their own meaning of the bits
+    if (!glds) k.order = ord;   // the register-staged kernel keeps its own meaning of the bits
     // 256 x 128 tile / 8 waves when the whole problem is ONE round of such workgroups on the 256 CUs (2 per CU) and every CU
     // gets at least one: measured on M = 12544, N = 1024 (392 workgroups): +7.5 % (K = 1024), +17..18 % (K = 3072, 4096; up to
     // 1095 TF/s); with several rounds (N = 3072: equal, N = 4096: -5 %) the coarser tiles lose to the tail.  Variant bit 5
     // forces it, bit 6 forbids it.
-    const bool fits32 = (uint64_t)a->M * (uint64_t)a->lda * sizeof(T) < (1ull << 32) && (uint64_t)a->N * (uint64_t)a->ldb * sizeof(T) < (1ull << 32);
-    const bool full_tiles = (a->M % BM == 0) && (a->N % BN == 0);
-    if (glds && (a->variant & 128) && full_tiles && fits32) {   // 5 workgroups per CU (A/B)
-        if (ord == 0) k.order = k.tiles_n > 8 ? 2 : 0;
-        hipLaunchKernelGGL((gemm_nt_sb5_kernel<T, Tout, EPI>), grid, block, STAGE_BYTES, stream, k);
-        return mtp_launch_status();
-    }
     const int tiles_m8 = (k.M + NT8_BM - 1) / NT8_BM;
     const bool one_round = tiles_m8 * k.tiles_n >= 256 && tiles_m8 * k.tiles_n <= 512;
-    if (glds && !(a->variant & 8) && ((a->variant & 32) || (one_round && !(a->variant & 64)))) {
+    if (glds && ((a->variant & 32) || (one_round && !(a->variant & 64)))) {
         if (ord == 0) k.order = k.tiles_n > 8 ? 2 : 0;
         hipLaunchKernelGGL((gemm_nt_sb8_kernel<T, Tout, EPI>), dim3(tiles_m8 * k.tiles_n), dim3(NT8_THREADS), NT8_STAGE_BYTES, stream, k);
         return mtp_launch_status();
     }
-    if (glds && !(a->variant & 8))
+    if (glds)
         hipLaunchKernelGGL((gemm_nt_sb_kernel<T, Tout, EPI>), grid, block, STAGE_BYTES, stream, k);
-    else if (glds)
-        hipLaunchKernelGGL((gemm_nt_kernel<T, Tout, EPI, true>), grid, block, LDS_BYTES, stream, k);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<T, Tout, EPI, false>), grid, block, LDS_BYTES, stream, k);
     return mtp_launch_status();
@@ -815,7 +752,8 @@ extern "C" int mtp_gemm_nt(const mtp_gemm_args* a, mtp_stream_t stream) {
     return MTP_ERR_UNSUPPORTED;
 }
 
-extern "C" int64_t mtp_gemm_nt_workspace_bytes(void) { return (int64_t)mtp_nt_p8_workspace_bytes(); }
+// (round 4: the stream-K form that used `workspace` was removed -- measured slower; the query stays in the ABI and answers 0)
+extern "C" int64_t mtp_gemm_nt_workspace_bytes(void) { return 0; }
 
 extern "C" int mtp_gemm_nt_tile(const mtp_gemm_args* a) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return MTP_ERR_ARG;

@@ -3,13 +3,6 @@
 #pragma once
 #include "common.h"
 
-struct SkSplit {             // stream-K split of the NT kernel (gemm_p8.hip), per XCD
-    int cpx, ppt;            // workgroups per XCD, k-tile pairs per tile
-    int tail_kp0[8];         // first k-tile pair of the XCD's TAIL piece (0 = none)
-    int head_np[8];          // k-tile pairs of its HEAD piece (0 = none)
-    int s_full0[8], nfull[8];   // its whole super-tiles; the tail's super-tile is s_full0 - 1, the head's s_full0 + nfull
-};
-
 struct KArgs {
     const char* A;
     const char* B;
@@ -32,25 +25,13 @@ struct KArgs {
     int order;              // tile order experiment: bit0 = no XCD remap, bit1 = M-fastest instead of N-fastest
     int64_t split_stride;   // TN split-K with workspace: partial tile of split z lives at C + z*split_stride (f32 elements)
     float* colsum;          // TN (transpose-read kernel): colsum[m] += sum_k A[k][m], or nullptr
-    void* sk_ws;            // NT stream-K (gemm_p8.hip): caller's workspace (flags | status | partial-sum slots), or nullptr
-    size_t sk_ws_bytes;
-    SkSplit sk;
 };
 
 // gemm_p8.hip: 256 x 256 x 64 tile, 8 waves, 8-phase LDS-DMA pipeline (bf16 NT, complete K tiles).  flags: bit0 = 224-row tiles,
-// bit2 = 256-row tiles (neither: picked per problem), bit1 = plain tile order (no XCD remap / grouping), bits 4-7 = ablation switches (gemm_p8.hip: XP).  Returns MTP_ERR_UNSUPPORTED when the
+// bit2 = 256-row tiles (neither: picked per problem), bit1 = plain tile order (no XCD remap / grouping), bits 8 / 9 = force / forbid persistent tiles, bits 13-14 = store policy of the epilogue.  Returns MTP_ERR_UNSUPPORTED when the
 // problem does not fit the kernel's preconditions (the caller then uses the 128-wide kernels of gemm.hip).
 int mtp_nt_p8_launch(const KArgs& k, int out_dtype, int epilogue, int flags, hipStream_t stream);
 int mtp_nt_p8_fits(const KArgs& k, int out_dtype, int epilogue);   // 1 when mtp_nt_p8_launch would run the problem
-size_t mtp_nt_p8_workspace_bytes();                                // what the stream-K form of the kernel needs in KArgs::sk_ws
-
-// gemm_c2.hip: the same pipeline on 256 x 128 tiles with 4 waves, two co-resident workgroups per CU (same preconditions and flags bits 1,
-// 13-14 as mtp_nt_p8_launch)
-int mtp_nt_c2_launch(const KArgs& k, int out_dtype, int epilogue, int flags, hipStream_t stream);
-
-// gemm_tn_w4.hip: the grouped weight-gradient GEMM on 4 waves x (128 x 128) of 32x32x16 MFMAs; arguments already validated by
-// mtp_gemm_tn_grouped (gemm_tn_p8.hip)
-int mtp_gemm_tn_grouped_w4(const mtp_gemm_args* args, int count, hipStream_t stream);
 
 namespace {
 

@@ -251,186 +251,6 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
-// ---- stream-K at XCD granularity (round 3) -------------------------------------------------------------------------------------------
-// What the persistent kernel above leaves on the table at K = 1024 (fc1 forward: 132 us for a main loop that needs 84): every CU
-// runs the SAME sequence main loop -> epilogue at the same time, so the chip alternates between "all matrix pipes busy, HBM idle"
-// and "all CUs storing 58 MB at once, matrix pipes idle", and a problem of 3.5 rounds of tiles takes 4.  Here the work is cut along
-// K instead of being rounded up to whole tiles, ONE XCD AT A TIME:
-//   * the tiles are grouped into super-tiles of CPX = gridDim.x / 8 consecutive tiles (panel order: 8 tile rows x 4 tile columns at
-//     CPX = 32); workgroup (xcd = blockIdx % 8, c = blockIdx / 8) always works on tile 32 s + c of a super-tile s, so the 32 CUs of
-//     an XCD stay in lock step on tiles that share their operand panels through that XCD's L2 -- as they do today;
-//   * the NS super-tiles x PPT k-tile pairs form one line of NS * PPT "super-pairs"; XCD x takes the contiguous range
-//     [x * SP / 8, (x + 1) * SP / 8).  A range starts / ends inside a super-tile: its pieces are a HEAD (pairs [0, h) of the last
-//     super-tile it touches), whole super-tiles, and a TAIL (pairs [t, PPT) of the first one).  Every XCD does exactly SP / 8 pairs
-//     (no rounding to whole tiles: 2.625 / 3.5 tile-times instead of 3 / 4) and the XCDs' epilogues are spread over the tile period
-//     (offsets 5 x / 8 of a tile for 2.625, 0 / 4 for 3.5), so one XCD stores while the others multiply;
-//   * HEAD first, TAIL last: the head's accumulators are published early (write-through stores + flag) and the workgroup at the
-//     same position c of XCD x + 1 starts its tail from them ~2 tile-times later -- the k order of every output element is unchanged
-//     (k ascending, same MFMA chain): results stay bit-identical to every other NT kernel.
-// Hand-off (MI355X guide, Guideline 16, form R1): partial sums leave as 16-byte `sc1` (write-through) buffer stores, every wave drains
-// `vmcnt(0)`, barrier, one lane stores the flag (relaxed, agent scope); the consumer polls that word from ONE lane (relaxed, s_sleep,
-// bounded), takes ONE agent-scope acquire, resets the flag for the next launch, barrier, and loads with `sc1`.  The producer never
-// waits for anything before publishing, so no placement or dispatch order can deadlock it; a consumer that gives up (bounded spin)
-// raises the status word instead of hanging the GPU.
-constexpr int SK_FLAG_WORDS = 16;                 // one flag per 64-byte line
-constexpr int SK_STATUS_OFF = 16384, SK_SLOT0 = 65536, SK_SLOT_BYTES = 262144;   // bytes: 256 flags | status | one slot per workgroup
-constexpr unsigned SK_SPIN_LIMIT = 1u << 22;      // x s_sleep 8 (~0.25 us): ~1 s
-typedef __attribute__((address_space(1))) unsigned int gu32_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32v4_t;
-
-struct SkItem {
-    int tile, kp0, np, kind;   // kind: 0 = whole tile, 1 = head (publish the partial sums), 2 = tail (continue from the partial sums)
-};
-// the q-th piece of XCD `x` (HEAD, whole super-tiles, TAIL; the split itself comes from the host: KArgs::sk), skipping pieces whose
-// tile does not exist (ragged last super-tile); q is advanced past the piece returned
-__device__ __forceinline__ bool sk_next(const KArgs& p, int x, int cpos, int ntiles, int& q, SkItem& it) {
-    const int head_np = p.sk.head_np[x], tail_kp0 = p.sk.tail_kp0[x], nfull = p.sk.nfull[x];
-    const int has_head = head_np != 0, has_tail = tail_kp0 != 0;
-    const int n = has_head + nfull + has_tail;
-    for (; q < n; ++q) {
-        int s;
-        if (has_head && q == 0) { s = p.sk.s_full0[x] + nfull; it.kp0 = 0; it.np = head_np; it.kind = 1; }
-        else if (q - has_head < nfull) { s = p.sk.s_full0[x] + q - has_head; it.kp0 = 0; it.np = p.sk.ppt; it.kind = 0; }
-        else { s = p.sk.s_full0[x] - 1; it.kp0 = tail_kp0; it.np = p.sk.ppt - tail_kp0; it.kind = 2; }
-        it.tile = s * p.sk.cpx + cpos;
-        if (it.tile < ntiles) { ++q; return true; }
-    }
-    return false;
-}
-
-template <typename Tout, int EPI, int MI1>
-__global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_p8_sk_kernel(KArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WROWS = 64 + 16 * MI1, BM = 2 * WROWS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int fr = lane & 15, g = lane >> 4;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.tiles_n, ntiles = tiles_m * tiles_n;
-
-    P8Ctx c;
-    {
-        const uint32_t lanepart = (uint32_t)(fr * 128 + ((g ^ (fr & 7)) << 4));
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            c.addrA[b][0] = lds0 + b * P8_BUF + wr * 8192 + lanepart;
-            c.addrA[b][1] = lds0 + b * P8_BUF + wr * 8192 + (lanepart ^ 64u);
-            c.addrA1[b][0] = lds0 + b * P8_BUF + wr * (MI1 * 2048) + lanepart;
-            c.addrA1[b][1] = lds0 + b * P8_BUF + wr * (MI1 * 2048) + (lanepart ^ 64u);
-            c.addrB[b][0] = lds0 + b * P8_BUF + wc * 4096 + lanepart;
-            c.addrB[b][1] = lds0 + b * P8_BUF + wc * 4096 + (lanepart ^ 64u);
-        }
-        c.m0base = lds0 + wave * 2048;
-    }
-    const uint32_t lanesrc = (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
-    const uint32_t voffA0 = (uint32_t)((lane >> 3) * (int)p.lda * 2) + lanesrc;
-    const uint32_t voffB0 = (uint32_t)((lane >> 3) * (int)p.ldb * 2) + lanesrc;
-
-    // ---- this XCD's range of the super-pair line (split on the host: p8_sk_plan)
-    const int xcd = (int)blockIdx.x & 7, cpos = (int)blockIdx.x >> 3;
-    char* const ws = reinterpret_cast<char*>(p.sk_ws);
-    gu32_t* const flags = (gu32_t*)(uintptr_t)ws;
-    // slot / flag of the head this workgroup publishes, and of the head (XCD - 1, same position) its tail continues
-    const int my_slot = xcd * p.sk.cpx + cpos, in_slot = my_slot - p.sk.cpx;
-
-    int q = 0;
-    SkItem cur, nxt;
-    if (!sk_next(p, xcd, cpos, ntiles, q, cur)) return;
-    int tm, tn;
-    tile_coords(cur.tile, tiles_m, tiles_n, 0, tm, tn);
-    int m0 = tm * BM, n0 = tn * P8_BN;
-    p8_tile_sources<MI1>(p, c, wave, m0, n0, voffA0 + (uint32_t)cur.kp0 * 256u, voffB0 + (uint32_t)cur.kp0 * 256u);
-    p8_issue_prologue(c);
-
-    u32x4_t a[2][4], b0[2][2], b1[2][2];
-    f32x4_t acc[4][8];
-    for (;;) {
-        if (cur.kind == 2) {
-            // ---- continue from the partial sums of (XCD - 1, same position): poll -> ONE acquire -> reset -> barrier -> sc1 loads
-            if (tid == 0) {
-                gu32_t* f = flags + (size_t)in_slot * SK_FLAG_WORDS;
-                unsigned spins = 0;
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > SK_SPIN_LIMIT) {     // never seen in a healthy launch: report instead of hanging the device
-                        __hip_atomic_store((gu32_t*)(uintptr_t)(ws + SK_STATUS_OFF), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws + SK_SLOT0 + (size_t)in_slot * SK_SLOT_BYTES, 0, SK_SLOT_BYTES, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j < 4 + MI1)
-                        acc[i][j] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (i * 8 + j) * (P8_THREADS * 16), 16));
-                    else
-                        acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                }
-            // retire them HERE, with a wait the compiler sees: left to hipcc, the first use of the accumulators is inside the main loop and
-            // its bookkeeping puts an `s_waitcnt vmcnt(0)` into the loop body (every iteration would drain the DMA stream)
-            __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-
-        wait_vm<12>();   // S_0, S_1 have landed (this lane's pieces)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        nt_read_b<KB1, 0>(c, b1);
-        wait_b(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
-        __builtin_amdgcn_sched_barrier(0);
-
-        for (int it = 0; it < cur.np - 1; ++it) two_tiles<NtOps<MI1>, false, 0>(c, a, b0, b1, acc);
-        two_tiles<NtOps<MI1>, true, 0>(c, a, b0, b1, acc);
-
-        __builtin_amdgcn_sched_barrier(0);
-        if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align
-        __builtin_amdgcn_sched_barrier(0);
-
-        const int em0 = m0, en0 = n0;
-        const bool more = sk_next(p, xcd, cpos, ntiles, q, nxt);
-        if (more) {   // the ring is idle: the next piece's first two K-tiles go out before this piece's stores
-            tile_coords(nxt.tile, tiles_m, tiles_n, 0, tm, tn);
-            m0 = tm * BM; n0 = tn * P8_BN;
-            p8_tile_sources<MI1>(p, c, wave, m0, n0, voffA0 + (uint32_t)nxt.kp0 * 256u, voffB0 + (uint32_t)nxt.kp0 * 256u);
-            p8_issue_prologue(c);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (cur.kind == 1) {
-            // ---- publish the partial sums (accumulators as they lie: 16 B per lane, 8 KiB per wave-wide instruction group, write-through)
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws + SK_SLOT0 + (size_t)my_slot * SK_SLOT_BYTES, 0, SK_SLOT_BYTES, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4 + MI1; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32v4_t, acc[i][j]), rsrc, tid * 16, (i * 8 + j) * (P8_THREADS * 16), 16);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains (its stores and the next piece's DMA)
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(flags + (size_t)my_slot * SK_FLAG_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!more) break;
-        } else {
-            epilogue_lds16<Tout, EPI, WROWS>(p, acc, smem + P8_LDS + wave * 4096, em0 + wr * WROWS, en0 + wc * 64, lane);
-            if (!more) break;
-            __builtin_amdgcn_sched_barrier(0);
-            wait_vm<0>();   // stores and side loads of the epilogue retired: only the DMA stream is counted from here on
-        }
-        cur = nxt;
-    }
-}
-
 int p8_cus() {
     static int ncu = 0;
     if (!ncu) {
@@ -452,33 +272,6 @@ int launch_p8_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
     return mtp_launch_status();
 }
 
-// workspace of the stream-K kernel: 256 flags (one per 64-B line) | status word | one 256-KiB slot of partial sums per workgroup
-size_t p8_sk_workspace_bytes() { return (size_t)SK_SLOT0 + (size_t)p8_cus() * SK_SLOT_BYTES; }
-
-// the split: XCD x takes super-pairs [x * SP / 8, (x + 1) * SP / 8) of the NS * PPT line (see the kernel's header)
-void p8_sk_plan(KArgs& a, int ntiles) {
-    const int cpx = p8_cus() / 8, ppt = a.k_tiles / 2;
-    const int64_t ns = (ntiles + cpx - 1) / cpx, sp = ns * ppt;
-    a.sk.cpx = cpx;
-    a.sk.ppt = ppt;
-    for (int x = 0; x < 8; ++x) {
-        const int64_t lo = sp * x / 8, hi = sp * (x + 1) / 8;
-        a.sk.tail_kp0[x] = (int)(lo % ppt);
-        a.sk.head_np[x] = (int)(hi % ppt);
-        a.sk.s_full0[x] = (int)((lo + ppt - 1) / ppt);
-        a.sk.nfull[x] = (int)(hi / ppt) - a.sk.s_full0[x];
-    }
-}
-
-template <typename Tout, int EPI, int MI1>
-int launch_p8_sk_kernel(const KArgs& a, hipStream_t stream) {
-    constexpr int LDS = P8_LDS + 8 * 4096;
-    static unsigned long long optin = 0;
-    if (const int e = mtp_optin_lds((const void*)gemm_nt_p8_sk_kernel<Tout, EPI, MI1>, LDS, optin)) return e;
-    hipLaunchKernelGGL((gemm_nt_p8_sk_kernel<Tout, EPI, MI1>), dim3(p8_cus()), dim3(P8_THREADS), LDS, stream, a);
-    return mtp_launch_status();
-}
-
 // rows per tile: whole rounds of one workgroup per CU cost (rows per tile) each -- take the cheaper of 256 and 224
 int p8_pick_bm(int64_t M, int64_t N) {
     const int64_t cus = p8_cus(), tn = (N + P8_BN - 1) / P8_BN;
@@ -497,36 +290,9 @@ int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
     a.order = (flags >> 1) & 1;
     a.atomic_out = 0;
     const int ntiles = tiles_m * tiles_n;
-    if constexpr (EPI == MTP_EPI_BIAS && sizeof(Tout) == 2) {   // ablation builds of the plain bf16 kernel only
-        switch ((flags >> 4) & 15) {
-            case 0: break;
-            case 1: return launch_p8_kernel<Tout, EPI, 4, 1>(a, ntiles, stream);
-            case 2: return launch_p8_kernel<Tout, EPI, 4, 2>(a, ntiles, stream);
-            case 4: return launch_p8_kernel<Tout, EPI, 4, 4>(a, ntiles, stream);
-            case 8: return launch_p8_kernel<Tout, EPI, 4, 8>(a, ntiles, stream);
-            case 12: return launch_p8_kernel<Tout, EPI, 4, 12>(a, ntiles, stream);
-            case 15: return launch_p8_kernel<Tout, EPI, 4, 16>(a, ntiles, stream);   // (the variant field is 4 bits wide: 15 = direct epilogue)
-            default: return MTP_ERR_UNSUPPORTED;
-        }
-    }
     // persistent tiles: default for problems of more than one round of 224-row tiles (measured, tools/ab_gemm.py: +3...4 % at N = 3072 /
     // 4096, K = 1024 and on the FPN GEMM, nothing to gain on one-round problems; the 256-row instantiations spill 2-17 VGPRs with the
-    // second tile loop and stay opt-in).  variant bit 15 forces it, bit 16 forbids it (A/B).
-    // stream-K at XCD granularity (above), always on 224-row tiles (the 256-row instantiations spill): needs the caller's workspace,
-    // 8 XCD-sized groups of workgroups (grid = CUs, a multiple of 8, <= 256 flags) and at least one whole tile of work per
-    // workgroup.  flags bit 10 asks for it, bit 11 forbids it, bit 12 = wherever the heuristic expects a gain: more than one round
-    // of tiles whose rounds do not come out even, or short tiles (K <= 2048: the epilogue is a large part of a tile's time) --
-    // measured per shape with tools/ab_gemm.py.
-    if (!(flags & 2048) && (flags & (1024 | 4096)) && k.sk_ws) {
-        const int cus = p8_cus(), cpx = cus / 8;
-        const int t224 = (int)((k.M + 223) / 224) * tiles_n;
-        const bool sk_can = k.sk_ws_bytes >= p8_sk_workspace_bytes() && cus % 8 == 0 && cus <= 256 && cpx > 0 && (t224 + cpx - 1) / cpx >= 8 && t224 > cus;
-        const bool sk_auto = (t224 % cus) != 0 || k.K <= 2048;
-        if (sk_can && ((flags & 1024) || sk_auto)) {
-            p8_sk_plan(a, t224);
-            return launch_p8_sk_kernel<Tout, EPI, 3>(a, stream);
-        }
-    }
+    // second tile loop and stay opt-in).  flags bit 8 forces it, bit 9 forbids it (A/B).
     const bool persist = (flags & 256) || (!(flags & 512) && bm == 224 && ntiles > p8_cus());
     // store policy of the epilogue (224-row tiles; flags bits 13-14: 0 = by epilogue, 1 = nt, 2 = sc1 write-through, 3 = plain).  Measured with
     // rotating output buffers (tools/ab_gemm.py, MTP_AB_ROTATE=8: in the training step every GEMM writes fresh memory) and in the step
@@ -566,8 +332,6 @@ int mtp_nt_p8_fits(const KArgs& k, int out_dtype, int epi) {
     if (out_dtype == MTP_BF16) return epi == MTP_EPI_BIAS || epi == MTP_EPI_BIAS_GELU || epi == MTP_EPI_DGELU || epi == MTP_EPI_BIAS_GELU_DG || epi == MTP_EPI_MUL;
     return out_dtype == MTP_F32 && epi == MTP_EPI_BIAS;
 }
-
-size_t mtp_nt_p8_workspace_bytes() { return p8_sk_workspace_bytes(); }
 
 int mtp_nt_p8_launch(const KArgs& k, int out_dtype, int epi, int flags, hipStream_t stream) {
     if (!mtp_nt_p8_fits(k, out_dtype, epi)) return MTP_ERR_UNSUPPORTED;

@@ -255,7 +255,6 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     if (count > TN_MAX_PROBLEMS) return MTP_ERR_UNSUPPORTED;
     TnGroup g = {};
     int64_t tiles = 0;
-    bool plain256 = true;
     for (int i = 0; i < count; ++i) {
         const mtp_gemm_args& a = args[i];
         if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return MTP_ERR_ARG;
@@ -271,7 +270,6 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
             kchunk = ((a.K / 128 + splits - 1) / splits) * 128;
             splits = (int)((a.K + kchunk - 1) / kchunk);
         }
-        if ((a.M % P8_BM) || (a.N % P8_BN) || splits > 1) plain256 = false;
         TnProb& q = g.p[i];
         q.A = (const char*)a.A; q.B = (const char*)a.B; q.C = splits > 1 ? (float*)a.aux : (float*)a.C; q.colsum = a.colsum;
         q.M = (int)a.M; q.N = (int)a.N; q.K = (int)a.K;
@@ -285,12 +283,9 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     g.nprob = count;
     g.ntiles = (int)tiles;
     g.plain = (args[0].variant >> 1) & 1;
-    // the 4-wave 32x32x16 form (gemm_tn_w4.hip): variant bit 5 of the first problem asks for it, bit 6 forbids it
-    if ((args[0].variant & 32) && !(args[0].variant & 64) && plain256) return mtp_gemm_tn_grouped_w4(args, count, (hipStream_t)stream);
-    const int xp = (args[0].variant >> 11) & 15;   // ablation builds (tools/ab_wgrad.py): 2 = no stagger, 8 = no MFMAs
-    void (*kern)(TnGroup) = xp == 2 ? gemm_tn_p8_kernel<2> : xp == 8 ? gemm_tn_p8_kernel<8> : gemm_tn_p8_kernel<0>;
-    static unsigned long long optin[3] = {0, 0, 0};     // 128 KiB of dynamic LDS: opt-in once per kernel and device
-    if (const int e = mtp_optin_lds((const void*)kern, P8_LDS, optin[xp == 2 ? 1 : xp == 8 ? 2 : 0])) return e;
+    void (*kern)(TnGroup) = gemm_tn_p8_kernel<0>;
+    static unsigned long long optin = 0;     // 128 KiB of dynamic LDS: opt-in once per kernel and device
+    if (const int e = mtp_optin_lds((const void*)kern, P8_LDS, optin)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);
     int rc = mtp_launch_status();
     // the split problems' images -> C

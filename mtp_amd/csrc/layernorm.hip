@@ -62,12 +62,17 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const Tx* __restrict
     }
 }
 
+// per-window addend of the incoming gradient (mtp_layernorm_bwd_win): token row r = (b, y, x) of a (B, Hp, Wp) grid belongs to the 7 x 7 window
+// ((y + pad_t) / 7, (x + pad_l) / 7) of image b (VIT:298-310)
+struct LnWin { int Hp, Wp, pad_t, pad_l, nh, nw; };
+
 template <typename Tact, typename Tx, typename Tdx, bool GELU, int MV>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restrict__ dy, const Tx* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dres, const float* __restrict__ extra, Tdx* __restrict__ dx,
                                                            Tact* __restrict__ dx_copy, const float* __restrict__ copy_scale, int rows_per_sample,
-                                                           float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int64_t part_ld, int64_t rows, int C) {
+                                                           float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int64_t part_ld, int64_t rows, int C,
+                                                           const float* __restrict__ win_add, LnWin wg) {
     __shared__ float4 red[2][3][64 * MV];   // waves 1..3 -> wave 0
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
@@ -103,12 +108,24 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
 #pragma unroll
             for (int i = 0; i < MV; ++i) ee[i] = *reinterpret_cast<const float4*>(extra + row * C + col[i]);
         }
+        float4 wa[MV];
+#pragma unroll
+        for (int i = 0; i < MV; ++i) wa[i] = zero4;
+        if (win_add) {      // (uniform; the row -> window arithmetic is wave-uniform 32-bit integer work)
+            const uint32_t r32 = (uint32_t)row, npi = (uint32_t)(wg.Hp * wg.Wp);
+            const uint32_t b = r32 / npi, t = r32 - b * npi, y = t / (uint32_t)wg.Wp, xq = t - y * (uint32_t)wg.Wp;
+            const uint32_t win = (b * (uint32_t)wg.nh + (y + (uint32_t)wg.pad_t) / 7u) * (uint32_t)wg.nw + (xq + (uint32_t)wg.pad_l) / 7u;
+            const float* wrow = win_add + (int64_t)win * C;
+#pragma unroll
+            for (int i = 0; i < MV; ++i) wa[i] = *reinterpret_cast<const float4*>(wrow + col[i]);
+        }
         const float mu = mean[row], rs = rstd[row];
         const float cs = (dx_copy && copy_scale) ? copy_scale[(uint32_t)row / (uint32_t)rows_per_sample] : 1.0f;   // (64-bit division is ~150 instructions)
         float4 xh[MV], d[MV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MV; ++i) {
+            dv[i].x += wa[i].x; dv[i].y += wa[i].y; dv[i].z += wa[i].z; dv[i].w += wa[i].w;
             if (!ok[i]) dv[i] = zero4;   // select on the loaded VALUE: masked lanes add nothing below
             xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
             if (GELU) {   // y = gelu(z), z = xhat*gamma+beta
@@ -272,21 +289,21 @@ int launch_ln_fwd(const void* x, const float* g, const float* b, void* y, float*
 template <typename Tact, typename Tx, typename Tdx>
 int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int gelu,
                   const float* dres, const float* extra, void* dx, void* dx_copy, const float* copy_scale, int64_t rps,
-                  float* dgp, float* dbp, int64_t part_ld, int64_t rows, int64_t C, hipStream_t s) {
+                  float* dgp, float* dbp, int64_t part_ld, int64_t rows, int64_t C, hipStream_t s, const float* win_add = nullptr, LnWin wg = LnWin{1, 1, 0, 0, 1, 1}) {
     dim3 grid((unsigned)mtp_layernorm_bwd_partial_rows(rows)), block(LN_THREADS);
     if (C > 1024) {
         if (gelu)
             hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true, 8>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);
         else
             hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false, 8>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);
     } else if (gelu)
         hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true, 4>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);
     else
         hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false, 4>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C);
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);
     return mtp_launch_status();
 }
 
@@ -324,6 +341,26 @@ extern "C" int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
         return launch_ln_bwd<float, float, float>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s);
     if (dy_dtype == MTP_BF16 && x_dtype == MTP_BF16 && dx_dtype == MTP_BF16)
         return launch_ln_bwd<bf16_t, bf16_t, bf16_t>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s);
+    return MTP_ERR_UNSUPPORTED;
+}
+
+extern "C" int mtp_layernorm_bwd_win(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                                     const float* gamma, const float* dres, const float* extra, void* dx, int dx_dtype,
+                                     void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
+                                     float* dgamma_part, float* dbeta_part, int64_t part_ld, int64_t rows, int64_t C,
+                                     const float* win_add, int64_t B, int64_t Hp, int64_t Wp, mtp_stream_t stream) {
+    if (part_ld == 0) part_ld = C;
+    if (part_ld < C || (part_ld % 4)) return MTP_ERR_ARG;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma_part || !dbeta_part || rows <= 0 || rows > INT32_MAX || (C % 4) || C > 256 * MAXV) return MTP_ERR_ARG;
+    if (!win_add || B <= 0 || Hp <= 0 || Wp <= 0 || B * Hp * Wp != rows) return MTP_ERR_ARG;
+    if (dx_copy && copy_dtype != dy_dtype) return MTP_ERR_ARG;
+    const int pad_h = (int)((7 - Hp % 7) % 7), pad_w = (int)((7 - Wp % 7) % 7);
+    const LnWin wg = {(int)Hp, (int)Wp, pad_h / 2, pad_w / 2, (int)((Hp + pad_h) / 7), (int)((Wp + pad_w) / 7)};
+    hipStream_t s = (hipStream_t)stream;
+    if (dy_dtype == MTP_BF16 && x_dtype == MTP_F32 && dx_dtype == MTP_F32)
+        return launch_ln_bwd<bf16_t, float, float>(dy, x, mean, rstd, gamma, nullptr, 0, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s, win_add, wg);
+    if (dy_dtype == MTP_F32 && x_dtype == MTP_F32 && dx_dtype == MTP_F32)
+        return launch_ln_bwd<float, float, float>(dy, x, mean, rstd, gamma, nullptr, 0, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s, win_add, wg);
     return MTP_ERR_UNSUPPORTED;
 }
 

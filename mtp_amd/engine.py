@@ -17,8 +17,6 @@ import torch
 from . import ops
 
 F32 = torch.float32
-_FUSED_SAMPLING = os.environ.get("MTP_FUSED_SAMPLING", "1") != "0"     # A/B switch: 0 = pool / linear as separate launches
-_DEFER_LN = os.environ.get("MTP_DEFER_LN_REDUCE", "1") != "0"         # A/B switch: 0 = one reduction launch per LayerNorm backward
 
 
 class _Blk:
@@ -115,9 +113,10 @@ class BackboneEngine:
         self._wimg = ops.WeightImages(entries, act)
 
     # ------------------------------------------------------------------ helpers
+    wgrad_side_stream = False     # True: grouped weight-gradient launches go to a side stream (ops.WgradQueue); measured +0.3 ms, off
+
     def _wgrad_stream(self):
-        """MTP_WGRAD_STREAM=1: grouped weight-gradient launches go to a side stream (ops.WgradQueue)"""
-        if os.environ.get("MTP_WGRAD_STREAM", "0") != "1":
+        if not self.wgrad_side_stream:
             return None
         st = getattr(self, "_wstream", None)
         if st is None or st.device != self.dev:
@@ -136,7 +135,7 @@ class BackboneEngine:
 
     def _ln_bwd(self, *args, **kw):
         # the dgamma / dbeta partial rows wait in self._ln_parts and are reduced once per burst of blocks (_ln_flush)
-        return ops.layernorm_bwd(*args, accumulate=True, defer=(self._ln_parts if _DEFER_LN else None), **kw)
+        return ops.layernorm_bwd(*args, accumulate=True, defer=self._ln_parts, **kw)
 
     def _ln_flush(self):
         if self._ln_parts:
@@ -187,11 +186,7 @@ class BackboneEngine:
             nh, nw = ops.rvsa_windows(Hp, Wp)
             R = B * nh * nw
             avg, pooled = self._e(R, C, dtype=F32), self._e(R, C, dtype=F32)
-            if _FUSED_SAMPLING:
-                samp = ops.rvsa_sampling_fwd(ln1, b.wsamp, b.bsamp, avg, pooled, self._e(R, 5 * self.heads, dtype=F32), B, Hp, Wp)
-            else:     # A/B: the two-launch form
-                ops.rvsa_pool_fwd(ln1, avg, pooled, B, Hp, Wp)
-                samp = ops.small_linear_fwd(pooled, b.wsamp, b.bsamp, self._e(R, 5 * self.heads, dtype=F32))
+            samp = ops.rvsa_sampling_fwd(ln1, b.wsamp, b.bsamp, avg, pooled, self._e(R, 5 * self.heads, dtype=F32), B, Hp, Wp)
             lse = self._e(R * self.heads * 49, dtype=F32)
             ops.rvsa_attn_fwd(qkv, samp, o, lse, P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"],
                               P[pre + "attn.relative_position_bias_table"], B, Hp, Wp, self.heads, self.scale)
@@ -245,17 +240,9 @@ class BackboneEngine:
                               G[pre + "attn.rel_pos_h"], G[pre + "attn.rel_pos_w"], G[pre + "attn.relative_position_bias_table"],
                               B, Hp, Wp, H, self.scale, accumulate=True)
             names = ("sampling_offsets", "sampling_scales", "sampling_angles")
-            if _FUSED_SAMPLING:     # the stacked heads' weight / bias gradients accumulate straight into the three parameters' buffers
-                ops.small_linear_dw_segments(s["pooled"], dsamp, [G[pre + "attn.%s.2.weight" % n].view(-1, C) for n in names],
-                                             [G[pre + "attn.%s.2.bias" % n] for n in names])
-                dpooled = None
-            else:
-                dwb = self._e(5 * H * C + 5 * H, dtype=F32)   # [dW stacked | db]: one clearing pass
-                dws, dbs = dwb[:5 * H * C].view(5 * H, C), dwb[5 * H * C:]
-                dpooled = self._e(R, C, dtype=F32)
-                ops.small_linear_bwd(s["pooled"], b.wsamp, dsamp, dpooled, dws, dbs)
-                ops.copy_segments([dws[:2 * H], dws[2 * H:4 * H], dws[4 * H:], dbs[:2 * H], dbs[2 * H:4 * H], dbs[4 * H:]],
-                                  [G[pre + "attn.%s.2.weight" % n] for n in names] + [G[pre + "attn.%s.2.bias" % n] for n in names])
+            # the stacked heads' weight / bias gradients accumulate straight into the three parameters' buffers
+            ops.small_linear_dw_segments(s["pooled"], dsamp, [G[pre + "attn.%s.2.weight" % n].view(-1, C) for n in names],
+                                         [G[pre + "attn.%s.2.bias" % n] for n in names])
         else:
             rel_h, rel_w = self._full_rel(pre, Hp, Wp)
             if pre + "attn.full_attn_rel_pos_h" in G:
@@ -267,14 +254,15 @@ class BackboneEngine:
                               accumulate=True)
         wq.add(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], G[pre + "attn.qkv.bias"])
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
+        win_add = None
         if b.window:
-            if _FUSED_SAMPLING:
-                ops.rvsa_sampling_bwd(dsamp, b.wsamp, s["avg"], dln1, B, Hp, Wp)     # dln1 += pool'(linear'(dsamp)), one launch
-            else:
-                ops.rvsa_pool_bwd(dpooled, s["avg"], dln1, B, Hp, Wp, accumulate=True)
+            # dln1 += pool'(linear'(dsamp)): the per-window factor (windows, C) is one small launch; norm1's backward adds it to every token
+            # row of the window while it reads the row anyway (round 4: was a read-modify-write pass over (T, C), 17 us per block)
+            win_add = ops.rvsa_sampling_bwd_win(dsamp, b.wsamp, s["avg"], self._e(*s["avg"].shape, dtype=F32))
         dx0, dx0_act = self._e(T, C, dtype=F32), self._e(T, C)
         self._ln_bwd(dln1, s["x"], s["mean1"], s["rstd1"], P[pre + "norm1.weight"], dx0, G[pre + "norm1.weight"], G[pre + "norm1.bias"],
-                          dres=dx1, extra=extra, dx_copy=dx0_act, copy_scale=prev_scale, rows_per_sample=N)
+                          dres=dx1, extra=extra, dx_copy=dx0_act, copy_scale=prev_scale, rows_per_sample=N,
+                          **(dict(win_add=win_add, grid=(B, Hp, Wp)) if win_add is not None else {}))
         return dx0, dx0_act
 
     # ------------------------------------------------------------------ whole forward

@@ -16,7 +16,6 @@ allocates buffers and draws the drop-path masks.
 import torch
 
 from . import ops
-from .engine import _DEFER_LN
 from .ops_dcnv3 import functions as dcn
 
 F32 = torch.float32
@@ -126,7 +125,7 @@ class InternEngine:
         # the dgamma / dbeta partial rows wait in self._ln_parts and are reduced together with the next weight-gradient burst (_ln_flush):
         # three LayerNorms per layer were 240 reduction launches per InternImage-XL step
         ops.layernorm_bwd(dy, x, mean, rstd, P[key + ".weight"], dx, G[key + ".weight"], G[key + ".bias"],
-                          beta=P[key + ".bias"] if gelu else None, gelu=gelu, accumulate=True, defer=(self._ln_parts if _DEFER_LN else None))
+                          beta=P[key + ".bias"] if gelu else None, gelu=gelu, accumulate=True, defer=self._ln_parts)
         return dx
 
     def _ln_flush(self):

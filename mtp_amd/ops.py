@@ -11,32 +11,6 @@ from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_DG, EPI_BIAS_RES, EPI_
                    check)
 
 _DT = {torch.float32: MTP_F32, torch.bfloat16: MTP_BF16}
-_NT_VARIANT = int(__import__("os").environ.get("MTP_NT_VARIANT", "0"))   # whole-model A/B of the NT GEMM kernel choices (mtp_hip.h: variant)
-NT_STREAMK, NT_NO_STREAMK, NT_STREAMK_AUTO = 1 << 17, 1 << 18, 1 << 19
-_NT_SK_DEFAULT = NT_STREAMK_AUTO if __import__("os").environ.get("MTP_NT_STREAMK", "0") != "0" else 0   # MTP_NT_STREAMK=0: never (A/B)
-_NT_WS = {}      # (device, stream) -> zero-initialised workspace of the stream-K NT kernel (flags + partial-sum slots, 64 MB)
-
-
-def nt_workspace():
-    """the stream-K workspace of the CURRENT stream (mtp_gemm_args.workspace: one per stream, zero when first used, then owned by the kernels)"""
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    ws = _NT_WS.get(key)
-    if ws is None:
-        ws = _NT_WS[key] = torch.zeros(lib().mtp_gemm_nt_workspace_bytes(), device="cuda", dtype=torch.uint8)
-    return ws
-
-
-def nt_streamk_status(reset=True):
-    """nonzero when a stream-K consumer gave up waiting for its partial sums (never in a healthy run; tests check it)"""
-    bad = 0
-    for ws in _NT_WS.values():
-        st = ws[16384:16388].view(torch.int32)
-        bad |= int(st.item())
-        if reset:
-            st.zero_()
-    return bad
-
-
 def lib():
     return _lib.load()
 
@@ -91,10 +65,7 @@ def _nt_args(a, w, out, epi, bias, bias_mod, res, res_mod, rowscale, rows_per_sa
     g.aux, g.aux_ld = _p(aux), (aux.shape[-1] if aux is not None else 0)
     if aux is not None:
         assert aux.dtype == out.dtype and tuple(aux.shape) == (M, N) and out.shape[1] == N
-    g.split_k, g.variant = 1, variant or (_NT_VARIANT or _NT_SK_DEFAULT)
-    if (g.variant & (NT_STREAMK | NT_STREAMK_AUTO)) and a.dtype == torch.bfloat16 and M >= 256:
-        ws = nt_workspace()
-        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
+    g.split_k, g.variant = 1, variant
     return g
 
 
@@ -167,9 +138,6 @@ def gemm_tn(a, b, out, split_k=None, use_workspace=True, variant=0, colsum=None,
 
 
 MAX_GROUPED = 32      # MTP_MAX_GROUPED_GEMMS
-TN_W4, TN_NO_W4 = 32, 64      # mtp_gemm_tn_grouped variant bits: the 4-wave 32x32x16 form (gemm_tn_w4.hip) / the 8-wave 8-phase form (gemm_tn_p8.hip)
-_TN_DEFAULT = TN_W4 if __import__("os").environ.get("MTP_TN_W4", "0") != "0" else 0
-_NO_GROUPED = bool(int(__import__("os").environ.get("MTP_NO_GROUPED_WGRAD", "0")))   # A/B: every weight gradient through mtp_gemm_tn
 
 
 def grouped_tiles(M, N):
@@ -195,7 +163,7 @@ class WgradQueue:
     the grouped kernel cannot take (f32 parity mode, sizes that are not multiples of 8 / 128) run immediately through gemm_tn."""
 
     def __init__(self, cus=256, variant=0, stream=None):
-        self.jobs, self.tiles, self.cus, self.variant = [], 0, cus, variant or _TN_DEFAULT
+        self.jobs, self.tiles, self.cus, self.variant = [], 0, cus, variant
         # stream: launch on this (side) stream instead of the current one.  The weight gradients are off the backward pass's
         # critical path; next to the chain of data-gradient GEMMs (224 or 672 tiles on 256 CUs: 12.5 % of the CUs idle in the last
         # round) their tiles fill the idle CUs.  flush() orders the launch after everything issued so far; wait() orders the
@@ -211,7 +179,7 @@ class WgradQueue:
         # a problem outside them runs now through gemm_tn instead of failing the whole deferred launch several blocks later
         fits = (K * M * 2 < (1 << 32) and K * N * 2 < (1 << 32) and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
                 and dy.is_contiguous() and x.is_contiguous())
-        if _NO_GROUPED or t == 0 or K % 128 or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not fits:
+        if t == 0 or K % 128 or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not fits:
             gemm_tn(dy, x, dw, colsum=colsum)
             if after is not None:
                 after()
@@ -296,7 +264,7 @@ def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-6, gelu=False)
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=False, dres=None, extra=None,
-                  dx_copy=None, copy_scale=None, rows_per_sample=0, accumulate=False, defer=None):
+                  dx_copy=None, copy_scale=None, rows_per_sample=0, accumulate=False, defer=None, win_add=None, grid=None):
     """dx = [dres] + [extra] + LN'(dy); dgamma/dbeta (C,) f32 are overwritten (or accumulated into).  With `defer` (a list) the
     per-workgroup partials are kept and appended to it instead of being reduced: reduce_rows_deferred(defer) finishes several
     LayerNorms' parameter gradients in one launch."""
@@ -305,10 +273,19 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=F
     #  the kernel from 61 to 106 us; per-workgroup partials + two 8 us reductions are faster)
     nblk = lib().mtp_layernorm_bwd_partial_rows(rows)
     part = torch.empty(nblk, 2 * Cc, device=x.device, dtype=torch.float32)     # [dgamma partials | dbeta partials] per workgroup
-    check(lib().mtp_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _f32(mean), _f32(rstd), _f32(gamma), _f32(beta), int(gelu),
-                                  _f32(dres), _f32(extra), _p(dx), _dt(dx), _p(dx_copy), (_dt(dx_copy) if dx_copy is not None else 0),
-                                  _f32(copy_scale), rows_per_sample, part.data_ptr(), part.data_ptr() + 4 * Cc, 2 * Cc, rows, Cc, _s()),
-          "mtp_layernorm_bwd")
+    if win_add is not None:
+        # dy_eff = dy + win_add[window(row)]: the RVSA sampling heads' input gradient, added per 7 x 7 window of the (B, Hp, Wp) token grid
+        B, Hp, Wp = grid
+        nh, nw = rvsa_windows(Hp, Wp)
+        assert not gelu and tuple(win_add.shape) == (B * nh * nw, Cc) and B * Hp * Wp == rows
+        check(lib().mtp_layernorm_bwd_win(_p(dy), _dt(dy), _p(x), _dt(x), _f32(mean), _f32(rstd), _f32(gamma), _f32(dres), _f32(extra), _p(dx), _dt(dx),
+                                          _p(dx_copy), (_dt(dx_copy) if dx_copy is not None else 0), _f32(copy_scale), rows_per_sample,
+                                          part.data_ptr(), part.data_ptr() + 4 * Cc, 2 * Cc, rows, Cc, _f32(win_add), B, Hp, Wp, _s()), "mtp_layernorm_bwd_win")
+    else:
+        check(lib().mtp_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _f32(mean), _f32(rstd), _f32(gamma), _f32(beta), int(gelu),
+                                      _f32(dres), _f32(extra), _p(dx), _dt(dx), _p(dx_copy), (_dt(dx_copy) if dx_copy is not None else 0),
+                                      _f32(copy_scale), rows_per_sample, part.data_ptr(), part.data_ptr() + 4 * Cc, 2 * Cc, rows, Cc, _s()),
+              "mtp_layernorm_bwd")
     # weight and bias gradient adjacent in one buffer (the flat gradient buffer of mtp_amd.parallel) -> ONE reduction launch
     if defer is not None and _adjacent(dgamma, dbeta) and dgamma.numel() == Cc:
         defer.append((part, dgamma, accumulate))
@@ -546,6 +523,13 @@ def rvsa_sampling_bwd(dsamp, w, avg, dx, B, Hp, Wp):
     """dx += broadcast((dsamp . w) * leaky'(avg) / 49) in one launch (mtp_rvsa_sampling_bwd)"""
     check(lib().mtp_rvsa_sampling_bwd(_f32(dsamp), _f32(w), _f32(avg), _p(dx), _dt(dx), B, Hp, Wp, dx.shape[-1], w.shape[0], _s()), "mtp_rvsa_sampling_bwd")
     return dx
+
+
+def rvsa_sampling_bwd_win(dsamp, w, avg, g):
+    """g (windows, C) f32 = (dsamp . w) * leaky'(avg) / 49 -- the per-window addend layernorm_bwd(win_add=...) spreads over the tokens"""
+    R, Cc = avg.shape
+    check(lib().mtp_rvsa_sampling_bwd_win(_f32(dsamp), _f32(w), _f32(avg), _f32(g), R, Cc, w.shape[0], _s()), "mtp_rvsa_sampling_bwd_win")
+    return g
 
 
 def small_linear_fwd(x, w, b, y):

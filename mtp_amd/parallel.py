@@ -78,8 +78,8 @@ class FlatParams:
         # Gradients the engine OVERWRITES in every backward (the blocks' Linear weights and the patch embedding: TN GEMM outputs, ~97 % of
         # the buffer) need no clearing; everything else accumulates (bias by-products, LayerNorm / table partial sums, the stacked
         # sampling heads; the FPN weights, which a loss that ignores a map leaves unwritten) and is cleared by ONE launch over a table of
-        # runs of at most 64 K floats (zero_accumulating()).  MTP_ZERO_ALL_GRADS=1: clear everything (A/B).
-        over = None if os.environ.get("MTP_ZERO_ALL_GRADS") == "1" else getattr(module, "_overwritten_grads", None)
+        # runs of at most 64 K floats (zero_accumulating()).
+        over = getattr(module, "_overwritten_grads", None)
         self._zero_tab = None
         if over is not None and self.grad.is_cuda:
             runs = []

@@ -544,7 +544,7 @@ def test_window_partition_reverse_on_device_bit_exact(golden):
 
 
 def test_weight_gradients_on_a_side_stream_give_the_same_gradients(monkeypatch):
-    """MTP_WGRAD_STREAM=1 (A/B option, DESIGN section 4): the grouped weight-gradient launches go to a side stream, ordered by events;
+    """BackboneEngine.wgrad_side_stream (A/B option, DESIGN section 4): the grouped weight-gradient launches go to a side stream, ordered by events;
     the operands stay referenced until the main stream has waited.  Same gradients as the single-stream schedule (f32 atomics of
     the bias-gradient by-product reorder sums: 1e-6)."""
     net = build(256, 8, 4, 4, [1, 3, 5, 7], "bf16").train()
@@ -556,9 +556,10 @@ def test_weight_gradients_on_a_side_stream_give_the_same_gradients(monkeypatch):
         sum(f.float().mean() for f in net(img)).backward()
         torch.cuda.synchronize()
         return {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
-    monkeypatch.setenv("MTP_WGRAD_STREAM", "0")
+    from mtp_amd.engine import BackboneEngine
+    monkeypatch.setattr(BackboneEngine, "wgrad_side_stream", False)
     a = grads()
-    monkeypatch.setenv("MTP_WGRAD_STREAM", "1")
+    monkeypatch.setattr(BackboneEngine, "wgrad_side_stream", True)
     b = grads()
     assert a.keys() == b.keys()
     for n in a:

@@ -35,7 +35,7 @@ def e(*shape, dtype=torch.float32):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("variant", [0, 1, 8, 32, 36])   # default / register-staged / double-buffered / 256x128 8-wave tile (+ grouped order)
+@pytest.mark.parametrize("variant", [0, 1, 32, 36])   # default / register-staged / 256x128 8-wave tile (+ grouped order)
 @pytest.mark.parametrize("M,N,K", [(392, 384, 128), (300, 256, 192), (1024, 768, 768), (128, 128, 64)])
 def test_gemm_nt_bias(ops, dtype, variant, M, N, K):
     a, w, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1), rnd(N, seed=2)
@@ -92,17 +92,17 @@ def test_gemm_nt_epilogues(ops, dtype):
 def test_gemm_nt_tile_variants_bit_identical(ops, dtype):
     """the 256x128 / 8-wave kernel (variant 32; picked automatically for one-round problems such as M = 12544, N = 1024) and the
     tile orders accumulate in the same k order as the default kernel: every epilogue must come out bit-identical"""
-    M, N, K, rps = 1024, 384, 256, 256   # complete 128-row tiles, so that variant 128 (5 workgroups per CU, asm LDS-DMA loads) applies
+    M, N, K, rps = 1024, 384, 256, 256   # complete 128-row tiles
     a, w, b = dev(rnd(M, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.2), dtype), dev(rnd(N, seed=2))
     res, rs, uu = dev(rnd(M, N, seed=3)), dev(torch.tensor([0.0, 1.1, 0.9, 1.0])), dev(rnd(M, N, dtype=dtype, seed=5), dtype)
     outs = {}
-    for v in (0, 32, 36, 4, 64, 128, 132):
+    for v in (0, 32, 36, 4, 64):
         u = e(M, N, dtype=dtype)
         h = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU, bias=b, aux=u, variant=v)
         r = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=v)
         d = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_DGELU, aux=uu, variant=v)
         outs[v] = (u, h, r, d)
-    for v in (32, 36, 4, 64, 128, 132):
+    for v in (32, 36, 4, 64):
         for x, y in zip(outs[0], outs[v]):
             assert torch.equal(x, y), v
 
@@ -116,10 +116,9 @@ P8_SHAPES = [(256, 256, 128),      # one tile, the shortest pipeline (one K-tile
 
 
 PS = 32768       # variant bit 15: persistent tiles (the next tile's first K-tiles are issued before the epilogue of the current one)
-C2 = 256 + (1 << 22)   # variant bit 22: the co-resident 4-wave form (gemm_c2.hip: 256 x 128 tiles, two workgroups per CU)
 
 
-@pytest.mark.parametrize("variant", [256, 512, 768, 514, 512 + PS, 768 + PS, C2, C2 + 2])
+@pytest.mark.parametrize("variant", [256, 512, 768, 514, 512 + PS, 768 + PS])
 @pytest.mark.parametrize("M,N,K", P8_SHAPES)
 def test_gemm_nt_p8_vs_oracle(ops, variant, M, N, K):
     dtype = torch.bfloat16
@@ -135,7 +134,7 @@ def test_gemm_nt_p8_asymmetric_identity(ops):
     M = N = K = 512
     w = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :]) % 251).float()     # exact in bf16, no two rows alike
     a = torch.eye(M)
-    for variant in (512, 768, C2):
+    for variant in (512, 768):
         out = ops.gemm_nt(dev(a, torch.bfloat16), dev(w, torch.bfloat16), e(M, N), variant=variant)
         assert torch.equal(out.cpu(), w.t().contiguous()), variant
 
@@ -162,7 +161,7 @@ def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
     ref = run(1024)
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
     NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20          # store policy of the epilogue: nt / sc1 (write-through) / plain stores (0 = picked per epilogue)
-    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN, C2, C2 + NT_, C2 + SC1, C2 + PLAIN):
+    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN):
         for rep in range(4):
             for x, y in zip(ref, run(v)):
                 assert torch.equal(x, y), (v, rep)
@@ -176,65 +175,12 @@ def test_gemm_nt_p8_vit_l_shapes_race_screen(ops):
     for (N, K) in [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C), (C, 3 * C)]:
         a, w, b = dev(rnd(T, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.05), dtype), dev(rnd(N, seed=2))
         ref = ops.gemm_nt(a, w, e(T, N, dtype=dtype), bias=b, variant=1024)
-        for v in (512, 768, 512 + PS, 768 + PS, C2):
+        for v in (512, 768, 512 + PS, 768 + PS):
             out = e(T, N, dtype=dtype)
             for rep in range(6):
                 out.zero_()
                 ops.gemm_nt(a, w, out, bias=b, variant=v)
                 assert torch.equal(out, ref), (N, K, v, rep)
-
-
-SK = 512 + (1 << 17)     # 224-row tiles, stream-K forced (variant bit 17; needs the workspace ops.gemm_nt attaches)
-
-
-@pytest.mark.parametrize("M,N,K", [(12544, 3072, 1024),     # qkv forward: 672 tiles = 2.625 per CU, a cut inside every XCD boundary (7 x 32 hand-offs)
-                                   (12544, 4096, 1024),     # fc1 forward / fc2 dgrad: 3.5 per CU, cuts at the odd boundaries only
-                                   (12544, 1024, 4096),     # 224 tiles < 256 CUs: the kernel must decline (falls back to the persistent form)
-                                   (12544 + 5 * 224, 2816, 256),    # ragged last super-tile (671 tiles: workgroups without a tile in it), ONE pair per tile... 2 k-tiles
-                                   (12552, 2056, 384),      # ragged M and N edges inside the last tiles, 3 pairs per tile
-                                   (50176, 4096, 1024)])    # the FPN GEMM: 14 rounds, no cut needed (pure de-synchronisation)
-def test_gemm_nt_streamk_bit_identical_and_repeatable(ops, M, N, K):
-    """stream-K form of the pipelined NT kernel (work cut along K per XCD, partial sums handed between workgroups through the
-    workspace): same k order -> bit-identical to the 128-wide kernels for every epilogue; every launch with FRESH data, so that a
-    partial sum left over from the previous launch (stale flag, stale cache line) or a hand-off race shows up as a mismatch"""
-    dtype, rps = torch.bfloat16, 196
-    g = torch.Generator(device="cuda").manual_seed(M + N + K)
-
-    def grnd(*shape, dt=torch.float32, scale=1.0):          # drawn on the device: the operands are up to 0.8 GB
-        return (torch.randn(*shape, device="cuda", generator=g) * scale).to(dt)
-    for rep in range(1 if M > 20000 else 3):
-        a, w, b = grnd(M, K, dt=dtype), grnd(N, K, dt=dtype, scale=0.1), grnd(N)
-        res, uu = grnd(M, N), grnd(M, N, dt=dtype)
-        rs = 1.0 + 0.1 * grnd((M + rps - 1) // rps)
-
-        def run(v):
-            r = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=v)
-            f = ops.gemm_nt(a, w, e(M, N, dtype=dtype), bias=b, variant=v)
-            dg = e(M, N, dtype=dtype)
-            h2 = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU_DG, bias=b, aux=dg, variant=v)
-            mu = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_MUL, aux=uu, variant=v)
-            return r, f, dg, h2, mu
-        ref = run(1024)
-        for k2 in range(2):
-            for x, y in zip(ref, run(SK)):
-                assert torch.equal(x, y), (rep, k2)
-    assert ops.nt_streamk_status() == 0        # no consumer ever gave up waiting for its partial sums
-
-
-def test_gemm_nt_streamk_back_to_back_different_shapes(ops):
-    """launches of different shapes share the workspace back to back on one stream (flags are left at zero by the consumers)"""
-    dtype = torch.bfloat16
-    shapes = [(12544, 3072, 1024), (12544, 4096, 1024), (12544, 3072, 1024), (50176, 4096, 1024), (12544, 4096, 1024)]
-    data = []
-    g = torch.Generator(device="cuda").manual_seed(77)
-    for i, (M, N, K) in enumerate(shapes):
-        a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
-        w = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(dtype)
-        data.append((a, w, ops.gemm_nt(a, w, e(M, N, dtype=dtype), variant=1024)))
-    outs = [ops.gemm_nt(a, w, e(*ref.shape, dtype=dtype), variant=SK) for a, w, ref in data]     # no sync in between
-    for (a, w, ref), out in zip(data, outs):
-        assert torch.equal(out, ref)
-    assert ops.nt_streamk_status() == 0
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -280,7 +226,7 @@ def _wgrad_group(ops, shapes, seed=0):
     [(128, 256, 256, True)],                                                                  # one tile, one K-tile pair
     [(256, 512, 256, True), (384, 256, 768, False), (1024, 256, 256, True)],                   # different contractions in one launch
     [(1536, 768, 256, True), (1536, 256, 256, True), (1536, 1024, 256, False), (1536, 256, 1024, True)]])   # a block's four gradients
-@pytest.mark.parametrize("variant", [0, 32])       # 0 = the 8-wave 8-phase kernel, 32 = the 4-wave 32x32x16 kernel (gemm_tn_w4.hip)
+@pytest.mark.parametrize("variant", [0])       # the 8-wave 8-phase kernel (the 4-wave 32x32x16 form of round 3 lives in tools/ablation/)
 def test_gemm_tn_grouped_vs_oracle(ops, shapes, variant):
     q, refs = _wgrad_group(ops, shapes)
     q.variant = variant
@@ -309,7 +255,7 @@ def test_gemm_tn_grouped_edge_tiles_and_pieces(ops, shapes):
             assert rel_err(cs.cpu(), cs0 + a.float().sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [0, 32])
+@pytest.mark.parametrize("variant", [0])
 def test_gemm_tn_grouped_vit_l_block_repeatable(ops, variant):
     """the four weight gradients of a ViT-L block at the training size (T = 12544 tokens, 192 tiles, 98 K-tile pairs each) against
     the split-K kernels of gemm.hip, and launch-to-launch bit-identical (no atomics on dW; one atomic per bias-gradient entry):
@@ -698,6 +644,44 @@ def test_small_linear_shapes(ops, R, N, K):
     dx, dw, db = e(R, K), e(N, K), e(N)
     ops.small_linear_bwd(dev(x), dev(w), dev(dy), dx, dw, db)
     assert rel_err(dx.cpu(), dy @ w) < 1e-5 and rel_err(dw.cpu(), dy.t() @ x) < 1e-5 and rel_err(db.cpu(), dy.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Hp,Wp", [(14, 14), (16, 12), (32, 32)])
+def test_layernorm_bwd_with_window_addend(ops, dtype, Hp, Wp):
+    """mtp_rvsa_sampling_bwd_win + mtp_layernorm_bwd_win (round 4: norm1's backward adds the sampling heads' input gradient per 7 x 7 window
+    while it reads the row) against torch: dy_eff = dy + broadcast((dsamp . w) * leaky'(avg) / 49) through LayerNorm's backward -- and against
+    the two-pass form (mtp_rvsa_sampling_bwd into dy, then mtp_layernorm_bwd).  32 x 32 is the padded case (35 x 35, 25 windows)."""
+    B, C, N5 = 3, 256, 20
+    T = B * Hp * Wp
+    nh, nw = ops.rvsa_windows(Hp, Wp)
+    R = B * nh * nw
+    pt, pl = ((7 - Hp % 7) % 7) // 2, ((7 - Wp % 7) % 7) // 2
+    x, dy, gamma, beta = rnd(T, C), rnd(T, C, dtype=dtype, seed=1), 1.0 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    dsamp, w, avg, dres = rnd(R, N5, seed=4), 0.1 * rnd(N5, C, seed=5), rnd(R, C, seed=6), rnd(T, C, seed=7)
+    # torch: the per-window factor, spread over the tokens
+    g_ref = (dsamp @ w) * torch.where(avg > 0, torch.tensor(1.0), torch.tensor(0.01)) / 49.0
+    ys, xs = torch.arange(Hp), torch.arange(Wp)
+    win = (((ys + pt) // 7)[:, None] * nw + ((xs + pl) // 7)[None, :]).reshape(-1)                    # (Hp * Wp,) window of each token
+    win_all = (torch.arange(B)[:, None] * (nh * nw) + win[None, :]).reshape(-1)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-6)
+    yr.backward(dy.float() + g_ref[win_all])
+    mean, rstd = e(T), e(T)
+    ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), e(T, C, dtype=dtype), mean, rstd)
+    g = ops.rvsa_sampling_bwd_win(dev(dsamp), dev(w), dev(avg), e(R, C))
+    assert rel_err(g.cpu(), g_ref) < 1e-5
+    dx, dgm, dbt = e(T, C), e(C), e(C)
+    ops.layernorm_bwd(dev(dy, dtype), dev(x), mean, rstd, dev(gamma), dx, dgm, dbt, dres=dev(dres), win_add=g, grid=(B, Hp, Wp))
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert rel_err(dx.cpu(), xr.grad + dres) < tol and rel_err(dgm.cpu(), gr.grad) < tol and rel_err(dbt.cpu(), br.grad) < tol
+    # the two-pass form it replaces (the bf16 form rounds dy + g to bf16 before the LayerNorm backward; the fused one adds in f32)
+    dy2 = dev(dy, dtype).clone()
+    ops.rvsa_sampling_bwd(dev(dsamp), dev(w), dev(avg), dy2, B, Hp, Wp)
+    dx2, dgm2, dbt2 = e(T, C), e(C), e(C)
+    ops.layernorm_bwd(dy2, dev(x), mean, rstd, dev(gamma), dx2, dgm2, dbt2, dres=dev(dres))
+    assert rel_err(dx.cpu(), dx2.cpu()) < tol and rel_err(dgm.cpu(), dgm2.cpu()) < tol
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -13,11 +13,8 @@ from mtp_amd import ops
 from tools.bench_ops import r
 
 T, C = 12544, 1024
-SK = 1 << 17
 NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20
-C2 = 256 + (1 << 22)     # the co-resident 4-wave form (gemm_c2.hip)
-NAMES = {-1: "hipBLASLt(torch.addmm)", C2: "c2-256x128", C2 + 2: "c2-plain-order", 512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + SK: "p8-224-streamk", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain", 256 + (1 << 11): "p8-noprio", 256 + (2 << 11): "p8-nostagger",
-         256 + (3 << 11): "p8-noprio-nostagger", 256 + (4 << 11): "p8-nostore", 256 + (8 << 11): "p8-nomfma", 256 + (12 << 11): "p8-nomfma-nostore", 256 + (15 << 11): "p8-direct-epi"}
+NAMES = {-1: "hipBLASLt(torch.addmm)",  512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain"}
 
 
 def time_many(fn, iters):
@@ -83,7 +80,7 @@ def main():
                     okv[v] = True
                     time_many(lambda: launch(v), 3)
                 continue
-            if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + SK, 512 + NT_, 512 + SC1, 512 + PLAIN, C2, C2 + 2) and epi != "bias":
+            if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + NT_, 512 + SC1, 512 + PLAIN) and epi != "bias":
                 continue
             out.zero_()
             ops.gemm_nt(a, w, out, variant=v, **kw)
