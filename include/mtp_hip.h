@@ -140,6 +140,9 @@ int mtp_reduce_rows_batched_f32(const float* const* parts, float* const* outs, i
                                 mtp_stream_t stream);
 /* the same, result transposed: part (rows, R*C) f32, column a*C + b is summed into out[b*R + a] (out is (C, R)) */
 int mtp_reduce_rows_t_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t R, int64_t C, int accumulate, mtp_stream_t stream);
+/* ... and n <= MTP_REDUCE_BATCH_MAX of those of one shape in one launch (host arrays of device pointers) */
+int mtp_reduce_rows_t_batched_f32(const float* const* parts, float* const* outs, int n, int64_t ld, int64_t rows, int64_t R, int64_t C, int accumulate,
+                                  mtp_stream_t stream);
 /* bias gradient: out[n] = sum_m dY[m][n] */
 int mtp_colsum(const void* dY, int dtype, int64_t ld, float* out, int64_t M, int64_t N, mtp_stream_t stream);
 /* same, accumulating: out[n] += ... (no clearing pass; used with a gradient buffer that is zeroed once per step) */
@@ -266,6 +269,10 @@ int mtp_small_linear_bwd(const float* x, const float* w, const float* dy, float*
  * dw[j] (rows_j, K) += dy[:, r0_j : r0_j + rows_j]^T x, db[j] (rows_j) += column sums.  seg_rows, dw, db: host arrays; db may be NULL. */
 int mtp_small_linear_dw_segments(const float* x, const float* dy, int64_t R, int64_t N, int64_t K, int nseg, const int64_t* seg_rows,
                                  float* const* dw, float* const* db, mtp_stream_t stream);
+/* the same for count <= 8 problems of one shape in ONE launch (the stacked heads of a burst of RVSA blocks, round 4): xs / dys are host arrays
+ * of device pointers, dw / db host arrays of count * nseg device pointers, problem-major */
+int mtp_small_linear_dw_segments_batched(const float* const* xs, const float* const* dys, int count, int64_t R, int64_t N, int64_t K, int nseg,
+                                         const int64_t* seg_rows, float* const* dw, float* const* db, mtp_stream_t stream);
 /* RotatedVariedSizeWindowAttention core (VIT:312-428): samp (B*nh*nw, 5*heads) f32 = [off(h,2)|scale(h,2)|angle(h)];
  * lse (B, heads, nh*nw, 49) f32 */
 int mtp_rvsa_attn_fwd(const void* qkv, const float* samp, void* o, float* lse, int dtype,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mtp_reduce_rows_f32": (i32, [p, i64, p, i64, i64, i32, p]),
     "mtp_reduce_rows_batched_f32": (i32, [p, p, i32, i64, i64, i64, i32, p]),
     "mtp_reduce_rows_t_f32": (i32, [p, i64, p, i64, i64, i64, i32, p]),
+    "mtp_reduce_rows_t_batched_f32": (i32, [p, p, i32, i64, i64, i64, i64, i32, p]),
     "mtp_copy_segments_f32": (i32, [p, p, p, i32, p]),
     "mtp_colsum": (i32, [p, i32, i64, p, i64, i64, p]),
     "mtp_colsum_acc": (i32, [p, i32, i64, p, i64, i64, p]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "mtp_small_linear_fwd": (i32, [p, p, p, p, i64, i64, i64, p]),
     "mtp_small_linear_bwd": (i32, [p, p, p, p, p, p, i64, i64, i64, p]),
     "mtp_small_linear_dw_segments": (i32, [p, p, i64, i64, i64, i32, p, p, p, p]),
+    "mtp_small_linear_dw_segments_batched": (i32, [p, p, i32, i64, i64, i64, i32, p, p, p, p]),
     "mtp_rvsa_attn_fwd": (i32, [p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_rvsa_attn_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_zero_segments_f32": (i32, [p, p, p, i32, p]),

@@ -373,13 +373,23 @@ struct SlSegs {
     int row0[5];
     int nseg;
 };
+// batched form (round 4): the same gradients of up to SL_BATCH independent problems of one shape (the stacked heads of a burst of RVSA
+// blocks) in ONE launch -- blockIdx.z = problem * zsplit + row split
+constexpr int SL_BATCH = 8;
+struct SlBatch {
+    const float* dy[SL_BATCH];
+    const float* x[SL_BATCH];
+    SlSegs seg[SL_BATCH];
+    int zsplit;
+};
 template <bool SEG>
-__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K, SlSegs seg) {
+__device__ __forceinline__ void small_linear_dw_body(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K,
+                                                     const SlSegs& seg, int zrow) {
     __shared__ float4 red[3][8][64];
     __shared__ float redb[3][8];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = (blockIdx.x * 64 + lane) * 4, n0 = blockIdx.y * 8;
-    const int r0 = (blockIdx.z * 4 + wave) * SL_DW_ROWS, r1 = (r0 + SL_DW_ROWS) < R ? (r0 + SL_DW_ROWS) : R;
+    const int r0 = (zrow * 4 + wave) * SL_DW_ROWS, r1 = (r0 + SL_DW_ROWS) < R ? (r0 + SL_DW_ROWS) : R;
     const bool kok = k < K;
     const int kc = kok ? k : 0;
     int nn[8];
@@ -436,6 +446,14 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __res
             if (dbp && blockIdx.x == 0 && lane == 0 && n0 + q < N) atomicAdd(dbp, sb[q]);
         }
     }
+}
+template <bool SEG>
+__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int R, int N, int K, SlSegs seg) {
+    small_linear_dw_body<SEG>(dy, x, dw, db, R, N, K, seg, (int)blockIdx.z);
+}
+__global__ __launch_bounds__(256) void small_linear_dw_batched_kernel(SlBatch t, int R, int N, int K) {
+    const int pi = __builtin_amdgcn_readfirstlane((int)blockIdx.z / t.zsplit);
+    small_linear_dw_body<true>(t.dy[pi], t.x[pi], nullptr, nullptr, R, N, K, t.seg[pi], (int)blockIdx.z - pi * t.zsplit);
 }
 
 // ------------------------------------------------------------------------------------------------ optimizer
@@ -1010,6 +1028,34 @@ extern "C" int mtp_small_linear_dw_segments(const float* x, const float* dy, int
     seg.nseg = nseg;
     hipLaunchKernelGGL(small_linear_dw_kernel<true>, dim3((unsigned)((K + 255) / 256), (unsigned)((N + 7) / 8), (unsigned)((R + 4 * SL_DW_ROWS - 1) / (4 * SL_DW_ROWS))), dim3(256), 0,
                        (hipStream_t)stream, dy, x, (float*)nullptr, (float*)nullptr, (int)R, (int)N, (int)K, seg);
+    return mtp_launch_status();
+}
+
+/* the same for `count` <= 8 problems of one shape in one launch: xs / dys host arrays of device pointers, dw / db host arrays of
+ * count * nseg device pointers (problem-major) */
+extern "C" int mtp_small_linear_dw_segments_batched(const float* const* xs, const float* const* dys, int count, int64_t R, int64_t N, int64_t K, int nseg,
+                                                    const int64_t* seg_rows, float* const* dw, float* const* db, mtp_stream_t stream) {
+    if (!xs || !dys || !seg_rows || !dw || count <= 0 || count > SL_BATCH || R <= 0 || N <= 0 || K <= 0 || (K % 4) || nseg < 1 || nseg > 4) return MTP_ERR_ARG;
+    SlBatch t{};
+    for (int i = 0; i < count; ++i) {
+        if (!xs[i] || !dys[i]) return MTP_ERR_ARG;
+        t.x[i] = xs[i];
+        t.dy[i] = dys[i];
+        int64_t r = 0;
+        for (int j = 0; j < nseg; ++j) {
+            if (!dw[i * nseg + j] || seg_rows[j] <= 0) return MTP_ERR_ARG;
+            t.seg[i].dw[j] = dw[i * nseg + j];
+            t.seg[i].db[j] = db ? db[i * nseg + j] : nullptr;
+            t.seg[i].row0[j] = (int)r;
+            r += seg_rows[j];
+        }
+        if (r != N) return MTP_ERR_ARG;
+        t.seg[i].row0[nseg] = (int)N;
+        t.seg[i].nseg = nseg;
+    }
+    t.zsplit = (int)((R + 4 * SL_DW_ROWS - 1) / (4 * SL_DW_ROWS));
+    hipLaunchKernelGGL(small_linear_dw_batched_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)((N + 7) / 8), (unsigned)(t.zsplit * count)), dim3(256), 0,
+                       (hipStream_t)stream, t, (int)R, (int)N, (int)K);
     return mtp_launch_status();
 }
 

@@ -232,6 +232,20 @@ __global__ __launch_bounds__(256) void reduce_rows_t_kernel(const float* __restr
     atomicAdd(out + q, s);
 }
 
+// ... and n of those in one launch (blockIdx.z = buffer): the bias-table gradients of a burst of RVSA blocks
+__global__ __launch_bounds__(256) void reduce_rows_t_batched_kernel(RrBatch t, int64_t ld, int64_t rows, int R, int C, int64_t rows_per_block) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (int64_t)R * C) return;
+    const int a = (int)(q % R), b = (int)(q / R);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    const float* src = t.part[blockIdx.z] + (int64_t)a * C + b;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += src[r * ld];
+    atomicAdd(t.out[blockIdx.z] + q, s);
+}
+
 // bias gradient: column sums of dY (M, N).  Block = 64 columns-of-4 x 4 row-lanes; grid.y splits the rows; f32 atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, int64_t ld, float* __restrict__ out, int64_t M, int64_t N, int64_t rows_per_block) {
@@ -403,6 +417,30 @@ extern "C" int mtp_reduce_rows_batched_f32(const float* const* parts, float* con
     const int64_t rpb = (rows + splits - 1) / splits;
     splits = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(reduce_rows_batched_kernel, dim3((unsigned)col_blocks, (unsigned)splits, (unsigned)n), dim3(256), 0, s, t, ld, rows, C, rpb);
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_reduce_rows_t_batched_f32(const float* const* parts, float* const* outs, int n, int64_t ld, int64_t rows, int64_t R, int64_t C, int accumulate,
+                                             mtp_stream_t stream) {
+    if (!parts || !outs || n <= 0 || n > MTP_REDUCE_BATCH_MAX || rows <= 0 || R <= 0 || C <= 0 || ld < R * C) return MTP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    RrBatch t;
+    for (int i = 0; i < n; ++i) {
+        if (!parts[i] || !outs[i]) return MTP_ERR_ARG;
+        t.part[i] = parts[i];
+        t.out[i] = outs[i];
+        if (!accumulate) {
+            hipError_t e = hipMemsetAsync(outs[i], 0, sizeof(float) * (size_t)(R * C), s);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    const int64_t col_blocks = (R * C + 255) / 256;
+    int64_t splits = 1024 / col_blocks;
+    if (splits < 1) splits = 1;
+    if (splits > rows) splits = rows;
+    const int64_t rpb = (rows + splits - 1) / splits;
+    splits = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(reduce_rows_t_batched_kernel, dim3((unsigned)col_blocks, (unsigned)splits, (unsigned)n), dim3(256), 0, s, t, ld, rows, (int)R, (int)C, rpb);
     return mtp_launch_status();
 }
 

@@ -37,6 +37,7 @@ class BackboneEngine:
         self.out_indices = list(module.out_indices)
         self._key = None
         self._ln_parts = []
+        self._sl_jobs = []
         self._blk = None
         self._fpn = None
         self._pe = None
@@ -140,6 +141,8 @@ class BackboneEngine:
     def _ln_flush(self):
         if self._ln_parts:
             ops.reduce_rows_deferred(self._ln_parts)
+        if self._sl_jobs:
+            ops.small_linear_dw_segments_flush(self._sl_jobs)
 
     def _full_rel(self, pre, Hp, Wp):
         """decomposed rel-pos tables of a full-attention block; zero tables for the ViTDet-style fine-tune copies, whose full
@@ -238,11 +241,12 @@ class BackboneEngine:
             ops.rvsa_attn_bwd(s["qkv"], s["samp"], s["o"], do, s["lse"], dqkv, dsamp,
                               P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], P[pre + "attn.relative_position_bias_table"],
                               G[pre + "attn.rel_pos_h"], G[pre + "attn.rel_pos_w"], G[pre + "attn.relative_position_bias_table"],
-                              B, Hp, Wp, H, self.scale, accumulate=True)
+                              B, Hp, Wp, H, self.scale, accumulate=True, defer=self._ln_parts)
             names = ("sampling_offsets", "sampling_scales", "sampling_angles")
-            # the stacked heads' weight / bias gradients accumulate straight into the three parameters' buffers
-            ops.small_linear_dw_segments(s["pooled"], dsamp, [G[pre + "attn.%s.2.weight" % n].view(-1, C) for n in names],
-                                         [G[pre + "attn.%s.2.bias" % n] for n in names])
+            # the stacked heads' weight / bias gradients accumulate straight into the three parameters' buffers; queued, one launch per burst of
+            # blocks (round 4: 20 launches of 18 us that are pure latency -> one per weight-gradient group)
+            self._sl_jobs.append((s["pooled"], dsamp, [G[pre + "attn.%s.2.weight" % n].view(-1, C) for n in names],
+                                  [G[pre + "attn.%s.2.bias" % n] for n in names]))
         else:
             rel_h, rel_w = self._full_rel(pre, Hp, Wp)
             if pre + "attn.full_attn_rel_pos_h" in G:
@@ -251,7 +255,7 @@ class BackboneEngine:
             else:   # ViTDet-style copies: no such parameters -- the table gradients go to a scratch buffer
                 drel_h, drel_w = self._e(*rel_h.shape, dtype=F32), self._e(*rel_w.shape, dtype=F32)
             ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, self.heads, self.scale,
-                              accumulate=True)
+                              accumulate=True, defer=self._ln_parts)
         wq.add(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], G[pre + "attn.qkv.bias"])
         dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         win_add = None
@@ -417,6 +421,7 @@ class BackboneEngine:
         P = self.P
         self.dev = ctx["cols"].device
         self._ln_parts = []
+        self._sl_jobs = []
         # weight gradients (FPN deconvolutions, the blocks' Linears, patch embed) are queued and launched in bursts (ops.WgradQueue)
         self._wq = wq = ops.WgradQueue(stream=self._wgrad_stream())
         if ctx["fctx"].get("taps_only"):

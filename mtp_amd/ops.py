@@ -298,18 +298,25 @@ REDUCE_BATCH_MAX = 32
 
 
 def reduce_rows_deferred(items):
-    """items: (part (rows, cols) f32, out (first of `cols` contiguous floats), accumulate) triples queued by layernorm_bwd(defer=...);
-    equally-shaped ones go out together, <= REDUCE_BATCH_MAX per launch (mtp_reduce_rows_batched_f32).  Empties the list."""
+    """items: (part (rows, cols) f32, out (first of `cols` contiguous floats), accumulate[, (R, C)]) tuples queued by layernorm_bwd(defer=...) /
+    rvsa_attn_bwd(defer=...); equally-shaped ones go out together, <= REDUCE_BATCH_MAX per launch (mtp_reduce_rows_batched_f32; with (R, C) the
+    transposed form mtp_reduce_rows_t_batched_f32: column a * C + b -> out[b * R + a]).  Empties the list."""
     groups = {}
-    for part, out, acc in items:
-        groups.setdefault((tuple(part.shape), part.stride(0), bool(acc)), []).append((part, out))
-    for ((rows, cols), ld, acc), g in groups.items():
+    for it in items:
+        part, out, acc = it[:3]
+        tr = it[3] if len(it) > 3 else None
+        groups.setdefault((tuple(part.shape), part.stride(0), bool(acc), tr), []).append((part, out))
+    for ((rows, cols), ld, acc, tr), g in groups.items():
         for i0 in range(0, len(g), REDUCE_BATCH_MAX):
             chunk = g[i0:i0 + REDUCE_BATCH_MAX]
             n = len(chunk)
             P = C.c_void_p * n
-            check(lib().mtp_reduce_rows_batched_f32(P(*[c[0].data_ptr() for c in chunk]), P(*[c[1].data_ptr() for c in chunk]), n, ld, rows, cols,
-                                                    int(acc), _s()), "mtp_reduce_rows_batched_f32")
+            if tr is None:
+                check(lib().mtp_reduce_rows_batched_f32(P(*[c[0].data_ptr() for c in chunk]), P(*[c[1].data_ptr() for c in chunk]), n, ld, rows, cols,
+                                                        int(acc), _s()), "mtp_reduce_rows_batched_f32")
+            else:
+                check(lib().mtp_reduce_rows_t_batched_f32(P(*[c[0].data_ptr() for c in chunk]), P(*[c[1].data_ptr() for c in chunk]), n, ld, rows, tr[0], tr[1],
+                                                          int(acc), _s()), "mtp_reduce_rows_t_batched_f32")
     del items[:]
 
 
@@ -486,7 +493,7 @@ def full_attn_fwd(qkv, o, lse, rel_h, rel_w, B, Hp, Wp, heads, scale):
     return o, lse
 
 
-def full_attn_bwd(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, heads, scale, accumulate=False):
+def full_attn_bwd(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, heads, scale, accumulate=False, defer=None):
     hd = qkv.shape[1] // (3 * heads)
     rt = (2 * Hp - 1) + (2 * Wp - 1)
     part = torch.empty(B * heads, rt * hd, device=qkv.device, dtype=torch.float32)
@@ -494,6 +501,9 @@ def full_attn_bwd(qkv, o, dout, lse, dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, 
     ws = torch.empty(nws, device=qkv.device, dtype=torch.float32) if nws else None
     check(lib().mtp_full_attn_bwd(_p(qkv), _p(o), _p(dout), _f32(lse), _p(dqkv), _dt(qkv), _f32(rel_h), _f32(rel_w), _p(part), _p(ws),
                                   B, Hp, Wp, heads, hd, scale, _s()), "mtp_full_attn_bwd")
+    if defer is not None and _adjacent(drel_h, drel_w) and drel_h.numel() == (2 * Hp - 1) * hd:
+        defer.append((part, drel_h, accumulate))       # reduced with the burst's other partial rows (reduce_rows_deferred)
+        return dqkv
     _reduce_pair(part, (2 * Hp - 1) * hd, drel_h, drel_w, accumulate)   # per-(image, head) partials -> the two parameters
     return dqkv
 
@@ -555,6 +565,28 @@ def small_linear_dw_segments(x, dy, dws, dbs):
           "mtp_small_linear_dw_segments")
 
 
+SL_BATCH = 8
+
+
+def small_linear_dw_segments_flush(jobs):
+    """jobs: (x, dy, dws, dbs) tuples queued instead of small_linear_dw_segments calls (the stacked sampling heads of a burst of RVSA blocks):
+    equally-shaped ones go out together, <= SL_BATCH per launch.  Empties the list."""
+    groups = {}
+    for x, dy, dws, dbs in jobs:
+        groups.setdefault((tuple(x.shape), tuple(dy.shape), tuple(d.shape[0] for d in dws)), []).append((x, dy, dws, dbs))
+    for ((R, K), (_, N), rows_), g in groups.items():
+        nseg = len(rows_)
+        rows = (C.c_int64 * nseg)(*rows_)
+        for i0 in range(0, len(g), SL_BATCH):
+            chunk = g[i0:i0 + SL_BATCH]
+            n = len(chunk)
+            P, PS = C.c_void_p * n, C.c_void_p * (n * nseg)
+            check(lib().mtp_small_linear_dw_segments_batched(P(*[_f32(c[0]) for c in chunk]), P(*[_f32(c[1]) for c in chunk]), n, R, N, K, nseg, rows,
+                                                             PS(*[_f32(d) for c in chunk for d in c[2]]), PS(*[_f32(d) for c in chunk for d in c[3]]), _s()),
+                  "mtp_small_linear_dw_segments_batched")
+    del jobs[:]
+
+
 def rvsa_attn_fwd(qkv, samp, o, lse, rel_h, rel_w, table, B, Hp, Wp, heads, scale):
     hd = qkv.shape[1] // (3 * heads)
     check(lib().mtp_rvsa_attn_fwd(_p(qkv), _f32(samp), _p(o), _f32(lse), _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table),
@@ -562,7 +594,7 @@ def rvsa_attn_fwd(qkv, samp, o, lse, rel_h, rel_w, table, B, Hp, Wp, heads, scal
     return o, lse
 
 
-def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, drel_h, drel_w, dtable, B, Hp, Wp, heads, scale, accumulate=False):
+def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, drel_h, drel_w, dtable, B, Hp, Wp, heads, scale, accumulate=False, defer=None):
     hd = qkv.shape[1] // (3 * heads)
     T, C3 = qkv.shape
     Cc = C3 // 3
@@ -574,6 +606,11 @@ def rvsa_attn_bwd(qkv, samp, o, dout, lse, dqkv, dsamp, rel_h, rel_w, table, dre
     tab_part = torch.empty(B * nh * nw, heads * 169, device=dev, dtype=torch.float32)     # (window, head, 169): contiguous per workgroup
     check(lib().mtp_rvsa_attn_bwd(_p(qkv), _f32(samp), _p(o), _p(dout), _f32(lse), _p(dqkv), _p(dkv), _f32(dsamp), _p(rel_part), _p(tab_part),
                                   _dt(qkv), _f32(rel_h), _f32(rel_w), _f32(table), B, Hp, Wp, heads, hd, scale, _s()), "mtp_rvsa_attn_bwd")
+    if defer is not None and _adjacent(drel_h, drel_w) and drel_h.numel() == 13 * hd:
+        # the partial rows wait for the burst's reduction launch (reduce_rows_deferred): one launch per burst of blocks instead of two per block
+        defer.append((rel_part, drel_h, accumulate))
+        defer.append((tab_part, dtable, accumulate, (heads, 169)))
+        return dqkv
     _reduce_pair(rel_part, 13 * hd, drel_h, drel_w, accumulate)   # per-workgroup partials -> the parameters, no staging copies
     # per-(window, head) partials (heads, 169) -> the (169, heads) parameter gradient: one launch, transposed on the way
     check(lib().mtp_reduce_rows_t_f32(_p(tab_part), tab_part.shape[1], _f32(dtable), tab_part.shape[0], heads, 169, int(accumulate), _s()),
