@@ -141,7 +141,7 @@ __device__ __forceinline__ void v3_bias_rows(const V3Geom& g, const char* RhI, c
 // row count every key-tile step sits in its own branch, which pins its LDS reads and its chain of four dependent MFMAs between two waits;
 // with a constant the compiler batches the reads of all tiles and interleaves their independent accumulation chains.
 template <int NW, int HPT>
-__global__ __launch_bounds__(64 * NW) void v3_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+__global__ __launch_bounds__(64 * NW, 2) void v3_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                          const float* __restrict__ rel_h, const float* __restrict__ rel_w, V3Geom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int NR = g.NPR - 16;      // (the forward's transposed V fragments stay inside 32 KK rows)
