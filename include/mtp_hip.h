@@ -129,6 +129,16 @@ int mtp_layernorm_bwd_win(const void* dy, int dy_dtype, const void* x, int x_dty
                           void* dx_copy, int copy_dtype, const float* copy_scale, int64_t rows_per_sample,
                           float* dgamma_part, float* dbeta_part, int64_t part_ld, int64_t rows, int64_t C,
                           const float* win_add, int64_t B, int64_t Hp, int64_t Wp, mtp_stream_t stream);
+/* InternImage's post-norm residual (intern_image.py:424-426) in one pass each way (round 4):
+ *   forward   out (rows, C) f32 = x + sample_scale[row / rows_per_sample] * layer_scale * LayerNorm(h);  out_act = its ACT copy (optional); h in `dtype`
+ *   backward  dh (`dtype`) = LN'(s * layer_scale * dout);  part: (mtp_layernorm_bwd_partial_rows(rows), 3 C) f32 = per-workgroup partials of
+ *             [d gamma | d beta | d layer_scale], d layer_scale = sum_rows s * dout * LN(h) with LN(h) recomputed from mean / rstd. */
+int mtp_layernorm_residual_fwd(const void* h, int dtype, const float* gamma, const float* beta, const float* x, const float* layer_scale,
+                               const float* sample_scale, int64_t rows_per_sample, float* out, void* out_act, float* mean, float* rstd,
+                               int64_t rows, int64_t C, float eps, mtp_stream_t stream);
+int mtp_layernorm_residual_bwd(const float* dout, const void* h, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               const float* layer_scale, const float* sample_scale, int64_t rows_per_sample, void* dh, float* part,
+                               int64_t rows, int64_t C, mtp_stream_t stream);
 /* out[c] (+)= sum_r part[r * ld + c], c < C   (per-workgroup partials -> parameter gradient; ld >= C lets one
  * partial buffer feed several parameters) */
 int mtp_reduce_rows_f32(const float* part, int64_t ld, float* out, int64_t rows, int64_t C, int accumulate, mtp_stream_t stream);

@@ -103,6 +103,8 @@ SIGNATURES = {
     "mtp_rvsa_sampling_fwd": (i32, [p, i32, p, p, p, p, p, i64, i64, i64, i64, i64, p]),
     "mtp_rvsa_sampling_bwd": (i32, [p, p, p, p, i32, i64, i64, i64, i64, i64, p]),
     "mtp_rvsa_sampling_bwd_win": (i32, [p, p, p, p, i64, i64, i64, p]),
+    "mtp_layernorm_residual_fwd": (i32, [p, i32, p, p, p, p, p, i64, p, p, p, p, i64, i64, f32, p]),
+    "mtp_layernorm_residual_bwd": (i32, [p, p, i32, p, p, p, p, p, p, i64, p, p, i64, i64, p]),
     "mtp_layernorm_bwd_win": (i32, [p, i32, p, i32, p, p, p, p, p, p, i32, p, i32, p, i64, p, p, i64, i64, i64, p, i64, i64, i64, p]),
     "mtp_small_linear_fwd": (i32, [p, p, p, p, i64, i64, i64, p]),
     "mtp_small_linear_bwd": (i32, [p, p, p, p, p, p, i64, i64, i64, p]),

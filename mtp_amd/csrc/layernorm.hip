@@ -178,6 +178,152 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const Tact* __restri
     }
 }
 
+// ---- InternImage's post-norm residual (intern_image.py:424-426) in ONE pass each way (round 4; was LayerNorm + scale_residual, two launches
+// and a bf16 round trip of the normalised rows each way):   out = x + s[sample] * ls * LayerNorm(h)
+//   forward: reads h (ACT) and x (f32), writes out (f32), its ACT copy, mean / rstd.
+//   backward: dout (f32) -> dh (ACT) = LN'(s * ls * dout); partials per workgroup [dgamma | dbeta | dls] with dls = sum_rows s * dout * z,
+//   z = xhat * gamma + beta recomputed from the saved statistics (never stored).
+template <typename Th, int MV>
+__global__ __launch_bounds__(LN_THREADS) void ln_res_fwd_kernel(const Th* __restrict__ h, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ x, const float* __restrict__ ls, const float* __restrict__ sample_scale,
+                                                               int rows_per_sample, float* __restrict__ out, Th* __restrict__ out_act,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    int col[MV];
+    bool ok[MV];
+    float4 g[MV], bb[MV], lv[MV];
+#pragma unroll
+    for (int i = 0; i < MV; ++i) {
+        const int c4 = lane + 64 * i;
+        ok[i] = c4 < nv;
+        col[i] = 4 * (ok[i] ? c4 : nv - 1);
+        g[i] = *reinterpret_cast<const float4*>(gamma + col[i]);
+        bb[i] = *reinterpret_cast<const float4*>(beta + col[i]);
+        lv[i] = *reinterpret_cast<const float4*>(ls + col[i]);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float4 v[MV], xv[MV];
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            v[i] = load4(h + row * C + col[i]);
+            xv[i] = *reinterpret_cast<const float4*>(x + row * C + col[i]);
+        }
+        const float sc = sample_scale ? sample_scale[(uint32_t)row / (uint32_t)rows_per_sample] : 1.0f;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MV; ++i) s += ok[i] ? (v[i].x + v[i].y + v[i].z + v[i].w) : 0.f;
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+            q += ok[i] ? (a * a + b * b + c * c + d * d) : 0.f;
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            const float4 z = make_float4((v[i].x - mu) * rs * g[i].x + bb[i].x, (v[i].y - mu) * rs * g[i].y + bb[i].y,
+                                         (v[i].z - mu) * rs * g[i].z + bb[i].z, (v[i].w - mu) * rs * g[i].w + bb[i].w);
+            const float4 o = make_float4(xv[i].x + sc * lv[i].x * z.x, xv[i].y + sc * lv[i].y * z.y, xv[i].z + sc * lv[i].z * z.z, xv[i].w + sc * lv[i].w * z.w);
+            if (ok[i]) {
+                *reinterpret_cast<float4*>(out + row * C + col[i]) = o;
+                if (out_act) store4(out_act + row * C + col[i], o);
+            }
+        }
+    }
+}
+
+template <typename Th, int MV>
+__global__ __launch_bounds__(LN_THREADS) void ln_res_bwd_kernel(const float* __restrict__ dout, const Th* __restrict__ h, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ ls, const float* __restrict__ sample_scale, int rows_per_sample,
+                                                               Th* __restrict__ dh, float* __restrict__ part, int64_t rows, int C) {
+    __shared__ float4 red[3][3][64 * MV];   // [dgamma | dbeta | dls] of waves 1..3 -> wave 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    float4 gacc[MV], bacc[MV], lacc[MV], g[MV], bt[MV], lv[MV];
+    int col[MV];
+    bool ok[MV];
+#pragma unroll
+    for (int i = 0; i < MV; ++i) {
+        gacc[i] = make_float4(0, 0, 0, 0);
+        bacc[i] = make_float4(0, 0, 0, 0);
+        lacc[i] = make_float4(0, 0, 0, 0);
+        const int c4 = lane + 64 * i;
+        ok[i] = c4 < nv;
+        col[i] = 4 * (ok[i] ? c4 : nv - 1);
+        g[i] = *reinterpret_cast<const float4*>(gamma + col[i]);
+        bt[i] = *reinterpret_cast<const float4*>(beta + col[i]);
+        lv[i] = *reinterpret_cast<const float4*>(ls + col[i]);
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float4 xv[MV], dv[MV];
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            xv[i] = load4(h + row * C + col[i]);
+            dv[i] = *reinterpret_cast<const float4*>(dout + row * C + col[i]);
+        }
+        const float mu = mean[row], rs = rstd[row];
+        const float sc = sample_scale ? sample_scale[(uint32_t)row / (uint32_t)rows_per_sample] : 1.0f;
+        float4 xh[MV], d[MV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            if (!ok[i]) dv[i] = zero4;
+            xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
+            const float4 sd = make_float4(sc * dv[i].x, sc * dv[i].y, sc * dv[i].z, sc * dv[i].w);
+            lacc[i].x += sd.x * (xh[i].x * g[i].x + bt[i].x); lacc[i].y += sd.y * (xh[i].y * g[i].y + bt[i].y);
+            lacc[i].z += sd.z * (xh[i].z * g[i].z + bt[i].z); lacc[i].w += sd.w * (xh[i].w * g[i].w + bt[i].w);
+            const float4 dy = make_float4(sd.x * lv[i].x, sd.y * lv[i].y, sd.z * lv[i].z, sd.w * lv[i].w);     // gradient of the LayerNorm output
+            gacc[i].x += dy.x * xh[i].x; gacc[i].y += dy.y * xh[i].y; gacc[i].z += dy.z * xh[i].z; gacc[i].w += dy.w * xh[i].w;
+            bacc[i].x += dy.x; bacc[i].y += dy.y; bacc[i].z += dy.z; bacc[i].w += dy.w;
+            d[i] = make_float4(dy.x * g[i].x, dy.y * g[i].y, dy.z * g[i].z, dy.w * g[i].w);
+            s1 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
+            s2 += d[i].x + d[i].y + d[i].z + d[i].w;
+        }
+        const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < MV; ++i)
+            if (ok[i])
+                store4(dh + row * C + col[i], make_float4((d[i].x - xh[i].x * c1 - c2) * rs, (d[i].y - xh[i].y * c1 - c2) * rs,
+                                                          (d[i].z - xh[i].z * c1 - c2) * rs, (d[i].w - xh[i].w * c1 - c2) * rs));
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            red[0][wave - 1][lane + 64 * i] = gacc[i];
+            red[1][wave - 1][lane + 64 * i] = bacc[i];
+            red[2][wave - 1][lane + 64 * i] = lacc[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* prow = part + (int64_t)blockIdx.x * 3 * C;
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            if (ok[i]) {
+                float4 a = gacc[i], b = bacc[i], l = lacc[i];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const float4 ra = red[0][w][lane + 64 * i], rb = red[1][w][lane + 64 * i], rl = red[2][w][lane + 64 * i];
+                    a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w;
+                    b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
+                    l.x += rl.x; l.y += rl.y; l.z += rl.z; l.w += rl.w;
+                }
+                *reinterpret_cast<float4*>(prow + col[i]) = a;
+                *reinterpret_cast<float4*>(prow + C + col[i]) = b;
+                *reinterpret_cast<float4*>(prow + 2 * C + col[i]) = l;
+            }
+        }
+    }
+}
+
 // sum of rows r0..r1 of one column: four independent loads in flight per thread (one 4-byte load at a time ran at ~1.8 TB/s out of L2)
 __device__ __forceinline__ float column_sum(const float* __restrict__ col, int64_t ld, int64_t r0, int64_t r1) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -331,6 +477,48 @@ extern "C" int mtp_layernorm_fwd(const void* x, int x_dtype, const float* gamma,
     if (x_dtype == MTP_F32 && y_dtype == MTP_BF16) return launch_ln_fwd<float, bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, fuse_gelu, s);
     if (x_dtype == MTP_BF16 && y_dtype == MTP_BF16) return launch_ln_fwd<bf16_t, bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, fuse_gelu, s);
     if (x_dtype == MTP_BF16 && y_dtype == MTP_F32) return launch_ln_fwd<bf16_t, float>(x, gamma, beta, y, mean, rstd, rows, C, eps, fuse_gelu, s);
+    return MTP_ERR_UNSUPPORTED;
+}
+
+template <typename Th>
+static int launch_ln_res(bool fwd, const void* a0, const void* h, const float* mean_c, float* mean, const float* rstd_c, float* rstd, const float* gamma, const float* beta,
+                         const float* x, const float* ls, const float* ss, int rps, float* out, void* oact, void* dh, float* part, int64_t rows, int64_t C, float eps,
+                         hipStream_t s) {
+    if (fwd) {
+        const dim3 grid(ln_grid(rows)), block(LN_THREADS);
+        if (C > 1024)
+            hipLaunchKernelGGL((ln_res_fwd_kernel<Th, 8>), grid, block, 0, s, (const Th*)h, gamma, beta, x, ls, ss, rps, out, (Th*)oact, mean, rstd, rows, (int)C, eps);
+        else
+            hipLaunchKernelGGL((ln_res_fwd_kernel<Th, 4>), grid, block, 0, s, (const Th*)h, gamma, beta, x, ls, ss, rps, out, (Th*)oact, mean, rstd, rows, (int)C, eps);
+    } else {
+        const dim3 grid((unsigned)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512)), block(LN_THREADS);
+        if (C > 1024)
+            hipLaunchKernelGGL((ln_res_bwd_kernel<Th, 8>), grid, block, 0, s, (const float*)a0, (const Th*)h, mean_c, rstd_c, gamma, beta, ls, ss, rps, (Th*)dh, part, rows, (int)C);
+        else
+            hipLaunchKernelGGL((ln_res_bwd_kernel<Th, 4>), grid, block, 0, s, (const float*)a0, (const Th*)h, mean_c, rstd_c, gamma, beta, ls, ss, rps, (Th*)dh, part, rows, (int)C);
+    }
+    return mtp_launch_status();
+}
+
+extern "C" int mtp_layernorm_residual_fwd(const void* h, int dtype, const float* gamma, const float* beta, const float* x, const float* layer_scale,
+                                          const float* sample_scale, int64_t rows_per_sample, float* out, void* out_act, float* mean, float* rstd,
+                                          int64_t rows, int64_t C, float eps, mtp_stream_t stream) {
+    if (!h || !gamma || !beta || !x || !layer_scale || !out || !mean || !rstd || rows <= 0 || rows > INT32_MAX || C <= 0 || (C % 4) || C > 256 * MAXV) return MTP_ERR_ARG;
+    if (sample_scale && rows_per_sample <= 0) return MTP_ERR_ARG;
+    const int rps = (int)(rows_per_sample > 0 ? rows_per_sample : 1);
+    if (dtype == MTP_BF16) return launch_ln_res<bf16_t>(true, nullptr, h, nullptr, mean, nullptr, rstd, gamma, beta, x, layer_scale, sample_scale, rps, out, out_act, nullptr, nullptr, rows, C, eps, (hipStream_t)stream);
+    if (dtype == MTP_F32) return launch_ln_res<float>(true, nullptr, h, nullptr, mean, nullptr, rstd, gamma, beta, x, layer_scale, sample_scale, rps, out, out_act, nullptr, nullptr, rows, C, eps, (hipStream_t)stream);
+    return MTP_ERR_UNSUPPORTED;
+}
+
+extern "C" int mtp_layernorm_residual_bwd(const float* dout, const void* h, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                          const float* layer_scale, const float* sample_scale, int64_t rows_per_sample, void* dh, float* part,
+                                          int64_t rows, int64_t C, mtp_stream_t stream) {
+    if (!dout || !h || !mean || !rstd || !gamma || !beta || !layer_scale || !dh || !part || rows <= 0 || rows > INT32_MAX || C <= 0 || (C % 4) || C > 256 * MAXV) return MTP_ERR_ARG;
+    if (sample_scale && rows_per_sample <= 0) return MTP_ERR_ARG;
+    const int rps = (int)(rows_per_sample > 0 ? rows_per_sample : 1);
+    if (dtype == MTP_BF16) return launch_ln_res<bf16_t>(false, dout, h, mean, nullptr, rstd, nullptr, gamma, beta, nullptr, layer_scale, sample_scale, rps, nullptr, nullptr, dh, part, rows, C, 0.f, (hipStream_t)stream);
+    if (dtype == MTP_F32) return launch_ln_res<float>(false, dout, h, mean, nullptr, rstd, nullptr, gamma, beta, nullptr, layer_scale, sample_scale, rps, nullptr, nullptr, dh, part, rows, C, 0.f, (hipStream_t)stream);
     return MTP_ERR_UNSUPPORTED;
 }
 

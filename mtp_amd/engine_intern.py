@@ -177,24 +177,25 @@ class InternEngine:
         y = dcn.dcnv3_forward(xp.view(N, H, W, C), off.view(N, H, W, -1), mask.view(N, H, W, -1), K, K, 1, 1, pad, pad, 1, 1, G, C // G,
                               self.m.offset_scale, 256).view(rows, C)
         h = self._linear(y, d + "output_proj.weight", P[d + "output_proj.bias"])
-        z1, m1, r1 = self._ln(h, P, pre + "norm1.0")
+        # x2 = x + s1 * gamma1 * LN1(h): LayerNorm and the layer-scale residual in one pass (round 4: were two launches and a bf16 round trip)
         s1 = scales[0] if scales is not None else None
         x32b, xab = self._e(rows, C, dtype=F32), self._e(rows, C)
-        ops.scale_residual_fwd(x32, z1, P[pre + "gamma1"], x32b, xab, s1, H * W)
+        m1, r1 = self._e(rows, dtype=F32), self._e(rows, dtype=F32)
+        ops.layernorm_residual_fwd(h, P[pre + "norm1.0.weight"], P[pre + "norm1.0.bias"], x32, P[pre + "gamma1"], x32b, xab, m1, r1, s1, H * W)
         # MLPLayer: fc1 -> GELU -> fc2 (dropout p = 0); fc1 stores gelu'(u) next to gelu(u) for the backward
         L1 = self._lin[pre + "mlp.fc1.weight"]
         u = self._e(rows, L1.R)
         ug = self._e(rows, L1.R) if save else None
         ops.gemm_nt(xab, L1.w, u, epi=(ops.EPI_BIAS_GELU_DG if save else ops.EPI_BIAS_GELU), bias=P[pre + "mlp.fc1.bias"], aux=ug)
         v = self._linear(u, pre + "mlp.fc2.weight", P[pre + "mlp.fc2.bias"])
-        z2, m2, r2 = self._ln(v, P, pre + "norm2.0")
         s2 = scales[1] if scales is not None else None
         x32c, xac = self._e(rows, C, dtype=F32), self._e(rows, C)
-        ops.scale_residual_fwd(x32b, z2, P[pre + "gamma2"], x32c, xac, s2, H * W)
+        m2, r2 = self._e(rows, dtype=F32), self._e(rows, dtype=F32)
+        ops.layernorm_residual_fwd(v, P[pre + "norm2.0.weight"], P[pre + "norm2.0.bias"], x32b, P[pre + "gamma2"], x32c, xac, m2, r2, s2, H * W)
         ctx = None
         if save:
-            ctx = dict(xa=xa, xp=xp, x1c=x1c, m0=m0, r0=r0, x1=x1, off=off, mask=mask, y=y, h=h, m1=m1, r1=r1, z1=z1, xab=xab, u=u, ug=ug, v=v,
-                       m2=m2, r2=r2, z2=z2, s1=s1, s2=s2)
+            ctx = dict(xa=xa, xp=xp, x1c=x1c, m0=m0, r0=r0, x1=x1, off=off, mask=mask, y=y, h=h, m1=m1, r1=r1, xab=xab, u=u, ug=ug, v=v,
+                       m2=m2, r2=r2, s1=s1, s2=s2)
         return x32c, xac, ctx
 
     def _layer_bwd(self, pre, c, dx32, N, H, W, C, G, Gd):
@@ -205,16 +206,16 @@ class InternEngine:
         Pn = K * K
         d = pre + "dcn."
         # ---- x3 = x2 + s2 * gamma2 * LN2(fc2(gelu(fc1(x2))))
-        dz2 = ops.scale_residual_bwd(dx32, c["z2"], P[pre + "gamma2"], self._e(rows, C), Gd[pre + "gamma2"], c["s2"], H * W, accumulate=True)
-        dv = self._ln_bwd(dz2, c["v"], c["m2"], c["r2"], P, Gd, pre + "norm2.0")
+        dv = ops.layernorm_residual_bwd(dx32, c["v"], c["m2"], c["r2"], P[pre + "norm2.0.weight"], P[pre + "norm2.0.bias"], P[pre + "gamma2"], self._e(rows, C),
+                                        Gd[pre + "norm2.0.weight"], Gd[pre + "norm2.0.bias"], Gd[pre + "gamma2"], c["s2"], H * W, defer=self._ln_parts)
         L1, L2 = self._lin[pre + "mlp.fc1.weight"], self._lin[pre + "mlp.fc2.weight"]
         self._wq.add(dv, c["u"], Gd[pre + "mlp.fc2.weight"], Gd[pre + "mlp.fc2.bias"])
         du = ops.gemm_nt(dv, L2.wt, self._e(rows, L1.R), epi=ops.EPI_MUL, aux=c["ug"])
         self._wq.add(du, c["xab"], Gd[pre + "mlp.fc1.weight"], Gd[pre + "mlp.fc1.bias"])
         dx2 = ops.gemm_nt(du, L1.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx32)      # + the residual path
         # ---- x2 = x + s1 * gamma1 * LN1(output_proj(dcnv3(...)))
-        dz1 = ops.scale_residual_bwd(dx2, c["z1"], P[pre + "gamma1"], self._e(rows, C), Gd[pre + "gamma1"], c["s1"], H * W, accumulate=True)
-        dh = self._ln_bwd(dz1, c["h"], c["m1"], c["r1"], P, Gd, pre + "norm1.0")
+        dh = ops.layernorm_residual_bwd(dx2, c["h"], c["m1"], c["r1"], P[pre + "norm1.0.weight"], P[pre + "norm1.0.bias"], P[pre + "gamma1"], self._e(rows, C),
+                                        Gd[pre + "norm1.0.weight"], Gd[pre + "norm1.0.bias"], Gd[pre + "gamma1"], c["s1"], H * W, defer=self._ln_parts)
         Lo = self._lin[d + "output_proj.weight"]
         self._wq.add(dh, c["y"], Gd[d + "output_proj.weight"], Gd[d + "output_proj.bias"])
         dy = ops.gemm_nt(dh, Lo.wt, self._e(rows, C))

@@ -294,6 +294,31 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, beta=None, gelu=F
     return dx
 
 
+def layernorm_residual_fwd(h, gamma, beta, x, layer_scale, out, out_act, mean, rstd, sample_scale=None, rows_per_sample=0, eps=1e-6):
+    """out (f32) = x + sample_scale[row / rows_per_sample] * layer_scale * LayerNorm(h); out_act = its ACT copy (InternImage's post-norm residual)"""
+    rows, Cc = h.shape
+    check(lib().mtp_layernorm_residual_fwd(_p(h), _dt(h), _f32(gamma), _f32(beta), _f32(x), _f32(layer_scale), _f32(sample_scale), rows_per_sample,
+                                           _f32(out), _p(out_act), _f32(mean), _f32(rstd), rows, Cc, eps, _s()), "mtp_layernorm_residual_fwd")
+    return out
+
+
+def layernorm_residual_bwd(dout, h, mean, rstd, gamma, beta, layer_scale, dh, dgamma, dbeta, dls, sample_scale=None, rows_per_sample=0, defer=None):
+    """dh = LN'(s * layer_scale * dout); dgamma / dbeta / dls (C,) f32 ACCUMULATE the three parameter gradients (deferred with `defer`)"""
+    rows, Cc = h.shape
+    nblk = lib().mtp_layernorm_bwd_partial_rows(rows)
+    part = torch.empty(nblk, 3 * Cc, device=h.device, dtype=torch.float32)
+    check(lib().mtp_layernorm_residual_bwd(_f32(dout), _p(h), _dt(h), _f32(mean), _f32(rstd), _f32(gamma), _f32(beta), _f32(layer_scale), _f32(sample_scale),
+                                           rows_per_sample, _p(dh), part.data_ptr(), rows, Cc, _s()), "mtp_layernorm_residual_bwd")
+    pair = _adjacent(dgamma, dbeta) and dgamma.numel() == Cc
+    if defer is not None and pair:
+        defer.append((part[:, :2 * Cc], dgamma, True))
+        defer.append((part[:, 2 * Cc:], dls, True))
+    else:
+        _reduce_pair(part[:, :2 * Cc], Cc, dgamma, dbeta, True)
+        reduce_rows(part[:, 2 * Cc:], dls, True)
+    return dh
+
+
 REDUCE_BATCH_MAX = 32
 
 

@@ -156,6 +156,29 @@ def test_layernorm_beyond_1024_channels(C):
     assert rel_err(dx.cpu(), xr.grad) < 1e-4 and rel_err(dgm.cpu(), gr.grad) < 1e-4 and rel_err(dbt.cpu(), br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(300, 192), (70, 1536)])
+def test_layernorm_residual_fused_fwd_bwd(dtype, rows, C):
+    """out = x + s[sample] * layer_scale * LayerNorm(h) (intern_image.py:424-426) in one pass each way, against torch autograd: forward,
+    dh and the three parameter gradients (LayerNorm weight / bias, layer scale); 1536 channels = the 8-float4-per-lane instantiation"""
+    rps = 50
+    ns = (rows + rps - 1) // rps
+    h, x, dout = rnd(rows, C, seed=1).to(dtype).float(), rnd(rows, C, seed=2), rnd(rows, C, seed=3)
+    g, b, ls = 1.0 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5), 0.5 * rnd(C, seed=6)
+    ss = (torch.arange(ns) % 3 != 0).float() / 0.8
+    hr, gr, br, lr = (t.clone().requires_grad_(True) for t in (h, g, b, ls))
+    ref = x + ss.repeat_interleave(rps)[:rows, None] * lr * torch.nn.functional.layer_norm(hr, (C,), gr, br, 1e-6)
+    ref.backward(dout)
+    out, oact, mean, rstd = e(rows, C), e(rows, C, dtype=dtype), e(rows), e(rows)
+    OPS.layernorm_residual_fwd(dev(h).to(dtype), dev(g), dev(b), dev(x), dev(ls), out, oact, mean, rstd, dev(ss), rps)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(out.cpu(), ref.detach()) < 1e-5 and rel_err(oact.float().cpu(), ref.detach()) < tol
+    dh, dg, db, dl = e(rows, C, dtype=dtype), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    OPS.layernorm_residual_bwd(dev(dout), dev(h).to(dtype), mean, rstd, dev(g), dev(b), dev(ls), dh, dg, db, dl, dev(ss), rps)
+    assert rel_err(dh.float().cpu(), hr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    assert rel_err(dg.cpu(), gr.grad) < 1e-4 and rel_err(db.cpu(), br.grad) < 1e-4 and rel_err(dl.cpu(), lr.grad) < 1e-4
+
+
 def test_padded_linear_images_and_casts():
     w = rnd(108, 64, seed=1)
     wp, wpt = e(112, 64, dtype=torch.bfloat16), e(64, 112, dtype=torch.bfloat16)
