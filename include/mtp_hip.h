@@ -343,6 +343,11 @@ int mtp_dcnv3_fwd(const void* input, const void* offset, const void* mask, void*
  * than a pixel beyond the kernel's reach; any other geometry -> bilinear scatter with f32 atomics, like the reference. */
 int mtp_dcnv3_bwd(const void* input, const void* offset, const void* mask, const void* grad_output, int dtype, float* grad_input, float* grad_offset,
                   float* grad_mask, const mtp_dcnv3_geom* geom, mtp_stream_t stream);
+/* The same, and grad_offset once more in the input dtype as rows of act_ld >= group * P * 2 elements (pad columns zero): the operand the offset
+ * head's dgrad / wgrad GEMMs read, written by the kernel that computes it instead of a cast-and-pad pass (round 4).  Only in the gather form of
+ * the backward (every InternImage level); MTP_ERR_UNSUPPORTED otherwise, with nothing launched. */
+int mtp_dcnv3_bwd_act(const void* input, const void* offset, const void* mask, const void* grad_output, int dtype, float* grad_input, float* grad_offset,
+                      float* grad_mask, void* grad_offset_act, int64_t act_ld, const mtp_dcnv3_geom* geom, mtp_stream_t stream);
 
 const char* mtp_version(void);
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mtp_dcnv3_out_size": (i32, [C.POINTER(Dcnv3Geom), C.POINTER(i64), C.POINTER(i64)]),
     "mtp_dcnv3_fwd": (i32, [p, p, p, p, i32, C.POINTER(Dcnv3Geom), p]),
     "mtp_dcnv3_bwd": (i32, [p, p, p, p, i32, p, p, p, C.POINTER(Dcnv3Geom), p]),
+    "mtp_dcnv3_bwd_act": (i32, [p, p, p, p, i32, p, p, p, p, i64, C.POINTER(Dcnv3Geom), p]),
     "mtp_gemm_nt": (i32, [C.POINTER(GemmArgs), p]),
     "mtp_gemm_nt_tile": (i32, [C.POINTER(GemmArgs)]),
     "mtp_gemm_nt_workspace_bytes": (i64, []),

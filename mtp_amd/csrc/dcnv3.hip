@@ -21,6 +21,8 @@ struct DcnGeom {
     int xcd_order;   // 1: each of the 8 XCDs takes a contiguous range of workgroups (= of pixels), see block_index()
     int scatter_bwd; // 1: always the per-corner atomic scatter backward (A/B, variant bit 1)
     int form3x3_bwd; // 1: the 3 x 3 form of the gather backward where it applies (variant bit 2): faster while offsets stay below a pixel, slower beyond
+    void* goff_act;  // mtp_dcnv3_bwd_act: also write grad_offset in the input dtype, rows of goff_act_ld >= G * P * 2 elements (pad columns zeroed)
+    int goff_act_ld;
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring pixels gather from / scatter into the
@@ -500,6 +502,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
     const float p0w = (float)(halfw - g.pw + wo * g.sw) - (float)halfw * g.os;
     const float p0h = (float)(halfh - g.ph + ho * g.sh) - (float)halfh * g.os;
     const int centre = (g.kw / 2) * g.kh + g.kh / 2;
+    if (g.goff_act && live && half == 0 && gi == 0)
+        for (int c = g.G * 2 * g.P; c < g.goff_act_ld; ++c) Elem<T>::store(reinterpret_cast<T*>(g.goff_act) + pix * g.goff_act_ld + c, 0.f);
 #pragma unroll
     for (int grp = 0; grp < 3; ++grp) {
         if (3 * grp >= g.P) break;
@@ -541,7 +545,13 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
             const float lh = pt[q].lh, lw = pt[q].lw, hh = 1.f - lh, hw = 1.f - lw;
             if (live && half == 0 && have) {
                 gmp[p] = hh * hw * d00 + hh * lw * d01 + lh * hw * d10 + lh * lw * d11;
-                *reinterpret_cast<float2*>(goffp + 2 * p) = make_float2(g.os * m * (hh * (d01 - d00) + lh * (d11 - d10)), g.os * m * (hw * (d10 - d00) + lw * (d11 - d01)));
+                const float gw_ = g.os * m * (hh * (d01 - d00) + lh * (d11 - d10)), gh_ = g.os * m * (hw * (d10 - d00) + lw * (d11 - d01));
+                *reinterpret_cast<float2*>(goffp + 2 * p) = make_float2(gw_, gh_);
+                if (g.goff_act) {      // the GEMM-operand copy of the same values (the offset head's dgrad / wgrad read it): no cast-and-pad pass
+                    T* ga = reinterpret_cast<T*>(g.goff_act) + pix * g.goff_act_ld + gi * (2 * g.P) + 2 * p;
+                    Elem<T>::store(ga, gw_);
+                    Elem<T>::store(ga + 1, gh_);
+                }
             }
             // corners the gather form does not reach (per corner, not per sample: a sample astride the edge of the reach sends only its outer corners here)
             const int h0 = (int)floorf(fminf(fmaxf(loc_h[q], -2.f), (float)g.H + 1.f)), w0 = (int)floorf(fminf(fmaxf(loc_w[q], -2.f), (float)g.W + 1.f));
@@ -595,6 +605,8 @@ int make_geom(const mtp_dcnv3_geom* a, DcnGeom& g) {
     g.xcd_order = (a->variant & 1) ? 0 : 1;
     g.scatter_bwd = (a->variant & 2) ? 1 : 0;
     g.form3x3_bwd = (a->variant & 4) ? 1 : 0;
+    g.goff_act = nullptr;
+    g.goff_act_ld = 0;
     return 0;
 }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -653,6 +665,7 @@ int launch_bwd(const void* input, const void* offset, const void* mask, const vo
 #undef MTP_DCN_GATHER
         }
     }
+    if (g.goff_act) return MTP_ERR_UNSUPPORTED;      // (the operand copy exists in the gather form only; the caller casts grad_offset itself)
     hipError_t e = hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)g.N * g.H * g.W * g.G * g.GC, s);   // the reference's at::zeros_like (dcnv3_cuda.cu:131)
     if (e != hipSuccess) return (int)e;
     if (!shfl) {
@@ -689,6 +702,22 @@ extern "C" int mtp_dcnv3_fwd(const void* input, const void* offset, const void* 
     if ((int64_t)g.N * g.Ho * g.Wo * g.G * g.GC >= ((int64_t)1 << 32) - 256) return MTP_ERR_UNSUPPORTED;   // one lane per element at most
     hipStream_t s = (hipStream_t)stream;
     return dtype == MTP_F32 ? launch_fwd<float>(input, offset, mask, output, g, s) : launch_fwd<bf16_t>(input, offset, mask, output, g, s);
+}
+
+extern "C" int mtp_dcnv3_bwd_act(const void* input, const void* offset, const void* mask, const void* grad_output, int dtype, float* grad_input, float* grad_offset,
+                                 float* grad_mask, void* grad_offset_act, int64_t act_ld, const mtp_dcnv3_geom* geom, mtp_stream_t stream) {
+    DcnGeom g;
+    const int rc = make_geom(geom, g);
+    if (rc) return rc;
+    MTP_CHECK_ARG(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask && grad_offset_act);
+    MTP_CHECK_ARG(dtype == MTP_F32 || dtype == MTP_BF16);
+    MTP_CHECK_ARG(act_ld >= (int64_t)g.G * g.P * 2 && act_ld < ((int64_t)1 << 30));
+    if ((int64_t)g.N * g.Ho * g.Wo * g.G * g.GC >= ((int64_t)1 << 32) - 256) return MTP_ERR_UNSUPPORTED;
+    g.goff_act = grad_offset_act;
+    g.goff_act_ld = (int)act_ld;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == MTP_F32 ? launch_bwd<float>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s)
+                            : launch_bwd<bf16_t>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s);
 }
 
 extern "C" int mtp_dcnv3_bwd(const void* input, const void* offset, const void* mask, const void* grad_output, int dtype, float* grad_input, float* grad_offset,

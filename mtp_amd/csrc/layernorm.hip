@@ -543,6 +543,8 @@ extern "C" int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
         return launch_ln_bwd<float, float, float>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s);
     if (dy_dtype == MTP_BF16 && x_dtype == MTP_BF16 && dx_dtype == MTP_BF16)
         return launch_ln_bwd<bf16_t, bf16_t, bf16_t>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s);
+    if (dy_dtype == MTP_F32 && x_dtype == MTP_BF16 && dx_dtype == MTP_BF16)      // f32 gradient straight out of a GEMM's f32 epilogue (InternImage's dw-conv branch): no cast pass
+        return launch_ln_bwd<float, bf16_t, bf16_t>(dy, x, mean, rstd, gamma, beta, fuse_gelu, dres, extra, dx, dx_copy, copy_scale, rows_per_sample, dgamma_part, dbeta_part, part_ld, rows, C, s);
     return MTP_ERR_UNSUPPORTED;
 }
 

@@ -220,17 +220,23 @@ class InternEngine:
         self._wq.add(dh, c["y"], Gd[d + "output_proj.weight"], Gd[d + "output_proj.bias"])
         dy = ops.gemm_nt(dh, Lo.wt, self._e(rows, C))
         pad = K // 2
-        dxp, doff, dmask = dcn.dcnv3_backward(c["xp"].view(N, H, W, C), c["off"].view(N, H, W, -1), c["mask"].view(N, H, W, -1), K, K, 1, 1, pad, pad,
-                                              1, 1, G, C // G, self.m.offset_scale, dy.view(N, H, W, C), 256)
-        # offset / mask heads -> d(x1)
         Lf, Lm = self._lin[d + "offset.weight"], self._lin[d + "mask.weight"]
-        doffa = ops.cast_pad_rows(doff.view(rows, -1), self._e(rows, Lf.Rp)) if (Lf.padded or self.act != F32) else doff.view(rows, -1)
+        doffa = None
+        if self.act != F32:     # grad_offset also as the ACT-dtype, padded GEMM operand, written by the DCNv3 backward itself (round 4: was a cast-and-pad pass)
+            dxp, doff, dmask, doffa = dcn.dcnv3_backward_act(c["xp"].view(N, H, W, C), c["off"].view(N, H, W, -1), c["mask"].view(N, H, W, -1), K, K, 1, 1, pad, pad,
+                                                             1, 1, G, C // G, self.m.offset_scale, dy.view(N, H, W, C), 256, Lf.Rp)
+        else:
+            dxp, doff, dmask = dcn.dcnv3_backward(c["xp"].view(N, H, W, C), c["off"].view(N, H, W, -1), c["mask"].view(N, H, W, -1), K, K, 1, 1, pad, pad,
+                                                  1, 1, G, C // G, self.m.offset_scale, dy.view(N, H, W, C), 256)
+        # offset / mask heads -> d(x1)
+        if doffa is None:
+            doffa = ops.cast_pad_rows(doff.view(rows, -1), self._e(rows, Lf.Rp)) if (Lf.padded or self.act != F32) else doff.view(rows, -1)
         dlog = ops.softmax_groups_bwd(c["mask"], dmask.view(rows, -1), self._e(rows, Lm.Rp), G, Pn)
         self._wgrad(doffa, c["x1"], d + "offset.weight", Gd)
         self._wgrad(dlog, c["x1"], d + "mask.weight", Gd)
         dx1 = ops.gemm_nt(doffa, Lf.wt, self._e(rows, C, dtype=F32))
         dx1 = ops.gemm_nt(dlog, Lm.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx1)
-        dx1c = self._ln_bwd(self._to_act(dx1), c["x1c"], c["m0"], c["r0"], P, Gd, d + "dw_conv.1.1", gelu=True)
+        dx1c = self._ln_bwd(dx1, c["x1c"], c["m0"], c["r0"], P, Gd, d + "dw_conv.1.1", gelu=True)      # (f32 dy, ACT x / dx: no cast pass)
         ops.dwconv3x3_bwd_dw(dx1c, c["xa"], Gd[d + "dw_conv.0.weight"], Gd[d + "dw_conv.0.bias"], N, H, W, accumulate=True)
         # input_proj -> d(x); plus the depth-wise branch and the residual path
         Li = self._lin[d + "input_proj.weight"]

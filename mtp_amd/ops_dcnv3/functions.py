@@ -89,6 +89,28 @@ def dcnv3_backward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, 
     return [grad_input, grad_offset, grad_mask]
 
 
+def dcnv3_backward_act(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, group_channels,
+                       offset_scale, grad_output, im2col_step, act_ld, remove_center=0):
+    """dcnv3_backward plus grad_offset in the input dtype as (N * Ho * Wo, act_ld) rows (pad columns zero) -- the GEMM operand of the offset head's
+    backward, written by the kernel that computes it.  -> [grad_input, grad_offset, grad_mask, grad_offset_act]; grad_offset_act is None when the
+    geometry has no gather-form backward (the caller then casts grad_offset itself)."""
+    _check_inputs([("input", input), ("offset", offset), ("mask", mask), ("grad_output", grad_output)], input, group, group_channels, im2col_step)
+    g = _geom(input, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, group_channels, offset_scale, im2col_step, remove_center)
+    Ho, Wo = out_size(g)
+    if tuple(grad_output.shape) != (input.shape[0], Ho, Wo, group * group_channels):
+        raise RuntimeError("grad_output must be (N, %d, %d, %d)" % (Ho, Wo, group * group_channels))
+    kw = dict(dtype=torch.float32, device=input.device)
+    grad_input, grad_offset, grad_mask = torch.empty(input.shape, **kw), torch.empty(offset.shape, **kw), torch.empty(mask.shape, **kw)
+    act = torch.empty(input.shape[0] * Ho * Wo, act_ld, dtype=input.dtype, device=input.device)
+    rc = lib().mtp_dcnv3_bwd_act(input.data_ptr(), offset.data_ptr(), mask.data_ptr(), grad_output.data_ptr(), _dt(input), grad_input.data_ptr(),
+                                 grad_offset.data_ptr(), grad_mask.data_ptr(), act.data_ptr(), act_ld, C.byref(g), _s())
+    if rc == -2:      # MTP_ERR_UNSUPPORTED: no gather-form backward for this geometry, nothing was launched
+        return dcnv3_backward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, group_channels,
+                              offset_scale, grad_output, im2col_step, remove_center) + [None]
+    _lib.check(rc, "mtp_dcnv3_bwd_act")
+    return [grad_input, grad_offset, grad_mask, act]
+
+
 class DCNv3Function(Function):
     """functions/dcnv3_func.py:22-77 -- same apply() arguments; the saved tensors and the 13 `None` gradients too."""
 

@@ -107,6 +107,34 @@ def test_gather_form_backward_equals_the_scatter_form(shape, osc, amp, rmc, dtyp
             assert torch.isfinite(a).all() and rel(a, b) < 2e-6, (variant, name)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,rmc,ld", [(12, 0, 216), (12, 0, 224), (6, 1, 104)])
+def test_backward_writes_grad_offset_as_gemm_operand(dtype, M, rmc, ld):
+    """mtp_dcnv3_bwd_act: grad_offset once more in the input dtype as rows of `ld` elements, pad columns zero -- equal to casting the f32
+    grad_offset (what the engine did in a separate pass before round 4); the three f32 gradients unchanged.  A geometry without a gather-form
+    backward (stride 2) answers None for the copy and still returns the gradients."""
+    from mtp_amd.ops_dcnv3.functions import dcnv3_backward, dcnv3_backward_act
+    torch.manual_seed(3)
+    N, H, W = 2, 19, 23
+    P = 9 - rmc
+    args = (3, 3, 1, 1, 1, 1, 1, 1, M, 16, 2.0)
+    x = torch.randn(N, H, W, M * 16, device="cuda").to(dtype)
+    off = ((torch.rand(N, H, W, M * P * 2, device="cuda") - 0.5) * 3).to(dtype)
+    m = torch.softmax(torch.randn(N, H, W, M, P, device="cuda"), -1).reshape(N, H, W, M * P).to(dtype)
+    G = torch.randn(N, H, W, M * 16, device="cuda").to(dtype)
+    ref = dcnv3_backward(x, off, m, *args, G, 256, rmc)
+    gi, go, gm, act = dcnv3_backward_act(x, off, m, *args, G, 256, ld, rmc)
+    assert rel(gi, ref[0]) < 2e-6 and torch.equal(go, ref[1]) and torch.equal(gm, ref[2])
+    assert act is not None and tuple(act.shape) == (N * H * W, ld) and act.dtype == dtype
+    n = M * P * 2
+    assert torch.equal(act[:, :n], ref[1].view(-1, n).to(dtype)) and float(act[:, n:].abs().max() if ld > n else 0.0) == 0.0
+    args2 = (3, 3, 2, 2, 1, 1, 1, 1, M, 16, 2.0)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    off2, m2, G2 = off[:, :Ho, :Wo].contiguous(), m[:, :Ho, :Wo].contiguous(), G[:, :Ho, :Wo].contiguous()
+    out = dcnv3_backward_act(x, off2, m2, *args2, G2, 256, ld, rmc)
+    assert out[3] is None and all(torch.isfinite(t).all() for t in out[:3])
+
+
 def test_bf16_matches_fp32_at_internimage_size():
     from mtp_amd.ops_dcnv3 import dcnv3_backward, dcnv3_forward
     torch.manual_seed(6)
