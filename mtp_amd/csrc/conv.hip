@@ -398,8 +398,8 @@ extern "C" int mtp_dwconv3x3_bwd_dx(const void* dy, int dtype, const float* w, f
 
 extern "C" int64_t mtp_dwconv3x3_bwd_dw_partial_rows(int64_t N, int64_t H, int64_t W) {
     const int64_t pixels = N * H * W;
-    const int64_t nb = (pixels + 255) / 256;
-    return nb < 256 ? nb : 256;
+    const int64_t nb = (pixels + 127) / 128;      // (round 4: up to 1024 workgroups; with 256 a level-0 launch had one 4-wave workgroup per CU and ran
+    return nb < 1024 ? nb : 1024;                 //  on the latency of its ten 8-byte loads per pixel)
 }
 
 /* part: (mtp_dwconv3x3_bwd_dw_partial_rows, 10 C) f32 = per-block partials of [dweight (C, 9) | dbias (C)] */

@@ -13,6 +13,7 @@ import torch
 # make_golden.f13 asserts that again.
 F13_INPUT_SEED = 2074
 F13_MIN_EDGE_DISTANCE = 1e-5
+F13_HARD_INPUT_SEED = 2023      # round 2's input: one sample 3.3e-6 px from an edge (fixture f13_vitl_hard.npz, looser gradient bound)
 
 
 def state_shapes(embed_dim=768, depth=12, heads=12, interval=3, img_size=224, mlp_ratio=4):
