@@ -692,17 +692,30 @@ __global__ __launch_bounds__(256, 2) void rvsa_scatter_gemm_kernel(const bf16_t*
             hit = (y > ylo && y < yhi) ? 1 : 0;
         }
         if (!__syncthreads_or(hit)) continue;       // (uniform) nothing in this chunk reaches the band
-        for (int idx = tid; idx < SCB * 8; idx += 256) {
-            const int sl = idx >> 3, ch = idx & 7, sg = c0 + sl;
-            uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
-            if (sg < S) {
-                const int w = sg / 49, k = sg - 49 * w;
+        // staging in two batches of unconditional loads on clamped rows (round 4): written as load -> store per iteration it was seven
+        // serialised global round trips per workgroup (a branch around a load makes hipcc wait for it inside the branch)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            constexpr int IT = 4;      // 2 x 4 x 256 >= SCB * 8 = 1792
+            uint4 kv[IT], vv[IT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const int idx = tid + 256 * (IT * half + i), sl = idx >> 3, ch = idx & 7, sg = c0 + sl;
+                const int sc = sg < S ? sg : S - 1;
+                const int w = sc / 49, k = sc - 49 * w;
                 const bf16_t* src = dsel + ((int64_t)(b * nW + w) * H + h) * (2 * 49 * HD) + k * HD + 8 * ch;
-                kv = ldg16(src);
-                vv = ldg16(src + 49 * HD);
+                kv[i] = ldg16(src);
+                vv[i] = ldg16(src + 49 * HD);
             }
-            *reinterpret_cast<uint4*>(Kimg + swz(sl, ch)) = kv;
-            *reinterpret_cast<uint4*>(Vimg + swz(sl, ch)) = vv;
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const int idx = tid + 256 * (IT * half + i), sl = idx >> 3, ch = idx & 7, sg = c0 + sl;
+                if (idx < SCB * 8) {
+                    const bool ok = sg < S;
+                    *reinterpret_cast<uint4*>(Kimg + swz(sl, ch)) = ok ? kv[i] : make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(Vimg + swz(sl, ch)) = ok ? vv[i] : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
         }
         __syncthreads();
         for (int kk = 0; kk < SCB / 32; ++kk) {

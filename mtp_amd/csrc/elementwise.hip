@@ -401,7 +401,7 @@ __device__ __forceinline__ void small_linear_dw_body(const float* __restrict__ d
         s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         sb[q] = 0.f;
     }
-#pragma unroll 2
+#pragma unroll 8      // (round 4: 8 rows in flight; with 2 the 32 rows of a wave were 16 serialised round trips -- the launch is latency, not bytes)
     for (int r = r0; r < r1; ++r) {
         const float4 xv = load4(x + (int64_t)r * K + kc);
         const float* dr = dy + (int64_t)r * N;
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void rvsa_sampling_fwd_kernel(const T* __restr
     const int j = win % nw, i = (win / nw) % nh, b = win / (nw * nh);
     for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
         float4 s = make_float4(0, 0, 0, 0);
-#pragma unroll 1
+#pragma unroll      // (round 4: all 49 row loads of the window in flight -- with `unroll 1` the seven rows were seven serialised round trips, most of the kernel's 17.6 us)
         for (int a = 0; a < 7; ++a) {
             const int y = i * 7 + a - pad_t;
             const bool yok = y >= 0 && y < Hp;
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void rvsa_sampling_bwd_win_kernel(const float*
     const int nq = (N + 3) / 4, n0 = q * nq, n1 = (n0 + nq) < N ? (n0 + nq) : N;
     float4 d = make_float4(0, 0, 0, 0);
     if (live) {
-#pragma unroll 4
+#pragma unroll 10
         for (int n = n0; n < n1; ++n) {
             const float4 ww = load4(w + (int64_t)n * C + 4 * c4);
             const float t = ds[n];

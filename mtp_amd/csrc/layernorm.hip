@@ -328,6 +328,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_res_bwd_kernel(const float* __r
 __device__ __forceinline__ float column_sum(const float* __restrict__ col, int64_t ld, int64_t r0, int64_t r1) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {     // (round 4: eight in flight -- the 16384-row partial buffers of the RVSA backward are ~113 rows per workgroup)
+        const float a = col[r * ld], b = col[(r + 1) * ld], c = col[(r + 2) * ld], d = col[(r + 3) * ld];
+        const float e = col[(r + 4) * ld], f = col[(r + 5) * ld], g = col[(r + 6) * ld], h = col[(r + 7) * ld];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+        s0 += e; s1 += f; s2 += g; s3 += h;
+    }
     for (; r + 4 <= r1; r += 4) {
         const float a = col[r * ld], b = col[(r + 1) * ld], c = col[(r + 2) * ld], d = col[(r + 3) * ld];
         s0 += a; s1 += b; s2 += c; s3 += d;

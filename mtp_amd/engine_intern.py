@@ -185,8 +185,8 @@ class InternEngine:
         # MLPLayer: fc1 -> GELU -> fc2 (dropout p = 0); fc1 stores gelu'(u) next to gelu(u) for the backward
         L1 = self._lin[pre + "mlp.fc1.weight"]
         u = self._e(rows, L1.R)
-        ug = self._e(rows, L1.R) if save else None
-        ops.gemm_nt(xab, L1.w, u, epi=(ops.EPI_BIAS_GELU_DG if save else ops.EPI_BIAS_GELU), bias=P[pre + "mlp.fc1.bias"], aux=ug)
+        ug = self._e(rows, L1.R)      # (also when nothing is saved: the GELU epilogues always write their side output -- the inference forward of bench.py's
+        ops.gemm_nt(xab, L1.w, u, epi=ops.EPI_BIAS_GELU_DG, bias=P[pre + "mlp.fc1.bias"], aux=ug)      #  `forward_only` found the aux = NULL call of rounds 2-3)
         v = self._linear(u, pre + "mlp.fc2.weight", P[pre + "mlp.fc2.bias"])
         s2 = scales[1] if scales is not None else None
         x32c, xac = self._e(rows, C, dtype=F32), self._e(rows, C)

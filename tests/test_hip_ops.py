@@ -1,9 +1,11 @@
 """GPU: every C-ABI op vs the oracle on seeded inputs.  f32 mode must meet north_star's 1e-3 (we assert 2e-4 relative to
 the tensor's max); bf16 mode is checked against the oracle evaluated on the same bf16-rounded inputs."""
+import os
+
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import ROOT, rel_err
 from oracle import vit_rvsa_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -712,6 +714,41 @@ def test_rvsa_attention_fwd_bwd(ops, dtype, Hp, Wp, sscale):
     assert rel_err(drh.cpu(), gh) < 10 * TOL[dtype] and rel_err(drw.cpu(), gw) < 10 * TOL[dtype] and rel_err(dtab.cpu(), gt) < 10 * TOL[dtype]
     if sscale > 0:   # at sscale == 0 every sample sits on a bilinear kink: d/d(coord) is one-sided (see test_oracle_golden)
         assert rel_err(dsamp.cpu(), gs) < 10 * TOL[dtype]
+
+
+def test_rvsa_backward_atomic_scatter_form_in_a_subprocess(ops, tmp_path):
+    """the backward's in-kernel f32-atomic scatter (grids beyond what the dense-product kernel takes; MTP_RVSA_SCATTER=dense forces it -- read once
+    per process, hence the subprocess) against the default dense-product form on the same inputs: same bf16 W / dK_sel operands, f32 accumulation in
+    a different order"""
+    import subprocess
+    import sys
+    code = """
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from mtp_amd import ops
+B, heads, hd, Hp, Wp = 2, 2, 64, 14, 14
+C, T = heads * hd, B * Hp * Wp
+g = torch.Generator().manual_seed(5)
+qkv = (0.5 * torch.randn(T, 3 * C, generator=g)).cuda().bfloat16()
+samp = (0.3 * torch.randn(B * 4, 5 * heads, generator=g)).cuda()
+rh, rw, tab = (0.3 * torch.randn(13, hd, generator=g)).cuda(), (0.3 * torch.randn(13, hd, generator=g)).cuda(), (0.3 * torch.randn(169, heads, generator=g)).cuda()
+do = torch.randn(T, C, generator=g).cuda().bfloat16()
+o, lse = torch.empty(T, C, device="cuda", dtype=torch.bfloat16), torch.empty(B * 4 * heads * 49, device="cuda")
+ops.rvsa_attn_fwd(qkv, samp, o, lse, rh, rw, tab, B, Hp, Wp, heads, hd ** -0.5)
+dqkv, dsamp = torch.empty(T, 3 * C, device="cuda", dtype=torch.bfloat16), torch.empty(B * 4, 5 * heads, device="cuda")
+d1, d2, d3 = torch.zeros(13, hd, device="cuda"), torch.zeros(13, hd, device="cuda"), torch.zeros(169, heads, device="cuda")
+ops.rvsa_attn_bwd(qkv, samp, o, do, lse, dqkv, dsamp, rh, rw, tab, d1, d2, d3, B, Hp, Wp, heads, hd ** -0.5)
+torch.cuda.synchronize()
+torch.save({"dqkv": dqkv.float().cpu(), "dsamp": dsamp.cpu()}, sys.argv[1])
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    outs = {}
+    for mode in ("gemm", "dense"):
+        f = str(tmp_path / (mode + ".pt"))
+        env = dict(os.environ, MTP_RVSA_SCATTER=mode)
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(f)
+    assert rel_err(outs["dense"]["dqkv"], outs["gemm"]["dqkv"]) < 1e-2 and rel_err(outs["dense"]["dsamp"], outs["gemm"]["dsamp"]) < 1e-3
 
 
 # ---- the attention kernels at the launch geometry of the headline benchmark: 64 images x 16 heads x 64 dims (ViT-L, B = 64)
