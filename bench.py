@@ -153,6 +153,7 @@ def self_launch(args, argv):
             return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")              # compute, weight-gradient, exchange and RCCL streams on separate hardware queues (mtp_amd/__init__.py)
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
@@ -342,11 +343,15 @@ def main():
                     help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (mtp_amd.parallel.GradReducer)")
     ap.add_argument("--comm-bf16", action="store_true", default=os.environ.get("MTP_COMM_BF16") == "1",
                     help="exchange the gradient buckets as bf16 (cast on the side stream, f32 again before the optimizer): half the xGMI bytes")
+    ap.add_argument("--wgrad-side-stream", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="A/B: grouped weight-gradient launches on a side stream (1) or the main stream (0); -1 = the engines' own defaults")
+    ap.add_argument("--wgrad-keep", type=int, default=-1, help="A/B: weight-gradient bursts that may stay in flight on the side stream (InternImage)")
     ap.add_argument("--cpu-standin", action="store_true",
                     help="TEST ONLY: gloo ranks on CPU exercising the launcher / rendezvous / comm-report plumbing without kernels (prints `standin: true`)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver (read when HIP initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")              # see mtp_amd/__init__.py
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -364,6 +369,14 @@ def main():
             print(_error_line(args, "rank %d has no GPU (%d visible)" % (local, torch.cuda.device_count() if torch.cuda.is_available() else 0)), flush=True)
         raise SystemExit(2)
     torch.cuda.set_device(local)
+    if args.wgrad_side_stream >= 0:
+        from mtp_amd.engine import BackboneEngine
+        from mtp_amd.engine_intern import InternEngine
+        BackboneEngine.wgrad_side_stream = InternEngine.wgrad_side_stream = args.wgrad_side_stream
+    if args.wgrad_keep >= 0:
+        from mtp_amd.engine import BackboneEngine
+        from mtp_amd.engine_intern import InternEngine
+        BackboneEngine.wgrad_keep = InternEngine.wgrad_keep = args.wgrad_keep
     import torch.distributed as dist
     force_comm = os.environ.get("MTP_FORCE_COMM") == "1"     # debugging aid: run the RCCL path on a single GPU
     if world > 1 or force_comm:

@@ -351,6 +351,12 @@ int mtp_dcnv3_bwd_act(const void* input, const void* offset, const void* mask, c
 
 const char* mtp_version(void);
 
+/* A non-blocking stream of the lowest priority the device offers, for launches that are off the critical path and should only take the CUs the
+ * main stream leaves idle (the reference has no counterpart: its weight gradients are ATen calls on the one autograd stream).  The caller owns the
+ * handle and frees it with mtp_stream_destroy. */
+int mtp_stream_create_low_priority(mtp_stream_t* stream);
+int mtp_stream_destroy(mtp_stream_t stream);
+
 /* ---- gradient all-reduce over RCCL (reference: DistributedDataParallel, main_pretrain.py:508-518) ------ */
 /* One communicator per process / GPU.  Rank 0 draws a 128-byte id (mtp_comm_unique_id) and hands it to every rank out of band;
  * mtp_comm_init is collective.  mtp_comm_allreduce_bucket: in-place SUM of `count` f32 values on `stream` (asynchronous; the

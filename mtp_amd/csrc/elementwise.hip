@@ -1116,3 +1116,22 @@ extern "C" int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, c
 // 0.4: round 4 -- mtp_gemm_args as of round 3 (workspace / workspace_bytes trailing fields; now ignored: the stream-K form is gone),
 // mtp_gemm_tn_grouped honours split_k / aux.  Bump whenever a struct in include/mtp_hip.h changes size or a field changes meaning.
 extern "C" const char* mtp_version(void) { return "mtp_hip 0.4 (gfx950)"; }
+
+// A stream of the LOWEST priority the device offers (non-blocking), for work that is off the critical path and should only take the CUs
+// the main stream leaves idle: the grouped weight-gradient launches next to under-filled data-gradient GEMMs (engine_intern.py).
+// The caller owns the handle (mtp_stream_destroy); it can be wrapped as a torch.cuda.ExternalStream.
+extern "C" int mtp_stream_create_low_priority(void** stream) {
+    if (!stream) return MTP_ERR_ARG;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return (int)e;
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
+    if (e != hipSuccess) return (int)e;
+    *stream = (void*)s;
+    return 0;
+}
+extern "C" int mtp_stream_destroy(void* stream) {
+    if (!stream) return MTP_ERR_ARG;
+    return (int)hipStreamDestroy((hipStream_t)stream);
+}

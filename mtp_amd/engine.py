@@ -114,11 +114,18 @@ class BackboneEngine:
         self._wimg = ops.WeightImages(entries, act)
 
     # ------------------------------------------------------------------ helpers
-    wgrad_side_stream = False     # True: grouped weight-gradient launches go to a side stream (ops.WgradQueue); measured +0.3 ms, off
+    # grouped weight-gradient launches on a side stream (ops.WgradQueue): the data-gradient GEMMs run 0.875 of whole
+    # rounds and one workgroup per CU -- the weight-gradient tiles take the CUs a round leaves idle.  Round 4, same box, three runs each: 35.76 -> 35.38 ms / step;
+    # rounds 2-3 measured a loss because the HIP runtime had put the side stream on the compute stream's hardware queue (mtp_amd/__init__.py).
+    # False: everything on the current stream; 2: a stream of the device's lowest priority.
+    wgrad_side_stream = True
+    wgrad_keep = 1                # bursts that may stay in flight on the side stream when the next one is launched
 
     def _wgrad_stream(self):
         if not self.wgrad_side_stream:
             return None
+        if int(self.wgrad_side_stream) == 2:      # a stream of the device's lowest priority
+            return ops.low_priority_stream(self.dev)
         st = getattr(self, "_wstream", None)
         if st is None or st.device != self.dev:
             st = self._wstream = torch.cuda.Stream(device=self.dev)
@@ -183,13 +190,16 @@ class BackboneEngine:
         s = {}
         mean1, rstd1 = self._e(T, dtype=F32), self._e(T, dtype=F32)
         ln1 = ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], self._e(T, C), mean1, rstd1)
-        qkv = ops.gemm_nt(ln1, b.wqkv, self._e(T, 3 * C), bias=P[pre + "attn.qkv.bias"])
-        o = self._e(T, C)
         if b.window:
+            # (the sampling heads on a second stream next to the qkv GEMM, joined by events: +0.25 ms per forward pass, round 4 -- the two cross-queue
+            #  waits per block cost more than the 22 us they hide)
             nh, nw = ops.rvsa_windows(Hp, Wp)
             R = B * nh * nw
             avg, pooled = self._e(R, C, dtype=F32), self._e(R, C, dtype=F32)
             samp = ops.rvsa_sampling_fwd(ln1, b.wsamp, b.bsamp, avg, pooled, self._e(R, 5 * self.heads, dtype=F32), B, Hp, Wp)
+        qkv = ops.gemm_nt(ln1, b.wqkv, self._e(T, 3 * C), bias=P[pre + "attn.qkv.bias"])
+        o = self._e(T, C)
+        if b.window:
             lse = self._e(R * self.heads * 49, dtype=F32)
             ops.rvsa_attn_fwd(qkv, samp, o, lse, P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"],
                               P[pre + "attn.relative_position_bias_table"], B, Hp, Wp, self.heads, self.scale)
@@ -257,12 +267,12 @@ class BackboneEngine:
             ops.full_attn_bwd(s["qkv"], s["o"], do, s["lse"], dqkv, rel_h, rel_w, drel_h, drel_w, B, Hp, Wp, self.heads, self.scale,
                               accumulate=True, defer=self._ln_parts)
         wq.add(dqkv, s["ln1"], G[pre + "attn.qkv.weight"], G[pre + "attn.qkv.bias"])
-        dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         win_add = None
         if b.window:
             # dln1 += pool'(linear'(dsamp)): the per-window factor (windows, C) is one small launch; norm1's backward adds it to every token
-            # row of the window while it reads the row anyway (round 4: was a read-modify-write pass over (T, C), 17 us per block)
+            # row of the window while it reads the row anyway (round 4: was a read-modify-write pass over (T, C), 17 us per block).
             win_add = ops.rvsa_sampling_bwd_win(dsamp, b.wsamp, s["avg"], self._e(*s["avg"].shape, dtype=F32))
+        dln1 = ops.gemm_nt(dqkv, b.wqkvT, self._e(T, C))
         dx0, dx0_act = self._e(T, C, dtype=F32), self._e(T, C)
         self._ln_bwd(dln1, s["x"], s["mean1"], s["rstd1"], P[pre + "norm1.weight"], dx0, G[pre + "norm1.weight"], G[pre + "norm1.bias"],
                           dres=dx1, extra=extra, dx_copy=dx0_act, copy_scale=prev_scale, rows_per_sample=N,
@@ -463,7 +473,7 @@ class BackboneEngine:
         # ACT copy of the output gradient of the last block, scaled by its mlp drop-path factor
         dx_act = self._scaled_copy(dx, dps[last][1], N)
         waiting = []     # blocks whose weight gradients are still queued: on_block_done fires once they have been launched
-        pending = None   # side-stream mode: the burst launched last (reported once the NEXT burst has been launched, after a wait)
+        pending = []     # side-stream mode: (lowest block, launch mark) of the bursts in flight, reported once the current stream has waited for them
         for i in range(last, -1, -1):
             s = saved[i]
             if ctx["ckpt"]:
@@ -479,19 +489,21 @@ class BackboneEngine:
             # cuts its buckets by size, and a single report at the end would leave no backward to overlap the exchange with
             if i == 0 or wq.should_flush() or not wq.jobs or (split_last and i == 1):
                 wq.flush()
-                self._ln_flush()
+                self._ln_flush()      # (on the current stream: behind the burst on the side stream they cost the whole gain, 35.4 -> 35.7 ms)
                 if wq.stream is None:
                     if on_block_done is not None:
                         on_block_done(waiting[-1])     # the lowest block of the burst: its group end covers the whole burst
                 else:
-                    wq.wait(keep=1)
-                    if pending is not None and on_block_done is not None:
-                        on_block_done(pending)
-                    pending = waiting[-1]
+                    pending.append((waiting[-1], wq.launched))
+                    wq.wait(keep=self.wgrad_keep)
+                    while pending and pending[0][1] <= wq.launched - len(wq.inflight):      # bursts the current stream has waited for
+                        g = pending.pop(0)[0]
+                        if on_block_done is not None:
+                            on_block_done(g)
                 waiting = []
         wq.wait()
-        if pending is not None and on_block_done is not None:
-            on_block_done(pending)
+        if pending and on_block_done is not None:
+            on_block_done(pending[-1][0])     # the lowest block still unreported covers the rest
         # ---- pos embed (the patch-embed weight gradient went out with block 0's)
         if "pos_embed" in G:
             ops.reduce_rows(dx.view(B, N * C), G["pos_embed"])

@@ -36,6 +36,22 @@ class InternEngine:
         self._wimg = None
         self._padded = []
 
+    # True: the grouped weight-gradient launches go to a side stream (ops.WgradQueue).  The Linear layers of the 768- / 1536-channel levels are 48-111
+    # tiles on 256 CUs: next to them the weight-gradient tiles (one per CU, off the critical path) run on the idle CUs.
+    # False: on the current stream; True: a side stream; 2: a side stream of the device's lowest priority (same box: 58.87 / 58.35 / 57.8 ms per step)
+    wgrad_side_stream = 2
+    wgrad_keep = 3                # bursts that may stay in flight on the side stream when the next one is launched
+
+    def _wgrad_stream(self):
+        if not self.wgrad_side_stream:
+            return None
+        if int(self.wgrad_side_stream) == 2:
+            return ops.low_priority_stream(self.dev)
+        st = getattr(self, "_wstream", None)
+        if st is None or st.device != self.dev:
+            st = self._wstream = torch.cuda.Stream(device=self.dev)
+        return st
+
     # ------------------------------------------------------------------ parameters -> GEMM-side images
     def params(self):
         return dict(self.m.named_parameters())
@@ -53,7 +69,9 @@ class InternEngine:
             self._wimg.refresh()
         for L in self._padded:
             ops.pack_rows_padded(P[L.name].detach(), L.w, L.wt)
-            L.bias[:L.R].copy_(P[L.name[:-len("weight")] + "bias"].detach())      # (device-to-device copy of R floats)
+        for k in range(0, len(self._padded), 12):      # the padded layers' biases: R floats each, 12 per launch
+            Ls = self._padded[k:k + 12]
+            ops.copy_segments([P[L.name[:-len("weight")] + "bias"].detach() for L in Ls], [L.bias[:L.R] for L in Ls])
         for name, (w2, w2t) in self._conv.items():
             ops.conv3x3_pack(P[name].detach().contiguous(), w2, w2t)
         self._key = key
@@ -303,7 +321,8 @@ class InternEngine:
         P = self.P
         img, cols1, y1, sm1, sr1, a1, cols2, y2, sm2, sr2, (N, Cin, H, W, H1, W1, H2, W2) = ctx["stem"]
         self.dev = cols1.device
-        self._wq = ops.WgradQueue()
+        self._wq = wq = ops.WgradQueue(stream=self._wgrad_stream())
+        pending = []        # side-stream mode: the layers whose bursts are in flight (reported once the current stream has waited for them)
         self._ln_parts = []
         taps = {}
         for idx, d in zip([i for i in range(len(m.depths)) if i in m.out_indices], dfeats):
@@ -336,11 +355,19 @@ class InternEngine:
                 # the weight gradients are queued and launched a few layers at a time (ops.WgradQueue: edge tiles for the 192- / 384-channel
                 # levels and the offset / mask heads, the contraction of the 131072- / 32768-token levels cut into pieces inside the launch);
                 # the layer is reported once they are out
-                if j == 0 or self._wq.should_flush() or not self._wq.jobs:
-                    self._wq.flush()
+                if j == 0 or wq.should_flush() or not wq.jobs:
+                    wq.flush()
                     self._ln_flush()
-                    if on_block_done is not None:
-                        on_block_done(sum(m.depths[:i]) + j)
+                    if wq.stream is None:
+                        if on_block_done is not None:
+                            on_block_done(sum(m.depths[:i]) + j)
+                    else:
+                        pending.append((sum(m.depths[:i]) + j, wq.launched))
+                        wq.wait(keep=self.wgrad_keep)
+                        while pending and pending[0][1] <= wq.launched - len(wq.inflight):      # bursts the current stream has waited for
+                            g = pending.pop(0)[0]
+                            if on_block_done is not None:
+                                on_block_done(g)
         if dx32 is None:
             return None
         # ---- stem backward
@@ -351,8 +378,9 @@ class InternEngine:
         dy1 = self._ln_bwd(self._to_act(da1), y1, sm1, sr1, P, G, "patch_embed.norm1.1", gelu=True)
         dimg = self._e(N, Cin, H, W, dtype=F32) if need_input_grad else None
         self._conv_bwd(dy1, cols1, "patch_embed.conv1.weight", G, "patch_embed.conv1.bias", dimg, (Cin * H * W, W, 1, H * W), N, H, W, Cin, 2)
-        self._wq.flush()      # the stem's two weight gradients
+        wq.flush()      # the stem's two weight gradients
         self._ln_flush()
+        wq.wait()
         if on_block_done is not None:
             on_block_done(-1)
         return dimg

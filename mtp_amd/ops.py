@@ -154,6 +154,22 @@ def grouped_splits(K, tiles):
     return max(1, min(64, K // 4096, 256 // tiles))
 
 
+_low_streams = {}
+
+
+def low_priority_stream(device):
+    """a side stream of the device's lowest priority (mtp_stream_create_low_priority), wrapped for torch; one per device, kept for the process"""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _low_streams.get(idx)
+    if st is None:
+        h = C.c_void_p()
+        with torch.cuda.device(idx):
+            check(lib().mtp_stream_create_low_priority(C.byref(h)), "mtp_stream_create_low_priority")
+        st = _low_streams[idx] = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
+    return st
+
+
 class WgradQueue:
     """Deferred weight gradients dW = dY^T X (+ bias gradient = column sums of dY): the weight gradients of a transformer block
     depend only on tensors the backward pass has anyway, so they are collected and launched together -- ONE
@@ -169,6 +185,7 @@ class WgradQueue:
         # round) their tiles fill the idle CUs.  flush() orders the launch after everything issued so far; wait() orders the
         # current stream after the launches (call it before the gradients are consumed).
         self.stream, self.inflight = stream, []
+        self.launched = 0    # side-stream launches so far; launched - len(inflight) of them have been waited for by the current stream
         self.after = []      # callables run right after the launch (on its stream): e.g. copying a padded result into the gradient buffer
 
     def add(self, dy, x, dw, colsum=None, after=None):
@@ -214,6 +231,7 @@ class WgradQueue:
             done = torch.cuda.Event()
             done.record()
         self.inflight.append((done, held))
+        self.launched += 1
 
     def wait(self, keep=0):
         """the current stream waits for the side-stream launches, except the `keep` most recent ones"""

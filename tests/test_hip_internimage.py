@@ -315,6 +315,30 @@ def test_internimage_xl_one_step_shapes():
     assert float(dict(net.named_parameters())["levels.0.blocks.0.dcn.input_proj.weight"].grad.abs().max()) > 0
 
 
+def test_internimage_weight_gradients_on_a_side_stream_give_the_same_gradients(monkeypatch):
+    """InternEngine.wgrad_side_stream: the grouped weight-gradient launches (edge tiles, pieces, padded heads with their copy-back) go to a side stream
+    next to the under-filled Linear layers of the deep levels; ordered by events, operands referenced until the main stream has waited.  Same gradients
+    as the single-stream schedule (the bias-gradient by-product's f32 atomics reorder sums: 1e-5)."""
+    from mtp_amd.engine_intern import InternEngine
+    net = mtp_amd.internimage_xl(drop_path_rate=0.0).cuda().train()
+    img = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def grads():
+        for q in net.parameters():
+            q.grad = None
+        sum(f.float().mean() for f in net(img)).backward()
+        torch.cuda.synchronize()
+        return {n: q.grad.clone() for n, q in net.named_parameters() if q.grad is not None}
+    monkeypatch.setattr(InternEngine, "wgrad_side_stream", False)
+    a = grads()
+    monkeypatch.setattr(InternEngine, "wgrad_side_stream", True)
+    b = grads()
+    c = grads()      # a second pass: the side stream and its event bookkeeping are reused
+    assert a.keys() == b.keys() == c.keys() and len(a) > 300
+    for n in a:
+        assert rel_err(b[n], a[n]) < 1e-5 and rel_err(c[n], a[n]) < 1e-5, n
+
+
 @pytest.mark.parametrize("recipe", ["kink_free", "data_dependent"])
 def test_internimage_xl_at_512_batch_1_vs_oracle(recipe):
     """BASELINE configs[4] at size: InternImage-XL (models.py:92-104: 192..1536 channels, depths 5 5 24 5, 12..96 groups) on ONE 512 x 512

@@ -25,7 +25,8 @@ def main():
         ref = torch.empty(M, N, device="cuda", dtype=bf)
         ops.gemm_nt(a, w, ref, bias=bias, variant=1024)
         ts, ok = {}, {}
-        for v in (0, 1024, 256, 512, 768):
+        C2 = 1 << 22      # the co-resident 4-wave form (tools/ablation/gemm_c2.hip): only in an ablation build (MTP_HIP_LIB=tools/_abl/libmtp_hip_c2.so)
+        for v in (0, 1024, 256, 512, 768) + ((C2,) if os.environ.get("MTP_AB_C2") else ()):
             try:
                 ops.gemm_nt(a, w, outs[0], bias=bias, variant=v)
             except Exception as e:
@@ -43,7 +44,7 @@ def main():
             for v in ts:
                 ts[v].append(time_many(lambda: (ops.gemm_nt(a, w, outs[0], bias=bias, variant=v)), 20))
         fl = 2.0 * M * N * K
-        names = {0: "default", 1024: "128-wide", 256: "p8-auto", 512: "p8-224", 768: "p8-256"}
+        names = {0: "default", 1024: "128-wide", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 1 << 22: "c2-256x128"}
         print("M=%d N=%d K=%d tiles256=%d | " % (M, N, K, -(-M // 256) * -(-N // 256)) +
               " | ".join("%s %.1fus %.0fTF%s" % (names[v], min(ts[v]) * 1e6, fl / statistics.median(ts[v]) / 1e12, ok[v]) for v in ts), flush=True)
 
