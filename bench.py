@@ -33,7 +33,9 @@ class GemmTimer:
     """HIP-event timing of every GEMM launch inside the timed region (events on the launch stream = torch's current stream)."""
 
     def __init__(self, ops):
-        self.ops, self.rec, self.on = ops, [], False
+        self.ops, self.on = ops, False
+        self.recs = ([], [])      # [0]: instrumented steps run on ONE stream (a launch's duration is the kernel's own); [1]: as the step runs (side stream)
+        self.rec = self.recs[0]
         self._nt, self._tn = ops.gemm_nt, ops.gemm_tn
 
     def install(self):
@@ -73,9 +75,12 @@ class GemmTimer:
             return r
         self.ops.WgradQueue._launch = flush     # (_launch runs under the queue's launch stream: the events land there)
 
-    def summary(self):
+    def use(self, k):
+        self.rec = self.recs[k]
+
+    def summary(self, k=0):
         fam = {}
-        for name, fl, s, e, _ in self.rec:
+        for name, fl, s, e, _ in self.recs[k]:
             d = fam.setdefault(name, [0.0, 0.0, 0])
             d[0] += fl
             d[1] += s.elapsed_time(e) * 1e-3
@@ -86,7 +91,7 @@ class GemmTimer:
     def shapes(self):
         """per-(family, shape) table of the instrumented launches (--gemm-shapes): where a model's GEMM time goes"""
         t = {}
-        for name, fl, s, e, shape in self.rec:
+        for name, fl, s, e, shape in self.recs[0]:
             d = t.setdefault((name,) + tuple(shape), [0.0, 0.0, 0])
             d[0] += fl
             d[1] += s.elapsed_time(e) * 1e-3
@@ -346,6 +351,7 @@ def main():
     ap.add_argument("--wgrad-side-stream", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="A/B: grouped weight-gradient launches on a side stream (1) or the main stream (0); -1 = the engines' own defaults")
     ap.add_argument("--wgrad-keep", type=int, default=-1, help="A/B: weight-gradient bursts that may stay in flight on the side stream (InternImage)")
+    ap.add_argument("--wgrad-max-jobs", type=int, default=-1)
     ap.add_argument("--cpu-standin", action="store_true",
                     help="TEST ONLY: gloo ranks on CPU exercising the launcher / rendezvous / comm-report plumbing without kernels (prints `standin: true`)")
     args = ap.parse_args()
@@ -377,6 +383,10 @@ def main():
         from mtp_amd.engine import BackboneEngine
         from mtp_amd.engine_intern import InternEngine
         BackboneEngine.wgrad_keep = InternEngine.wgrad_keep = args.wgrad_keep
+    if args.wgrad_max_jobs >= 0:
+        from mtp_amd.engine import BackboneEngine
+        from mtp_amd.engine_intern import InternEngine
+        BackboneEngine.wgrad_max_jobs = InternEngine.wgrad_max_jobs = args.wgrad_max_jobs
     import torch.distributed as dist
     force_comm = os.environ.get("MTP_FORCE_COMM") == "1"     # debugging aid: run the RCCL path on a single GPU
     if world > 1 or force_comm:
@@ -478,10 +488,25 @@ def main():
         sampler.start()
     t0 = time.perf_counter()
     timed_steps = 0
+    # Instrumented steps alternate: the first (third, ...) runs every launch on the one compute stream, so that the events around a GEMM launch time
+    # that kernel alone -- `roofline`; the second (fourth, ...) runs as every other step does, the weight-gradient bursts on their side stream, where a
+    # data-gradient GEMM shares the CUs with weight-gradient tiles and its events measure the pair -- `roofline.concurrent`.
+    eng_cls = type(trainer.engine)
+    side_default = getattr(eng_cls, "wgrad_side_stream", False)
+    conc_steps = 0
     for i in range(args.steps):
         timer.on = (not args.no_gemm_timer) and i % max(1, args.timer_every) == 0
-        timed_steps += int(timer.on)
+        if timer.on:
+            k = (timed_steps + conc_steps) % 2 if side_default else 0
+            timer.use(k)
+            if k == 0:
+                eng_cls.wgrad_side_stream = False
+                timed_steps += 1
+            else:
+                conc_steps += 1
         loss = trainer.step(img, loss_and_grads)
+        if timer.on:
+            eng_cls.wgrad_side_stream = side_default
     sync()
     dt = time.perf_counter() - t0
     clocks = sampler.stop() if sampler is not None else None
@@ -592,6 +617,14 @@ def main():
                         instrumented_steps=timed_steps,
                         families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / max(1, timed_steps) * 1e3, 2))
                                   for k, v in fams.items()})
+            if conc_steps:
+                fc = timer.summary(1)
+                roof["concurrent"] = dict(
+                    note="the same events in a step run as the timed steps are: weight-gradient bursts on the side stream, so a launch shares the CUs with "
+                         "the other family's tiles and its duration is no longer the kernel's own (`roofline` proper comes from instrumented steps run on one stream)",
+                    instrumented_steps=conc_steps,
+                    families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / conc_steps * 1e3, 2),
+                                      avg_launch_us=round(v["seconds"] / v["launches"] * 1e6, 1)) for k, v in fc.items()})
         gf = FWD_GF_PER_IMAGE.get(args.model, 0.0) * 3.0
         label = {"vit_l": "ViT-L + RVSA", "vit_b": "ViT-B + RVSA", "internimage_xl": "InternImage-XL (DCNv3)"}[args.model]
         out = {

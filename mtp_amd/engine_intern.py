@@ -40,6 +40,7 @@ class InternEngine:
     # tiles on 256 CUs: next to them the weight-gradient tiles (one per CU, off the critical path) run on the idle CUs.
     # False: on the current stream; True: a side stream; 2: a side stream of the device's lowest priority (same box: 58.87 / 58.35 / 57.8 ms per step)
     wgrad_side_stream = 2
+    wgrad_max_jobs = 0
     wgrad_keep = 3                # bursts that may stay in flight on the side stream when the next one is launched
 
     def _wgrad_stream(self):
@@ -322,6 +323,7 @@ class InternEngine:
         img, cols1, y1, sm1, sr1, a1, cols2, y2, sm2, sr2, (N, Cin, H, W, H1, W1, H2, W2) = ctx["stem"]
         self.dev = cols1.device
         self._wq = wq = ops.WgradQueue(stream=self._wgrad_stream())
+        wq.max_jobs = self.wgrad_max_jobs if wq.stream is not None else 0
         pending = []        # side-stream mode: the layers whose bursts are in flight (reported once the current stream has waited for them)
         self._ln_parts = []
         taps = {}

@@ -185,6 +185,7 @@ class WgradQueue:
         # round) their tiles fill the idle CUs.  flush() orders the launch after everything issued so far; wait() orders the
         # current stream after the launches (call it before the gradients are consumed).
         self.stream, self.inflight = stream, []
+        self.max_jobs = 0    # > 0: a burst goes out as soon as it holds this many problems (A/B of the burst size next to the side stream)
         self.launched = 0    # side-stream launches so far; launched - len(inflight) of them have been waited for by the current stream
         self.after = []      # callables run right after the launch (on its stream): e.g. copying a padded result into the gradient buffer
 
@@ -214,7 +215,7 @@ class WgradQueue:
         """whole rounds of the CUs, or no room for another block's problems"""
         if not self.jobs:
             return False
-        if len(self.jobs) + next_jobs > MAX_GROUPED:
+        if len(self.jobs) + next_jobs > MAX_GROUPED or (self.max_jobs and len(self.jobs) >= self.max_jobs):
             return True
         rounds = -(-self.tiles // self.cus)
         return self.tiles / (rounds * self.cus) >= 0.93

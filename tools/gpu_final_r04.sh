@@ -9,6 +9,8 @@ timeout 1800 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -6 > $O/
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gemm-timer --no-forward-only > $O/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_single -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gemm-timer --no-forward-only --wgrad-side-stream 0 > $O/trace_single.log 2>&1
+rm -f $O/trace_single/t_kernel_trace.csv
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timer --no-forward-only > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-timer --no-forward-only > $O/pmc_write.log 2>&1
 cd $R
@@ -46,11 +48,12 @@ timeout 300 python bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-forwar
 for i in 1 2 3; do
   (cd $R/_base && timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/ab_base_$i.json 2>> $O/ab.err)
   timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-forward-only > $O/ab_new_$i.json 2>> $O/ab.err
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-forward-only --wgrad-side-stream 0 > $O/ab_single_$i.json 2>> $O/ab.err
 done
 python - <<PY > $O/ab_step_vs_round3.txt
 import json, glob
-print("# same box, interleaved, 20 steps each: the round-3 tree (git b249d9b, its own libmtp_hip.so) vs this tree; ms per step")
-for tag in ("ab_base", "ab_new"):
+print("# same box, 20 steps each: the round-3 tree (git b249d9b, its own libmtp_hip.so) interleaved with this tree; ab_single = this tree with the weight-gradient bursts on the compute stream; ms per step")
+for tag in ("ab_base", "ab_new", "ab_single"):
     v = [json.load(open(f))["ms_per_step"] for f in sorted(glob.glob("$O/%s_*.json" % tag))]
     print(tag, v, "min %.3f" % min(v))
 PY
