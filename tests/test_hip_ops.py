@@ -824,3 +824,27 @@ def test_adamw_flat_and_sqnorm(ops):
         hyper = torch.tensor([lr, b1, b2, eps, 1 - b1 ** step, 1 - b2 ** step], device="cuda")
         ops.adamw_flat(dp, dg, dm, dv, dev(seg), dev(wd), hyper, sq, max_norm=5.0)
     assert rel_err(dp.cpu(), torch.cat([r.detach() for r in ref_p])) < 1e-5
+
+
+def test_low_priority_stream_entry_points(ops):
+    """mtp_stream_create_low_priority / mtp_stream_destroy (round 4): the handle is a real HIP stream -- kernels launched on it through the C ABI run and
+    are ordered by events against the compute stream -- and ops.low_priority_stream wraps one per device for torch (the weight-gradient side stream)."""
+    import ctypes as C
+    from mtp_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.mtp_stream_create_low_priority(C.byref(h)) == 0 and h.value
+    st = torch.cuda.ExternalStream(h.value)
+    x = torch.randn(4096, 256, device="cuda")
+    out = torch.zeros(256, device="cuda")
+    ready = torch.cuda.Event()
+    ready.record()
+    with torch.cuda.stream(st):
+        st.wait_event(ready)
+        ops.reduce_rows(x, out)
+    st.synchronize()
+    assert rel_err(out, x.sum(0)) < 1e-5
+    assert lib.mtp_stream_destroy(h) == 0
+    assert lib.mtp_stream_create_low_priority(None) != 0 and lib.mtp_stream_destroy(None) != 0
+    a, b = ops.low_priority_stream("cuda"), ops.low_priority_stream(torch.device("cuda", torch.cuda.current_device()))
+    assert a is b and a.cuda_stream != torch.cuda.current_stream().cuda_stream
