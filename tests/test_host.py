@@ -8,7 +8,7 @@ import torch
 
 import mtp_amd
 import recipe
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from mtp_amd.backbone import vit_win_rvsa_v3_wsz7 as V
 from mtp_amd.registry import BACKBONES, MODELS, _LocalRegistry
 
@@ -224,3 +224,16 @@ def test_unsupported_configs_fail_loudly():
         mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=96, num_heads=2)      # head_dim != 64
     with pytest.raises(NotImplementedError):
         mtp_amd.ViT_Win_RVSA_V3_WSZ7(init_values=0.1)
+
+
+def test_import_sets_the_hardware_queue_count_unless_the_user_did():
+    """mtp_amd/__init__.py: GPU_MAX_HW_QUEUES=8 by default (compute, weight-gradient, exchange and RCCL streams on separate hardware queues,
+    profiles/r04_ab_side_streams.txt (2)); a value from the environment wins.  Checked in fresh interpreters: the variable is read when HIP initialises."""
+    import subprocess
+    import sys
+    code = "import os, mtp_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "8", out.stderr[-500:]
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "4", out.stderr[-500:]
