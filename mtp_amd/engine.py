@@ -116,7 +116,8 @@ class BackboneEngine:
     # ------------------------------------------------------------------ helpers
     # grouped weight-gradient launches on a side stream (ops.WgradQueue): the data-gradient GEMMs run 0.875 of whole
     # rounds and one workgroup per CU -- the weight-gradient tiles take the CUs a round leaves idle.  Round 4, same box, three runs each: 35.76 -> 35.38 ms / step;
-    # rounds 2-3 measured a loss because the HIP runtime had put the side stream on the compute stream's hardware queue (mtp_amd/__init__.py).
+    # rounds 2-3 had measured it as a loss (bursts of four blocks, the reductions not yet batched); next to the gradient exchange it needs
+    # GPU_MAX_HW_QUEUES = 8 (mtp_amd/__init__.py: with 4 hardware queues the side stream shares the compute stream's).  DESIGN section 5.
     # False: everything on the current stream; 2: a stream of the device's lowest priority.
     wgrad_side_stream = True
     wgrad_max_jobs = 8            # side-stream mode: a burst goes out every two blocks (4 blocks = whole rounds matter only when nothing runs next to it):
