@@ -72,8 +72,9 @@ typedef struct {
                          * pipelined NT kernel (1 = tile height picked per problem, 2 = 224 x 256 tiles, 3 = 256 x 256 tiles), bit10
                          * forbids it; bit15 / bit16 force / forbid its persistent-tile form; bits20-21 store policy of its epilogue
                          * (0 = by epilogue: nt, sc1 for the f32 residual form; 1 = nt, 2 = sc1 write-through, 3 = plain).  All variants
-                         * of one problem give bit-identical results.  (Bits 7, 11-14, 17-19 selected kernels that were removed in
-                         * round 4 -- tools/ablation/ -- and are ignored.) */
+                         * of one problem give bit-identical results.  Bit 17 forces the strip kernel (round 5; see mtp_gemm_nt_tile), bit 18
+                         * forbids it.  (Bits 7, 11-14, 19 selected kernels that were removed in round 4 -- tools/ablation/ -- and are
+                         * ignored.) */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
     int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them
@@ -86,9 +87,11 @@ typedef struct {
 /* y = x W^T (+epilogue): nn.Linear fwd/dgrad (VIT:50,52,78,87,256,262), patch-embed conv as GEMM (VIT:529),
  * ConvTranspose2d(2,2) as GEMM (VIT:642-649).  C[m][n] = sum_k A[m][k] * B[n][k]. */
 int mtp_gemm_nt(const mtp_gemm_args* args, mtp_stream_t stream);
-/* Query: the tile width of the kernel family mtp_gemm_nt runs these arguments on -- 256 = the 8-wave pipelined
- * 256 x 256 x 64 kernel (bf16, K % 128 == 0, M % 8 == 0, N % 8 == 0), 128 = the 128-wide kernels (every other case, and f32).
- * Both families accumulate in the same k order: results are bit-identical. */
+/* Query: the kernel family mtp_gemm_nt runs these arguments on, named by its tile -- 256 = the 8-wave pipelined
+ * 256 x 256 x 64 kernel (bf16, K % 128 == 0, M % 8 == 0, N % 8 == 0), 64 = the strip kernel (round 5: 128 x 256 strips of
+ * 64 x 64 wave blocks with two accumulator sets, the epilogue of a strip computed under the next strip's K loop; bf16,
+ * K % 64 == 0, K >= 704), 128 = the 128-wide kernels (every other case, and f32).
+ * All families accumulate in the same k order: results are bit-identical. */
 int mtp_gemm_nt_tile(const mtp_gemm_args* args);
 /* bytes of `workspace` mtp_gemm_nt wants: 0 since round 4 (kept in the ABI for callers compiled against 0.3) */
 int64_t mtp_gemm_nt_workspace_bytes(void);

@@ -598,6 +598,15 @@ int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k) {
     return (tiles >= 72 || (tiles >= 40 && a->K >= 1536)) ? 1 : 0;
 }
 
+// the strip kernel of gemm_s8.hip (two accumulator sets, the epilogue of a strip under the next strip's K loop): variant bit 17 forces
+// it (when the problem fits), bit 18 forbids it.
+int nt_s8_mode(const mtp_gemm_args* a, const KArgs& k) {
+    if (a->in_dtype != MTP_BF16 || (a->variant & (1024 | (1 << 18))) || ((a->variant >> 8) & 3) || !mtp_nt_s8_fits(k, a->out_dtype, a->epilogue)) return 0;
+    if (a->variant & (1 << 17)) return 1;
+    static const int env = [] { const char* e = getenv("MTP_NT_S8"); return e ? atoi(e) : 0; }();   // A/B while the default is being measured
+    return env;
+}
+
 template <typename T, typename Tout, int EPI>
 int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     constexpr int E = Elem<T>::kPerChunk;
@@ -612,8 +621,9 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     // 3 = 256 rows), bits 11-14 an ablation build, bits 15 / 16 force / forbid persistent tiles; falls through to the 128-wide kernels
     // when the problem does not fit it
     if constexpr (sizeof(T) == 2) {
+        if (nt_s8_mode(a, k)) return mtp_nt_s8_launch(k, a->out_dtype, EPI, ((((a->variant >> 1) & 3) == 1) ? 2 : 0), stream);
         const int p8 = nt_p8_mode(a, k);
-        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 20) & 3) << 13), stream);
+        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 20) & 3) << 13) | (((a->variant >> 19) & 1) << 10), stream);
     }
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);
@@ -760,6 +770,7 @@ extern "C" int mtp_gemm_nt_tile(const mtp_gemm_args* a) {
     if (a->in_dtype != MTP_BF16) return 128;
     KArgs k;
     if (fill_common<bf16_t>(a, k)) return MTP_ERR_ARG;
+    if (nt_s8_mode(a, k)) return 64;
     return nt_p8_mode(a, k) ? 256 : 128;
 }
 

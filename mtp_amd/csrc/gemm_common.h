@@ -32,6 +32,10 @@ struct KArgs {
 // problem does not fit the kernel's preconditions (the caller then uses the 128-wide kernels of gemm.hip).
 int mtp_nt_p8_launch(const KArgs& k, int out_dtype, int epilogue, int flags, hipStream_t stream);
 int mtp_nt_p8_fits(const KArgs& k, int out_dtype, int epilogue);   // 1 when mtp_nt_p8_launch would run the problem
+// gemm_s8.hip: 128 x 256 x 64 strips, 8 waves, two accumulator sets: the epilogue of a strip runs under the next strip's K loop
+// (bf16 NT, K >= 704 in whole K-tiles).  flags: bit1 = plain strip order.  MTP_ERR_UNSUPPORTED when the problem does not fit.
+int mtp_nt_s8_launch(const KArgs& k, int out_dtype, int epilogue, int flags, hipStream_t stream);
+int mtp_nt_s8_fits(const KArgs& k, int out_dtype, int epilogue);
 
 namespace {
 

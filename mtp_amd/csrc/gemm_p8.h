@@ -105,6 +105,102 @@ __device__ __forceinline__ void two_tiles(typename OP::Ctx& c, u32x4_t (&a)[2][4
     }
 }
 
+// ---- read-ahead form of the phase (round 5) ---------------------------------------------------------------------------------
+// Measured (profiles/r05_ab_p8_loop_ablations.txt): the loop is not DMA-bound (4 instead of 6 half tiles in flight: same time) -- what a
+// wave's MFMAs wait for is its OWN fragment reads: in `phase` above the ds_reads of a half tile are issued at the start of the read part
+// and retired (lgkmcnt(0)) before the barrier that starts the 16 MFMAs consuming them, so their issue time plus the LDS round trip sit
+// on the wave's critical path (NT: 8 / 4 reads per phase, the read part ~1.15 x the MFMA part in the A phases; TN: 16 / 8 transpose
+// reads, the read part ~2 x the MFMA part -- the "LDS-read-issue bound" 0.50 of the weight-gradient kernel).
+// Here the fragments of phase g + 1 are read INSIDE the MFMA block of phase g: every register is overwritten right after the last
+// MFMA that uses it has been issued (a[ks][mi] after its two MFMAs; the b set in use after the last row of its k-step; an idle b set
+// spread over the first groups), so the LDS instructions issue in the shadow of the matrix pipe and their latency runs under the rest of
+// the block, the closing barrier and the next read part, which shrinks to { DMA issue, counted wait, lgkmcnt(0), barrier }.
+// Hazards: the half tile read in the MFMA block of phase g is S_{g+2}; under the stagger group 0 multiplies in the interval in which
+// group 1 runs R_g, so S_{g+2} must have been covered by the waits of R_{g-1}: every counted wait is ONE HALF TILE stricter
+// (vmcnt(10): S_{g+3} .. S_{g+8} in flight).  The reads still retire in R_{g+1} (before its barrier), the slot is refilled in R_{g+2}: the
+// WAR margin of the original schedule.  An LDS return lands >= 64 cycles after its issue, long after the preceding MFMAs have read
+// their operands.
+template <class OP, int NRK, int NRBUF, int QJ, int KS, int MI, int MIC>
+__device__ __forceinline__ void ra_reads(typename OP::Ctx& c, u32x4_t (&a)[2][4], u32x4_t (&b0)[2][2], u32x4_t (&b1)[2][2]) {
+    if constexpr (NRK == KA0 || NRK == KA1) {
+        constexpr int NMI = (NRK == KA1) ? OP::kMi1 : 4;       // fragments per k-step of the half tile being read
+        if constexpr (MI < NMI) OP::template read_a_frag<NRK, NRBUF, KS, MI>(c, a);
+        if constexpr (MI == MIC - 1 && MIC < NMI) OP::template read_a_frag<NRK, NRBUF, KS, (MIC < 4 ? MIC : 3)>(c, a);   // a row the current block does not multiply
+    } else if constexpr (NRK == KB0 || NRK == KB1) {
+        constexpr bool SAME = (NRK == KB0) == (QJ == 0);       // the set the current MFMAs use
+        u32x4_t(&nb)[2][2] = NRK == KB0 ? b0 : b1;
+        if constexpr (SAME) {
+            if constexpr (MI == MIC - 1) {
+                OP::template read_b_frag<NRK, NRBUF, KS, 0>(c, nb);
+                OP::template read_b_frag<NRK, NRBUF, KS, 1>(c, nb);
+            }
+        } else {
+            constexpr int G = KS * MIC + MI;                   // idle set: one fragment after each of the first four groups
+            if constexpr (G < 4) OP::template read_b_frag<NRK, NRBUF, (G >> 1), (G & 1)>(c, nb);
+        }
+    }
+}
+template <class OP, int QI, int QJ, int NRK, int NRBUF, int KS, int MI, int MIC>
+__device__ __forceinline__ void ra_group(typename OP::Ctx& c, u32x4_t (&a)[2][4], u32x4_t (&b0)[2][2], u32x4_t (&b1)[2][2], f32x4_t (&acc)[4][8]) {
+    if constexpr (MI < MIC) {
+        u32x4_t(&b)[2][2] = QJ ? b1 : b0;
+        mma(acc[QJ * 2 + 0][QI * 4 + MI], b[KS][0], a[KS][MI]);
+        mma(acc[QJ * 2 + 1][QI * 4 + MI], b[KS][1], a[KS][MI]);
+        if constexpr (NRK != KNONE) {
+            __builtin_amdgcn_sched_barrier(0);
+            ra_reads<OP, NRK, NRBUF, QJ, KS, MI, MIC>(c, a, b0, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ra_group<OP, QI, QJ, NRK, NRBUF, KS, MI + 1, MIC>(c, a, b0, b1, acc);
+    }
+}
+// phase g: retire the fragments read under phase g - 1 (half tile RK of buffer RBUF), issue half tile SK into buffer SBUF, keep at most VM
+// loads in flight; then the 16 MFMAs of quadrant (QI, QJ) with the reads of half tile NRK of buffer NRBUF (phase g + 1's operands) between them
+template <class OP, int RK, int RBUF, int SK, int SBUF, int VM, int QI, int QJ, int NRK, int NRBUF>
+__device__ __forceinline__ void phase_ra(typename OP::Ctx& c, u32x4_t (&a)[2][4], u32x4_t (&b0)[2][2], u32x4_t (&b1)[2][2], f32x4_t (&acc)[4][8]) {
+    if constexpr (SK != KNONE) OP::template stage<SK, SBUF>(c);
+    wait_vm<VM * OP::kLoadsPerPiecePair / 2>();
+    if constexpr (RK == KA0 || RK == KA1) OP::template retire_a<RK, RBUF>(c, a);
+    if constexpr (RK == KB0) OP::retire_b(b0);
+    if constexpr (RK == KB1) OP::retire_b(b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    constexpr int MIC = QI ? OP::kMi1 : 4;
+    ra_group<OP, QI, QJ, NRK, NRBUF, 0, 0, MIC>(c, a, b0, b1, acc);
+    ra_group<OP, QI, QJ, NRK, NRBUF, 1, 0, MIC>(c, a, b0, b1, acc);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+// the caller has read S_0 (B1 of the first even tile) into b1 and S_1 (its A0) into `a` and covered S_2 (prologue wait vmcnt(10))
+template <class OP, bool LAST>
+__device__ __forceinline__ void two_tiles_ra(typename OP::Ctx& c, u32x4_t (&a)[2][4], u32x4_t (&b0)[2][2], u32x4_t (&b1)[2][2], f32x4_t (&acc)[4][8]) {
+    if constexpr (!LAST) {
+        phase_ra<OP, KA0, 0, KB1, 0, 10, 0, 1, KB0, 0>(c, a, b0, b1, acc);
+        phase_ra<OP, KB0, 0, KA0, 0, 10, 0, 0, KA1, 0>(c, a, b0, b1, acc);
+        phase_ra<OP, KA1, 0, KB0, 0, 10, 1, 0, KB0, 1>(c, a, b0, b1, acc);
+        phase_ra<OP, KB0, 1, KA1, 0, 10, 1, 1, KA0, 1>(c, a, b0, b1, acc);
+        OP::next_ktile(c);
+        phase_ra<OP, KA0, 1, KB0, 1, 10, 0, 0, KB1, 1>(c, a, b0, b1, acc);
+        phase_ra<OP, KB1, 1, KA0, 1, 10, 0, 1, KA1, 1>(c, a, b0, b1, acc);
+        phase_ra<OP, KA1, 1, KB1, 1, 10, 1, 1, KB1, 0>(c, a, b0, b1, acc);
+        phase_ra<OP, KB1, 0, KA1, 1, 10, 1, 0, KA0, 0>(c, a, b0, b1, acc);
+        OP::next_ktile(c);
+    } else {
+        phase_ra<OP, KA0, 0, KNONE, 0, 8, 0, 1, KB0, 0>(c, a, b0, b1, acc);
+        phase_ra<OP, KB0, 0, KNONE, 0, 6, 0, 0, KA1, 0>(c, a, b0, b1, acc);
+        phase_ra<OP, KA1, 0, KNONE, 0, 4, 1, 0, KB0, 1>(c, a, b0, b1, acc);
+        phase_ra<OP, KB0, 1, KNONE, 0, 2, 1, 1, KA0, 1>(c, a, b0, b1, acc);
+        phase_ra<OP, KA0, 1, KNONE, 0, 0, 0, 0, KB1, 1>(c, a, b0, b1, acc);
+        phase_ra<OP, KB1, 1, KNONE, 0, 0, 0, 1, KA1, 1>(c, a, b0, b1, acc);
+        phase_ra<OP, KA1, 1, KNONE, 0, 0, 1, 1, KNONE, 0>(c, a, b0, b1, acc);
+        phase_ra<OP, KNONE, 0, KNONE, 0, 0, 1, 0, KNONE, 0>(c, a, b0, b1, acc);
+    }
+}
+
 // ---- epilogue through LDS ---------------------------------------------------------------------------------------------
 // Measured (tools/ab_gemm.py, ablation "nostore"): storing straight out of the MFMA layout (lane = 4 columns of one row; a wave
 // store = 16 rows x 32 B) costs 29 of 92 us at N = 3072, K = 1024 -- ~7 B/clk/CU, store-issue-bound, nothing to overlap it with at

@@ -84,6 +84,11 @@ struct TnOps {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) b[ks][ni] = tr_frag8(s + c.offB[BUF][ni] + ks * 8192);
     }
+    // one fragment = two transpose reads (read-ahead form of the phase, gemm_p8.h)
+    template <int K, int BUF, int KS, int MI>
+    static __device__ __forceinline__ void read_a_frag(Ctx& c, u32x4_t (&a)[2][4]) { a[KS][MI] = tr_frag8(c.smem + K * P8_HALF + c.offA[BUF][MI] + KS * 8192); }
+    template <int K, int BUF, int KS, int NI>
+    static __device__ __forceinline__ void read_b_frag(Ctx& c, u32x4_t (&b)[2][2]) { b[KS][NI] = tr_frag8(c.smem + K * P8_HALF + c.offB[BUF][NI] + KS * 8192); }
     template <int SK, int SBUF>
     static __device__ __forceinline__ void stage(Ctx& c) {
         constexpr int h = (SK == KA1 || SK == KB1) ? 1 : 0;
@@ -117,7 +122,7 @@ struct TnOps {
     }
 };
 
-template <int XP>
+template <int XP, int RA = 0>
 __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_p8_kernel(TnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -197,19 +202,25 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     TnOps::next_ktile(c);
     TnOps::stage<KB0, 1>(c); TnOps::stage<KA0, 1>(c); TnOps::stage<KB1, 1>(c); TnOps::stage<KA1, 1>(c);
     TnOps::next_ktile(c);
-    wait_vm<12>();
+    if constexpr (RA) wait_vm<10>(); else wait_vm<12>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     TnOps::read_b<KB1, 0>(c, b1);
+    if constexpr (RA) TnOps::read_a<KA0, 0>(c, a);     // read-ahead form: the first phase's A half too (retired, with its column sums, in that phase)
     TnOps::retire_b(b1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if (!(XP & 2) && wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int it = 0; it < pairs - 1; ++it) two_tiles<TnOps, false, XP>(c, a, b0, b1, acc);
-    two_tiles<TnOps, true, XP>(c, a, b0, b1, acc);
+    if constexpr (RA) {
+        for (int it = 0; it < pairs - 1; ++it) two_tiles_ra<TnOps, false>(c, a, b0, b1, acc);
+        two_tiles_ra<TnOps, true>(c, a, b0, b1, acc);
+    } else {
+        for (int it = 0; it < pairs - 1; ++it) two_tiles<TnOps, false, XP>(c, a, b0, b1, acc);
+        two_tiles<TnOps, true, XP>(c, a, b0, b1, acc);
+    }
 
     __builtin_amdgcn_sched_barrier(0);
     if (!(XP & 2) && wr == 0) __builtin_amdgcn_s_barrier();
@@ -283,7 +294,7 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     g.nprob = count;
     g.ntiles = (int)tiles;
     g.plain = (args[0].variant >> 1) & 1;
-    void (*kern)(TnGroup) = gemm_tn_p8_kernel<0>;
+    void (*kern)(TnGroup) = ((args[0].variant >> 19) & 1) ? gemm_tn_p8_kernel<0, 1> : gemm_tn_p8_kernel<0, 0>;   // variant bit 19 (A/B): read-ahead phases
     static unsigned long long optin = 0;     // 128 KiB of dynamic LDS: opt-in once per kernel and device
     if (const int e = mtp_optin_lds((const void*)kern, P8_LDS, optin)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);

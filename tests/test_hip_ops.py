@@ -118,6 +118,7 @@ P8_SHAPES = [(256, 256, 128),      # one tile, the shortest pipeline (one K-tile
 
 
 PS = 32768       # variant bit 15: persistent tiles (the next tile's first K-tiles are issued before the epilogue of the current one)
+RA = 1 << 19     # variant bit 19: read-ahead phases (the next phase's fragments are read under the current phase's MFMAs; NT 224-row tiles and grouped TN)
 
 
 @pytest.mark.parametrize("variant", [256, 512, 768, 514, 512 + PS, 768 + PS])
@@ -163,7 +164,7 @@ def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
     ref = run(1024)
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
     NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20          # store policy of the epilogue: nt / sc1 (write-through) / plain stores (0 = picked per epilogue)
-    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN):
+    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN, 512 + RA, 512 + PS + RA):
         for rep in range(4):
             for x, y in zip(ref, run(v)):
                 assert torch.equal(x, y), (v, rep)
@@ -177,12 +178,106 @@ def test_gemm_nt_p8_vit_l_shapes_race_screen(ops):
     for (N, K) in [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C), (C, 3 * C)]:
         a, w, b = dev(rnd(T, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.05), dtype), dev(rnd(N, seed=2))
         ref = ops.gemm_nt(a, w, e(T, N, dtype=dtype), bias=b, variant=1024)
-        for v in (512, 768, 512 + PS, 768 + PS):
+        for v in (512, 768, 512 + PS, 768 + PS, 512 + RA, 512 + PS + RA):
             out = e(T, N, dtype=dtype)
             for rep in range(6):
                 out.zero_()
                 ops.gemm_nt(a, w, out, bias=b, variant=v)
                 assert torch.equal(out, ref), (N, K, v, rep)
+
+
+# ---- the strip kernel (gemm_s8.hip, variant bit 17): 128 x 256 strips, two accumulator sets, epilogue slices under the next strip's K loop
+S8 = 1 << 17
+# M / N off the strip grid (clamped DMA rows, masked stores), one strip, several strips per workgroup (> 256 strips), K from the minimum (11 K-tiles) up
+S8_SHAPES = [(128, 256, 704), (392, 520, 768), (1000, 264, 1024), (2048, 2304, 768), (12544, 1024, 1024), (12544, 3072, 1024), (6272, 768, 3072)]
+
+
+@pytest.mark.parametrize("M,N,K", S8_SHAPES[:5])
+def test_gemm_nt_s8_vs_oracle(ops, M, N, K):
+    dtype = torch.bfloat16
+    a, w, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.1), rnd(N, seed=2)
+    da, dw, out = dev(a, dtype), dev(w, dtype), e(M, N, dtype=dtype)
+    assert ops.gemm_nt_tile(da, dw, out, bias=dev(b), variant=S8) == 64      # really the strip kernel, not a fall-through
+    ops.gemm_nt(da, dw, out, bias=dev(b), variant=S8)
+    assert rel_err(out.float().cpu(), a @ w.t() + b) < TOL[dtype]
+
+
+def test_gemm_nt_s8_asymmetric_identity(ops):
+    """A = I against an asymmetric B: a transposed / permuted fragment, a wrong half-tile <-> slot mapping or a wrong lane after the
+    permlane16 swaps of the epilogue shows up as a misplaced integer"""
+    M = N = K = 1024
+    w = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :]) % 251).float()     # exact in bf16, no two rows alike
+    a = torch.eye(M)
+    for dt in (torch.float32, torch.bfloat16):
+        out = ops.gemm_nt(dev(a, torch.bfloat16), dev(w, torch.bfloat16), e(M, N, dtype=dt), variant=S8)
+        assert torch.equal(out.float().cpu(), w.t().contiguous()), dt
+
+
+@pytest.mark.parametrize("M,N,K", S8_SHAPES)
+def test_gemm_nt_s8_bit_identical_to_128_wide_kernels(ops, M, N, K):
+    """same k order of accumulation and the same epilogue arithmetic as the 128-wide kernels -> every epilogue the strip kernel has must be
+    bit-identical (variant 1024 forbids the pipelined kernels); repeated launches screen the counted-wait pipeline and the in-flight
+    side loads for races (a stale LDS tile, a side register read before its load landed or a slice of the wrong strip is a mismatch)"""
+    dtype, rps = torch.bfloat16, 196
+    a, w, b = dev(rnd(M, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.1), dtype), dev(rnd(N, seed=2))
+    res, uu = dev(rnd(M, N, seed=3)), dev(rnd(M, N, dtype=dtype, seed=5), dtype)
+    rs = dev(1.0 + 0.1 * rnd((M + rps - 1) // rps, seed=6))
+
+    def run(v):
+        r = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=v)
+        r0 = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, variant=v)
+        f = ops.gemm_nt(a, w, e(M, N), bias=b, variant=v)
+        f0 = ops.gemm_nt(a, w, e(M, N), variant=v)
+        y = ops.gemm_nt(a, w, e(M, N, dtype=dtype), bias=b, variant=v)
+        y0 = ops.gemm_nt(a, w, e(M, N, dtype=dtype), variant=v)
+        dg = e(M, N, dtype=dtype)
+        h2 = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU_DG, bias=b, aux=dg, variant=v)
+        mu = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_MUL, aux=uu, variant=v)
+        return r, r0, f, f0, y, y0, dg, h2, mu
+    ref = run(1024)
+    assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=S8) == 64
+    assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), epi=ops.EPI_MUL, aux=uu, variant=S8) == 64
+    assert ops.gemm_nt_tile(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=S8) == 64
+    names = ("res+rowscale", "res", "f32 bias", "f32", "bf16 bias", "bf16", "gelu' out", "gelu out", "mul")
+    for v in (S8, S8 + 2):
+        for rep in range(3):
+            for nm, x, y in zip(names, ref, run(v)):
+                assert torch.equal(x, y), (nm, v, rep, (x.float() - y.float()).abs().max().item())
+
+
+def test_gemm_nt_s8_bias_mod_and_fallbacks(ops):
+    """ConvTranspose2d's repeated bias (bias_mod) through the strip kernel; what it does not take (K below 11 K-tiles, the broadcast
+    residual of the patch embedding) falls through to the other families even when forced"""
+    dtype = torch.bfloat16
+    M, N, K, C = 512, 1024, 768, 256
+    a, w, b = dev(rnd(M, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.1), dtype), dev(rnd(C, seed=2))
+    ref = ops.gemm_nt(a, w, e(M, N, dtype=dtype), bias=b, bias_mod=C, variant=1024)
+    out = ops.gemm_nt(a, w, e(M, N, dtype=dtype), bias=b, bias_mod=C, variant=S8)
+    assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, bias_mod=C, variant=S8) == 64 and torch.equal(out, ref)
+    a2 = dev(rnd(M, 512, dtype=dtype), dtype)
+    w2 = dev(rnd(N, 512, dtype=dtype, seed=1), dtype)
+    assert ops.gemm_nt_tile(a2, w2, e(M, N, dtype=dtype), variant=S8) != 64
+    res = dev(rnd(128, N, seed=3))
+    bn = dev(rnd(N, seed=4))
+    assert ops.gemm_nt_tile(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=bn, res=res, res_mod=128, variant=S8) != 64
+    r1 = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=bn, res=res, res_mod=128, variant=S8)
+    r2 = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=bn, res=res, res_mod=128, variant=1024)
+    assert torch.equal(r1, r2)
+
+
+def test_gemm_nt_s8_vit_l_shapes_race_screen(ops):
+    """the training shapes with a 1024-long contraction (qkv / proj / fc1 and their data gradients) at M = 64 x 196 tokens: up to 1568 strips
+    on 256 persistent workgroups, every launch compared bit for bit with the 128-wide kernels"""
+    T, C = 12544, 1024
+    dtype = torch.bfloat16
+    for (N, K) in [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C)]:
+        a, w, b = dev(rnd(T, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.05), dtype), dev(rnd(N, seed=2))
+        ref = ops.gemm_nt(a, w, e(T, N, dtype=dtype), bias=b, variant=1024)
+        out = e(T, N, dtype=dtype)
+        for rep in range(6):
+            out.zero_()
+            ops.gemm_nt(a, w, out, bias=b, variant=S8)
+            assert torch.equal(out, ref), (N, K, rep)
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -228,7 +323,7 @@ def _wgrad_group(ops, shapes, seed=0):
     [(128, 256, 256, True)],                                                                  # one tile, one K-tile pair
     [(256, 512, 256, True), (384, 256, 768, False), (1024, 256, 256, True)],                   # different contractions in one launch
     [(1536, 768, 256, True), (1536, 256, 256, True), (1536, 1024, 256, False), (1536, 256, 1024, True)]])   # a block's four gradients
-@pytest.mark.parametrize("variant", [0])       # the 8-wave 8-phase kernel (the 4-wave 32x32x16 form of round 3 lives in tools/ablation/)
+@pytest.mark.parametrize("variant", [0, RA])   # the 8-wave 8-phase kernel, plain and read-ahead phases (the 4-wave 32x32x16 form of round 3 lives in tools/ablation/)
 def test_gemm_tn_grouped_vs_oracle(ops, shapes, variant):
     q, refs = _wgrad_group(ops, shapes)
     q.variant = variant
@@ -245,11 +340,13 @@ def test_gemm_tn_grouped_vs_oracle(ops, shapes, variant):
     [(512, 96, 32, True), (256, 8, 8, True), (128, 264, 520, True)],                           # narrower than one half tile; 1-chunk problem; tiles 2 x 3 with both edges
     [(16384, 192, 192, True), (16384, 384, 216, True), (32768, 96, 32, False)],                # long contractions: cut into pieces inside the launch
     [(16384 + 128, 192, 384, True)]])                                                          # ... whose last piece is shorter
-def test_gemm_tn_grouped_edge_tiles_and_pieces(ops, shapes):
+@pytest.mark.parametrize("variant", [0, RA])
+def test_gemm_tn_grouped_edge_tiles_and_pieces(ops, shapes, variant):
     """sizes off the 256 grid (multiples of 8: the last tile row / column is clamped on the way in and masked on the way out) and few-tile
     problems with a long contraction (ops.grouped_splits: pieces of ~4096 rows, each an own workgroup, summed by one reduction launch)"""
     q, refs = _wgrad_group(ops, shapes)
     assert any(j[4] > 1 for j in q.jobs) == (shapes[0][0] >= 16384)
+    q.variant = variant
     q.flush()
     for a, b, cs0, dw, cs in refs:
         assert rel_err(dw.cpu(), a.float().t() @ b.float()) < 3e-4
@@ -257,7 +354,7 @@ def test_gemm_tn_grouped_edge_tiles_and_pieces(ops, shapes):
             assert rel_err(cs.cpu(), cs0 + a.float().sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [0])
+@pytest.mark.parametrize("variant", [0, RA])
 def test_gemm_tn_grouped_vit_l_block_repeatable(ops, variant):
     """the four weight gradients of a ViT-L block at the training size (T = 12544 tokens, 192 tiles, 98 K-tile pairs each) against
     the split-K kernels of gemm.hip, and launch-to-launch bit-identical (no atomics on dW; one atomic per bias-gradient entry):
@@ -285,7 +382,7 @@ def test_gemm_tn_grouped_vit_l_block_repeatable(ops, variant):
         else:
             for (x, xc), (y, yc) in zip(first, outs):
                 assert torch.equal(x, y), rep
-                if variant == 0:
+                if variant in (0, RA):
                     assert torch.equal(xc, yc), rep
                 else:      # the 4-wave form spreads the bias gradient over the tile row: tiles_n f32 atomics per entry, order not fixed
                     assert rel_err(xc, yc) < 1e-6, rep

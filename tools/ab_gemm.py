@@ -14,7 +14,8 @@ from tools.bench_ops import r
 
 T, C = 12544, 1024
 NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20
-NAMES = {-1: "hipBLASLt(torch.addmm)",  512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain"}
+S8, RA = 1 << 17, 1 << 19
+NAMES = {S8: "s8-strip", 512 + RA: "p8-224-readahead", 512 + 32768 + RA: "p8-224-persist-readahead", 256 + RA: "p8-auto-readahead", -1: "hipBLASLt(torch.addmm)",  512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain"}
 
 
 def time_many(fn, iters):
@@ -32,7 +33,10 @@ def main():
     variants = [int(v) for v in sys.argv[2:]] or [1024, 512, 768]
     bf = torch.bfloat16
     cases = []
-    for (M, N, K) in [(T, 3 * C, C), (T, C, C), (T, 4 * C, C), (T, C, 4 * C), (T, C, 3 * C), (4 * T, 4 * C, C), (T, C, 768)]:
+    shapes = [(T, 3 * C, C), (T, C, C), (T, 4 * C, C), (T, C, 4 * C), (T, C, 3 * C), (4 * T, 4 * C, C), (T, C, 768)]
+    if os.environ.get("MTP_AB_SHAPES") == "mid":      # ViT-B at batch 32 and InternImage-XL's 768- / 1536-channel levels
+        shapes = [(6272, 2304, 768), (6272, 768, 768), (6272, 3072, 768), (6272, 768, 3072), (8192, 768, 768), (8192, 3072, 768), (8192, 768, 3072), (2048, 1536, 1536), (2048, 6144, 1536), (2048, 1536, 6144)]
+    for (M, N, K) in shapes:
         cases.append(("bias", M, N, K))
     cases += [("gelu", T, 4 * C, C), ("dgelu", T, 4 * C, C), ("gelu_dg", T, 4 * C, C), ("mul", T, 4 * C, C), ("res", T, C, C), ("res", T, C, 4 * C)]
     for (epi, M, N, K) in cases:
@@ -80,7 +84,9 @@ def main():
                     okv[v] = True
                     time_many(lambda: launch(v), 3)
                 continue
-            if v not in (1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + NT_, 512 + SC1, 512 + PLAIN) and epi != "bias":
+            if v == S8 and epi in ("gelu", "dgelu"):
+                continue
+            if v not in (S8, 512 + RA, 512 + 32768 + RA, 256 + RA, 1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + NT_, 512 + SC1, 512 + PLAIN) and epi != "bias":
                 continue
             out.zero_()
             ops.gemm_nt(a, w, out, variant=v, **kw)
