@@ -603,8 +603,14 @@ int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k) {
 int nt_s8_mode(const mtp_gemm_args* a, const KArgs& k) {
     if (a->in_dtype != MTP_BF16 || (a->variant & (1024 | (1 << 18))) || ((a->variant >> 8) & 3) || !mtp_nt_s8_fits(k, a->out_dtype, a->epilogue)) return 0;
     if (a->variant & (1 << 17)) return 1;
-    static const int env = [] { const char* e = getenv("MTP_NT_S8"); return e ? atoi(e) : 0; }();   // A/B while the default is being measured
-    return env;
+    // default: problems of less than half a round of 256 x 256 tiles on the 256 CUs -- the 768- / 1536-channel levels of InternImage-XL, ViT-B at
+    // batch 32 with N = C.  Measured (tools/ab_gemm.py, MTP_AB_SHAPES=mid; profiles/r05_ab_gemm_s8_strip_mid_shapes.txt): 6272 x 768 x 768
+    // 17.1 -> 15.6 us, 6272 x 768 x 3072 45.4 -> 38.3, 8192 x 768 x 768 16.8 -> 15.4, 8192 x 768 x 3072 45.5 -> 38.8, 2048 x 1536 x 1536 26.0 -> 22.6,
+    // 2048 x 1536 x 6144 83.3 -> 67.9 (twice as many work units, each half as long, the epilogue of all but the last hidden); from 225 tiles on the
+    // 8-wave kernel wins (its loop moves 2/3 of the L2 -> LDS bytes per flop): 6272 x 2304 x 768 22.5 vs 29.0, every ViT-L shape 10-38 %.
+    // Below 40 tiles (not measured with this kernel) the 128-wide kernels keep the problem: 4 x as many, smaller workgroups.
+    const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    return tiles >= 40 && tiles <= 128;
 }
 
 template <typename T, typename Tout, int EPI>
@@ -623,7 +629,7 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
         if (nt_s8_mode(a, k)) return mtp_nt_s8_launch(k, a->out_dtype, EPI, ((((a->variant >> 1) & 3) == 1) ? 2 : 0), stream);
         const int p8 = nt_p8_mode(a, k);
-        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 20) & 3) << 13) | (((a->variant >> 19) & 1) << 10), stream);
+        if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 20) & 3) << 13), stream);
     }
     const int tiles_m = (k.M + BM - 1) / BM;
     dim3 grid(tiles_m * k.tiles_n), block(NT_THREADS);

@@ -110,7 +110,7 @@ __device__ __forceinline__ void two_tiles(typename OP::Ctx& c, u32x4_t (&a)[2][4
 // wave's MFMAs wait for is its OWN fragment reads: in `phase` above the ds_reads of a half tile are issued at the start of the read part
 // and retired (lgkmcnt(0)) before the barrier that starts the 16 MFMAs consuming them, so their issue time plus the LDS round trip sit
 // on the wave's critical path (NT: 8 / 4 reads per phase, the read part ~1.15 x the MFMA part in the A phases; TN: 16 / 8 transpose
-// reads, the read part ~2 x the MFMA part -- the "LDS-read-issue bound" 0.50 of the weight-gradient kernel).
+// reads, the read part ~2 x the MFMA part -- the "LDS-read-issue bound" 0.50 of the weight-gradient kernel).  Used by gemm_tn_p8.hip.
 // Here the fragments of phase g + 1 are read INSIDE the MFMA block of phase g: every register is overwritten right after the last
 // MFMA that uses it has been issued (a[ks][mi] after its two MFMAs; the b set in use after the last row of its k-step; an idle b set
 // spread over the first groups), so the LDS instructions issue in the shadow of the matrix pipe and their latency runs under the rest of
@@ -120,6 +120,9 @@ __device__ __forceinline__ void two_tiles(typename OP::Ctx& c, u32x4_t (&a)[2][4
 // (vmcnt(10): S_{g+3} .. S_{g+8} in flight).  The reads still retire in R_{g+1} (before its barrier), the slot is refilled in R_{g+2}: the
 // WAR margin of the original schedule.  An LDS return lands >= 64 cycles after its issue, long after the preceding MFMAs have read
 // their operands.
+// (Measured on the grouped TN kernel, profiles/r05_ab_wgrad_readahead.txt: 5-11 % ahead of the plain phases.  A SPLIT form -- only the
+// k-step-0 fragments under the MFMAs, the k-step-1 fragments at the start of the next read part -- was built too: bit-identical, 2-4 %
+// behind this one.  On the NT kernel, whose phases read 8 / 4 b128 fragments, read-ahead changes nothing: -1 ... +3 %.)
 template <class OP, int NRK, int NRBUF, int QJ, int KS, int MI, int MIC>
 __device__ __forceinline__ void ra_reads(typename OP::Ctx& c, u32x4_t (&a)[2][4], u32x4_t (&b0)[2][2], u32x4_t (&b1)[2][2]) {
     if constexpr (NRK == KA0 || NRK == KA1) {

@@ -102,13 +102,6 @@ struct NtOps {
     static constexpr int kMi1 = MI1;
     template <int K, int BUF> static __device__ __forceinline__ void read_a(Ctx& c, u32x4_t (&a)[2][4]) { nt_read_a<K, BUF, (K == KA1 ? MI1 : 4)>(c, a); }
     template <int K, int BUF> static __device__ __forceinline__ void read_b(Ctx& c, u32x4_t (&b)[2][2]) { nt_read_b<K, BUF>(c, b); }
-    // one fragment (read-ahead form of the phase, gemm_p8.h)
-    template <int K, int BUF, int KS, int MI> static __device__ __forceinline__ void read_a_frag(Ctx& c, u32x4_t (&a)[2][4]) {
-        dsr<K * P8_HALF + MI * 2048>(a[KS][MI], K == KA1 ? c.addrA1[BUF][KS] : c.addrA[BUF][KS]);
-    }
-    template <int K, int BUF, int KS, int NI> static __device__ __forceinline__ void read_b_frag(Ctx& c, u32x4_t (&b)[2][2]) {
-        dsr<K * P8_HALF + NI * 2048>(b[KS][NI], c.addrB[BUF][KS]);
-    }
     template <int SK, int SBUF> static __device__ __forceinline__ void stage(Ctx& c) { nt_stage<SK, SBUF>(c); }
     template <int K, int BUF> static __device__ __forceinline__ void retire_a(Ctx&, u32x4_t (&a)[2][4]) { wait_a<(K == KA1 ? MI1 : 4)>(a); }
     static __device__ __forceinline__ void retire_b(u32x4_t (&b)[2][2]) { wait_b(b); }
@@ -164,7 +157,7 @@ __device__ __forceinline__ void p8_issue_prologue(P8Ctx& c) {
 // through 4 KiB per wave beyond the ring: the first-load latency of a tile and the workgroup hand-over are hidden behind the
 // previous tile's stores.  The load queue is drained (vmcnt(0)) once per tile, after the epilogue: the counted waits of the main
 // loop assume that only the DMA stream is in flight.
-template <typename Tout, int EPI, int MI1, int XP, int PS, int SP = 0, int RA = 0>
+template <typename Tout, int EPI, int MI1, int XP, int PS, int SP = 0>
 __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_p8_kernel(KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WROWS = 64 + 16 * MI1, BM = 2 * WROWS;      // rows per wave row, rows per tile
@@ -211,28 +204,19 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-        if constexpr (RA) wait_vm<10>(); else wait_vm<12>();   // S_0, S_1 (read-ahead form: and S_2) have landed (this lane's pieces)
+        wait_vm<12>();   // S_0, S_1 have landed (this lane's pieces)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         nt_read_b<KB1, 0>(c, b1);
-        if constexpr (RA) {      // ... and the first phase's A half: from here on every phase reads the NEXT phase's fragments under its MFMAs
-            nt_read_a<KA0, 0, 4>(c, a);
-            wait_a<4>(a);
-        }
         wait_b(b1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         if (!(XP & 2) && wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind wave row 0
         __builtin_amdgcn_sched_barrier(0);
 
-        if constexpr (RA) {
-            for (int it = 0; it < pairs - 1; ++it) two_tiles_ra<NtOps<MI1>, false>(c, a, b0, b1, acc);
-            two_tiles_ra<NtOps<MI1>, true>(c, a, b0, b1, acc);
-        } else {
-            for (int it = 0; it < pairs - 1; ++it) two_tiles<NtOps<MI1>, false, XP>(c, a, b0, b1, acc);
-            two_tiles<NtOps<MI1>, true, XP>(c, a, b0, b1, acc);
-        }
+        for (int it = 0; it < pairs - 1; ++it) two_tiles<NtOps<MI1>, false, XP>(c, a, b0, b1, acc);
+        two_tiles<NtOps<MI1>, true, XP>(c, a, b0, b1, acc);
 
         __builtin_amdgcn_sched_barrier(0);
         if (!(XP & 2) && wr == 0) __builtin_amdgcn_s_barrier();   // re-align: every wave has finished its last phase behind this barrier
@@ -278,13 +262,13 @@ int p8_cus() {
     return ncu;
 }
 
-template <typename Tout, int EPI, int MI1, int XP, int PS = 0, int SP = 0, int RA = 0>
+template <typename Tout, int EPI, int MI1, int XP, int PS = 0, int SP = 0>
 int launch_p8_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
     constexpr int LDS = P8_LDS + ((PS || SP) ? 8 * 4096 : 0);
     static unsigned long long optin = 0;   // 128 / 160 KiB of dynamic LDS needs the opt-in once per kernel and device
-    if (const int e = mtp_optin_lds((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP, RA>, LDS, optin)) return e;
+    if (const int e = mtp_optin_lds((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>, LDS, optin)) return e;
     const int grid = PS ? (ntiles < p8_cus() ? ntiles : p8_cus()) : ntiles;
-    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP, RA>), dim3(grid), dim3(P8_THREADS), LDS, stream, a);
+    hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>), dim3(grid), dim3(P8_THREADS), LDS, stream, a);
     return mtp_launch_status();
 }
 
@@ -316,11 +300,6 @@ int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
     // its 103 MB of output per launch do not evict the operand panels from the 4-MiB L2s); whole step +1.0 %.
     int sp = (flags >> 13) & 3;
     if (sp == 0) sp = (EPI == MTP_EPI_BIAS_RES) ? 2 : 1;
-    if (flags & 1024) {    // A/B (variant bit 19): the read-ahead form of the phase, 224-row tiles with the default store policy
-        if (bm != 224) return MTP_ERR_UNSUPPORTED;
-        if (sp == 2) return persist ? launch_p8_kernel<Tout, EPI, 3, 0, 1, 2, 1>(a, ntiles, stream) : launch_p8_kernel<Tout, EPI, 3, 0, 0, 2, 1>(a, ntiles, stream);
-        return persist ? launch_p8_kernel<Tout, EPI, 3, 0, 1, 1, 1>(a, ntiles, stream) : launch_p8_kernel<Tout, EPI, 3, 0, 0, 1, 1>(a, ntiles, stream);
-    }
     if (bm == 224 && sp == 1) return persist ? launch_p8_kernel<Tout, EPI, 3, 0, 1, 1>(a, ntiles, stream) : launch_p8_kernel<Tout, EPI, 3, 0, 0, 1>(a, ntiles, stream);
     if (bm == 224 && sp == 2) return persist ? launch_p8_kernel<Tout, EPI, 3, 0, 1, 2>(a, ntiles, stream) : launch_p8_kernel<Tout, EPI, 3, 0, 0, 2>(a, ntiles, stream);
     if (persist) {

@@ -122,7 +122,7 @@ struct TnOps {
     }
 };
 
-template <int XP, int RA = 0>
+template <int XP, int RA = 1>
 __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_p8_kernel(TnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -294,7 +294,9 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     g.nprob = count;
     g.ntiles = (int)tiles;
     g.plain = (args[0].variant >> 1) & 1;
-    void (*kern)(TnGroup) = ((args[0].variant >> 19) & 1) ? gemm_tn_p8_kernel<0, 1> : gemm_tn_p8_kernel<0, 0>;   // variant bit 19 (A/B): read-ahead phases
+    // read-ahead phases (gemm_p8.h: the next phase's transpose reads issued under the current phase's MFMAs; round 5: +5-11 %); variant bit 19 = the
+    // plain phases of rounds 2-4 (A/B, bit-identical)
+    void (*kern)(TnGroup) = ((args[0].variant >> 19) & 1) ? gemm_tn_p8_kernel<0, 0> : gemm_tn_p8_kernel<0, 1>;
     static unsigned long long optin = 0;     // 128 KiB of dynamic LDS: opt-in once per kernel and device
     if (const int e = mtp_optin_lds((const void*)kern, P8_LDS, optin)) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);

@@ -118,7 +118,7 @@ P8_SHAPES = [(256, 256, 128),      # one tile, the shortest pipeline (one K-tile
 
 
 PS = 32768       # variant bit 15: persistent tiles (the next tile's first K-tiles are issued before the epilogue of the current one)
-RA = 1 << 19     # variant bit 19: read-ahead phases (the next phase's fragments are read under the current phase's MFMAs; NT 224-row tiles and grouped TN)
+PLAIN_TN = 1 << 19     # variant bit 19 (grouped TN): the plain phases of rounds 2-4 instead of the read-ahead phases (the next phase's fragments read under the current MFMAs)
 
 
 @pytest.mark.parametrize("variant", [256, 512, 768, 514, 512 + PS, 768 + PS])
@@ -164,7 +164,7 @@ def test_gemm_nt_p8_bit_identical_to_128_wide_kernels(ops, M, N, K):
     ref = run(1024)
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=1024) == 128
     NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20          # store policy of the epilogue: nt / sc1 (write-through) / plain stores (0 = picked per epilogue)
-    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN, 512 + RA, 512 + PS + RA):
+    for v in (512, 768, 512 + PS, 768 + PS, 512 + NT_, 512 + SC1, 512 + PLAIN, 512 + PS + NT_, 512 + PS + SC1, 512 + PS + PLAIN):
         for rep in range(4):
             for x, y in zip(ref, run(v)):
                 assert torch.equal(x, y), (v, rep)
@@ -178,7 +178,7 @@ def test_gemm_nt_p8_vit_l_shapes_race_screen(ops):
     for (N, K) in [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C), (C, 3 * C)]:
         a, w, b = dev(rnd(T, K, dtype=dtype), dtype), dev(rnd(N, K, dtype=dtype, seed=1, scale=0.05), dtype), dev(rnd(N, seed=2))
         ref = ops.gemm_nt(a, w, e(T, N, dtype=dtype), bias=b, variant=1024)
-        for v in (512, 768, 512 + PS, 768 + PS, 512 + RA, 512 + PS + RA):
+        for v in (512, 768, 512 + PS, 768 + PS):
             out = e(T, N, dtype=dtype)
             for rep in range(6):
                 out.zero_()
@@ -323,7 +323,7 @@ def _wgrad_group(ops, shapes, seed=0):
     [(128, 256, 256, True)],                                                                  # one tile, one K-tile pair
     [(256, 512, 256, True), (384, 256, 768, False), (1024, 256, 256, True)],                   # different contractions in one launch
     [(1536, 768, 256, True), (1536, 256, 256, True), (1536, 1024, 256, False), (1536, 256, 1024, True)]])   # a block's four gradients
-@pytest.mark.parametrize("variant", [0, RA])   # the 8-wave 8-phase kernel, plain and read-ahead phases (the 4-wave 32x32x16 form of round 3 lives in tools/ablation/)
+@pytest.mark.parametrize("variant", [0, PLAIN_TN])   # the 8-wave 8-phase kernel, read-ahead and plain phases (the 4-wave 32x32x16 form of round 3 lives in tools/ablation/)
 def test_gemm_tn_grouped_vs_oracle(ops, shapes, variant):
     q, refs = _wgrad_group(ops, shapes)
     q.variant = variant
@@ -340,7 +340,7 @@ def test_gemm_tn_grouped_vs_oracle(ops, shapes, variant):
     [(512, 96, 32, True), (256, 8, 8, True), (128, 264, 520, True)],                           # narrower than one half tile; 1-chunk problem; tiles 2 x 3 with both edges
     [(16384, 192, 192, True), (16384, 384, 216, True), (32768, 96, 32, False)],                # long contractions: cut into pieces inside the launch
     [(16384 + 128, 192, 384, True)]])                                                          # ... whose last piece is shorter
-@pytest.mark.parametrize("variant", [0, RA])
+@pytest.mark.parametrize("variant", [0, PLAIN_TN])
 def test_gemm_tn_grouped_edge_tiles_and_pieces(ops, shapes, variant):
     """sizes off the 256 grid (multiples of 8: the last tile row / column is clamped on the way in and masked on the way out) and few-tile
     problems with a long contraction (ops.grouped_splits: pieces of ~4096 rows, each an own workgroup, summed by one reduction launch)"""
@@ -354,7 +354,7 @@ def test_gemm_tn_grouped_edge_tiles_and_pieces(ops, shapes, variant):
             assert rel_err(cs.cpu(), cs0 + a.float().sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [0, RA])
+@pytest.mark.parametrize("variant", [0, PLAIN_TN])
 def test_gemm_tn_grouped_vit_l_block_repeatable(ops, variant):
     """the four weight gradients of a ViT-L block at the training size (T = 12544 tokens, 192 tiles, 98 K-tile pairs each) against
     the split-K kernels of gemm.hip, and launch-to-launch bit-identical (no atomics on dW; one atomic per bias-gradient entry):
@@ -382,7 +382,7 @@ def test_gemm_tn_grouped_vit_l_block_repeatable(ops, variant):
         else:
             for (x, xc), (y, yc) in zip(first, outs):
                 assert torch.equal(x, y), rep
-                if variant in (0, RA):
+                if variant in (0, PLAIN_TN):
                     assert torch.equal(xc, yc), rep
                 else:      # the 4-wave form spreads the bias gradient over the tile row: tiles_n f32 atomics per entry, order not fixed
                     assert rel_err(xc, yc) < 1e-6, rep

@@ -14,8 +14,8 @@ from tools.bench_ops import r
 
 T, C = 12544, 1024
 NT_, SC1, PLAIN = 1 << 20, 2 << 20, 3 << 20
-S8, RA = 1 << 17, 1 << 19
-NAMES = {S8: "s8-strip", 512 + RA: "p8-224-readahead", 512 + 32768 + RA: "p8-224-persist-readahead", 256 + RA: "p8-auto-readahead", -1: "hipBLASLt(torch.addmm)",  512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain"}
+S8 = 1 << 17
+NAMES = {S8: "s8-strip", -1: "hipBLASLt(torch.addmm)",  512 + NT_: "p8-224-nt", 512 + SC1: "p8-224-sc1", 512 + PLAIN: "p8-224-plain", 512 + 65536: "p8-224-oneshot", 1024: "w128", 256 + 32768: "p8-persist", 512 + 32768: "p8-224-persist", 768 + 32768: "p8-256-persist", 512 + 65536: "p8-224-oneshot", 768 + 65536: "p8-256-oneshot", 256: "p8-auto", 512: "p8-224", 768: "p8-256", 258: "p8-plain"}
 
 
 def time_many(fn, iters):
@@ -86,7 +86,7 @@ def main():
                 continue
             if v == S8 and epi in ("gelu", "dgelu"):
                 continue
-            if v not in (S8, 512 + RA, 512 + 32768 + RA, 256 + RA, 1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + NT_, 512 + SC1, 512 + PLAIN) and epi != "bias":
+            if v not in (S8, 1024, 256, 512, 768, 258, 256 + 32768, 512 + 32768, 768 + 32768, 512 + 65536, 768 + 65536, 512 + NT_, 512 + SC1, 512 + PLAIN) and epi != "bias":
                 continue
             out.zero_()
             ops.gemm_nt(a, w, out, variant=v, **kw)

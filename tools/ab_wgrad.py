@@ -1,5 +1,5 @@
-"""A/B of the grouped weight-gradient launch (gemm_tn_p8.hip) on the weight gradients of N ViT-L blocks: plain phases (variant 0) against the
-read-ahead phases (variant bit 19: the next phase's transpose reads issued under the current phase's MFMAs), interleaved rounds in one process,
+"""A/B of the grouped weight-gradient launch (gemm_tn_p8.hip) on the weight gradients of N ViT-L blocks: the plain phases of rounds 2-4 (variant bit 19)
+against the read-ahead phases (default since round 5: the next phase's transpose reads issued under the current phase's MFMAs), interleaved rounds in one process,
 results compared bit for bit.  usage: python tools/ab_wgrad.py [rounds] [blocks ...]"""
 import os
 import statistics
@@ -13,7 +13,7 @@ from tools.bench_ops import r
 
 T, C = 12544, 1024
 SHAPES = [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C)]      # qkv, proj, fc1, fc2: dW (M, N) = dY (T, M)^T X (T, N)
-RA = 1 << 19
+PLAIN = 1 << 19
 
 
 def timed(fn, iters):
@@ -41,14 +41,14 @@ def main():
                 q.add(a, b, dw, cs)
             q.flush()
 
-        grouped(0)
+        grouped(PLAIN)
         ref = [p[2].clone() for p in probs]
-        grouped(RA)
+        grouped(0)
         same = all(torch.equal(p[2], x) for p, x in zip(probs, ref))
         t0, t1 = [], []
         for _ in range(rounds):
-            t0.append(timed(lambda: grouped(0), 5))
-            t1.append(timed(lambda: grouped(RA), 5))
+            t0.append(timed(lambda: grouped(PLAIN), 5))
+            t1.append(timed(lambda: grouped(0), 5))
         tiles = sum((a.shape[1] // 256) * (b.shape[1] // 256) for a, b, _, _ in probs)
         print("%d block(s), %d tiles: plain %.1f us %.0f TF/s (min %.1f) | read-ahead %.1f us %.0f TF/s (min %.1f) %s" % (
             nblk, tiles, statistics.median(t0) * 1e6, fl / statistics.median(t0) / 1e12, min(t0) * 1e6,
