@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void flash_prep_kernel(const bf16_t* __restric
         for (int e = 0; e < 4; ++e)
             dl += bf16_bits_to_f32(a[e] & 0xffffu) * bf16_bits_to_f32(c[e] & 0xffffu) + bf16_bits_to_f32(a[e] >> 16) * bf16_bits_to_f32(c[e] >> 16);
     }
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);
+    dl = xor16_sum(dl);
+    dl = xor32_sum(dl);
     if (nv && gq == 0) delta[(int64_t)bh * N + n] = dl;
     const int hq = nc / g.Wp + g.Hp - 1, wq = nc % g.Wp + g.Wp - 1;
     float* row = bias + ((int64_t)bh * N + nc) * g.HW;

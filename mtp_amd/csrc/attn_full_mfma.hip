@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const bf16_t* __rest
                 s[kt][r] = v;
                 m = fmaxf(m, v);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = xor16_max(m);
+        m = xor32_max(m);
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 16; ++kt)
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const bf16_t* __rest
                 s[kt][r] = p;
                 l += p;
             }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor16_sum(l);
+        l = xor32_sum(l);
         f32x4_t oa[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
                 s[kt][r] = v;
                 bm = fmaxf(bm, v);
             }
-        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        bm = xor16_max(bm);
+        bm = xor32_max(bm);
         const float mnew = fmaxf(m, bm);
         const float alpha = __expf(m - mnew);   // first block: exp(-inf) = 0
         float lb = 0.f;
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
                 s[kt][r] = p;
                 lb += p;
             }
-        lb += __shfl_xor(lb, 16, 64);
-        lb += __shfl_xor(lb, 32, 64);
+        lb = xor16_sum(lb);
+        lb = xor32_sum(lb);
         l = l * alpha + lb;
         m = mnew;
 #pragma unroll
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(64 * NW) void full_bwd_a_mfma_kernel(const bf16_t* 
             for (int e = 0; e < 4; ++e)
                 dl += bf16_bits_to_f32(a[e] & 0xffffu) * bf16_bits_to_f32(c[e] & 0xffffu) + bf16_bits_to_f32(a[e] >> 16) * bf16_bits_to_f32(c[e] >> 16);
         }
-        dl += __shfl_xor(dl, 16, 64);
-        dl += __shfl_xor(dl, 32, 64);
+        dl = xor16_sum(dl);
+        dl = xor32_sum(dl);
         const float ls = nv ? lse[(int64_t)bh * N + nc] : 0.f;
         // transposed copy of this query tile for the table-gradient MFMA: Qtt[d][fr]
 #pragma unroll

@@ -203,8 +203,8 @@ __global__ __launch_bounds__(64 * NW, 2) void v3_fwd_kernel(const bf16_t* __rest
                 }
             }
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = xor16_max(m);
+        m = xor32_max(m);
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KTMAX; ++kt)
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(64 * NW, 2) void v3_fwd_kernel(const bf16_t* __rest
                 s[kt][r] = p;
                 l += p;
             }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor16_sum(l);
+        l = xor32_sum(l);
         f32x4_t oa[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_a_kernel(const bf16_t* __restr
                     dl += bf16_bits_to_f32(a[e] & 0xffffu) * bf16_bits_to_f32(c[e] & 0xffffu) + bf16_bits_to_f32(a[e] >> 16) * bf16_bits_to_f32(c[e] >> 16);
             }
         }
-        dl += __shfl_xor(dl, 16, 64);
-        dl += __shfl_xor(dl, 32, 64);
+        dl = xor16_sum(dl);
+        dl = xor32_sum(dl);
         v3_bias_rows(g, RhI, RwI, qf, xr, y, fr, gq, ahi, alo);
 
         // d(qs)^T = K^T.dS^T (+ table terms below); row / column sums of dS^T = gradients of the bias rows

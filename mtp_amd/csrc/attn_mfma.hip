@@ -228,8 +228,8 @@ __global__ __launch_bounds__(64) void rvsa_fwd_mfma_kernel(const bf16_t* __restr
                 s[kt][qt][r] = v;
                 m = fmaxf(m, v);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = xor16_max(m);
+        m = xor32_max(m);
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(64) void rvsa_fwd_mfma_kernel(const bf16_t* __restr
                 s[kt][qt][r] = p;
                 l += p;
             }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor16_sum(l);
+        l = xor32_sum(l);
         inv[qt] = 1.0f / l;
         if (gq == 0 && n < 49) lse[(int64_t)blockIdx.x * 49 + n] = m + __logf(l);
 #pragma unroll
@@ -584,8 +584,8 @@ __global__ __launch_bounds__(64) void rvsa_bwd_mfma_kernel(const bf16_t* __restr
                     }
                     dot = tok >= 0 ? dot : 0.f;
                 }
-                dot += __shfl_xor(dot, 16, 64);
-                dot += __shfl_xor(dot, 32, 64);
+                dot = xor16_sum(dot);
+                dot = xor32_sum(dot);
                 const int dx = k & 1, dy = k >> 1;
                 dix += dot * (dy ? fy : 1.0f - fy) * (dx ? 1.0f : -1.0f);
                 diy += dot * (dx ? fx : 1.0f - fx) * (dy ? 1.0f : -1.0f);

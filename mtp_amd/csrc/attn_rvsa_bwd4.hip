@@ -262,9 +262,9 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 dl += bf16_bits_to_f32(aw[e] & 0xffffu) * bf16_bits_to_f32(cw[e] & 0xffffu) + bf16_bits_to_f32(aw[e] >> 16) * bf16_bits_to_f32(cw[e] >> 16);
-            dl += __shfl_xor(dl, 1, 64);
-            dl += __shfl_xor(dl, 2, 64);
-            dl += __shfl_xor(dl, 4, 64);
+            dl += lane_xor<1>(dl);
+            dl += lane_xor<2>(dl);
+            dl += lane_xor<4>(dl);
             if (ch == 0) {
                 delta[key] = qtok[gi] >= 0 ? dl : 0.f;
                 lses[key] = key < 49 ? lse[(int64_t)blockIdx.x * 49 + key] : 0.f;
@@ -516,9 +516,9 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                     dot += dk[2 * e] * bf16_bits_to_f32(kw[e] & 0xffffu) + dk[2 * e + 1] * bf16_bits_to_f32(kw[e] >> 16)
                          + dv[2 * e] * bf16_bits_to_f32(vw[e] & 0xffffu) + dv[2 * e + 1] * bf16_bits_to_f32(vw[e] >> 16);
                 dot = live[gi][k] ? dot : 0.f;
-                dot += __shfl_xor(dot, 1, 64);
-                dot += __shfl_xor(dot, 2, 64);
-                dot += __shfl_xor(dot, 4, 64);
+                dot += lane_xor<1>(dot);
+                dot += lane_xor<2>(dot);
+                dot += lane_xor<4>(dot);
                 const int dx = k & 1, dy = k >> 1;
                 dix += dot * (dy ? fy : 1.0f - fy) * (dx ? 1.0f : -1.0f);
                 diy += dot * (dx ? fx : 1.0f - fx) * (dy ? 1.0f : -1.0f);

@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
             s[kt][r] = v;
             m = fmaxf(m, v);
         }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = xor16_max(m);
+    m = xor32_max(m);
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
             s[kt][r] = p;
             l += p;
         }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xor16_sum(l);
+    l = xor32_sum(l);
     if (gq == 0 && n < 49) lse[(int64_t)blockIdx.x * 49 + n] = m + __logf(l);
     f32x4_t oa[4];
 #pragma unroll

@@ -122,15 +122,54 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
 }
 
-// wave-wide reductions over 64 lanes
+// ---- lane exchanges without the LDS crossbar (round 5; probed in round 4: tools/dpp_probe.hip, profiles/r04_dpp_probe.txt) --------------------
+// hipcc turns every __shfl_xor into ds_bpermute_b32: an LDS instruction and an LDS round trip on the dependent chain (312 clocks per dependent 16-lane
+// butterfly against 88 with DPP).  The partners lane ^ 1 / 2 / 4 / 8 sit inside a 16-lane row and are reachable with DPP modifiers (xor 1, 2, 3 =
+// quad_perm; xor 7 = row_half_mirror; xor 15 = row_mirror; xor 4 = 7 o 3, xor 8 = 15 o 7); lane ^ 16 and lane ^ 32 cross rows: v_permlane16_swap /
+// v_permlane32_swap of a register with itself leave the pair (even rows | odd rows) resp. (lower half | upper half) replicated in both results, so the
+// SUM / MAX with the partner is one swap and one add / max -- the same two operands as v + v[lane ^ 16], hence the same bits.
+// ONLY where every lane of the wave is active (a DPP / permlane read of a disabled lane does not return that lane's register as ds_bpermute does):
+// every call site is straight-line code behind wave-uniform control flow (audit: tools/ablation/README.md, round 4).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) {   // v[lane ^ M], M = 1, 2, 4, 8
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8, "in-row partners only");
+    if constexpr (M == 1) return dpp_mov<0xB1>(v);
+    else if constexpr (M == 2) return dpp_mov<0x4E>(v);
+    else if constexpr (M == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));
+    else return dpp_mov<0x141>(dpp_mov<0x140>(v));
+}
+__device__ __forceinline__ float xor16_sum(float v) {   // v + v[lane ^ 16]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {   // v + v[lane ^ 32]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// over the four lanes that share (lane & 15): the MFMA layout's "same row, the four 4-column groups" reductions of the attention kernels
+__device__ __forceinline__ float rows_sum(float v) { return xor32_sum(xor16_sum(v)); }
+__device__ __forceinline__ float rows_max(float v) { return xor32_max(xor16_max(v)); }
+// wave-wide reductions over 64 lanes (same order of additions as the __shfl_xor butterflies 32, 16, 8, 4, 2, 1 they replace)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = xor32_sum(v); v = xor16_sum(v);
+    v += lane_xor<8>(v); v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = xor32_max(v); v = xor16_max(v);
+    v = fmaxf(v, lane_xor<8>(v)); v = fmaxf(v, lane_xor<4>(v)); v = fmaxf(v, lane_xor<2>(v)); v = fmaxf(v, lane_xor<1>(v));
     return v;
 }
 
