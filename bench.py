@@ -131,6 +131,47 @@ def cpu_baseline(model, seconds_budget=25.0):
                        % (model, B, n, threads, cores))
 
 
+def parse_rccl_log(path):
+    """what RCCL reported about itself in its NCCL_DEBUG=INFO log (rank 0): version, channel count, the algorithm / protocol names it mentions for the
+    collectives of the run, the transports of its rings.  A tolerant line scan -- the log format is RCCL's, not ours; absent keys stay None."""
+    import re
+    info = dict(version=None, channels=None, algorithms=[], protocols=[], transports=[], collective_lines=0, log_lines=0)
+    try:
+        lines = open(path, errors="replace").read().splitlines()
+    except OSError:
+        return None
+    info["log_lines"] = len(lines)
+    chans = set()
+    for ln in lines:
+        m = re.search(r"(?:RCCL|NCCL) version ([\w.+-]+)", ln)
+        if m and not info["version"]:
+            info["version"] = m.group(1)
+        m = re.search(r"Channel (\d+)[/ :]", ln)
+        if m:
+            chans.add(int(m.group(1)))
+        m = re.search(r"(\d+) coll channels", ln)
+        if m:
+            info["channels"] = int(m.group(1))
+        m = re.search(r"nChannels (\d+)", ln)
+        if m and info["channels"] is None:
+            info["channels"] = int(m.group(1))
+        for a in ("Ring", "Tree", "CollNet", "NVLS", "PAT"):
+            if re.search(r"\b(?:Algo|algo|algorithm)\b.*\b%s\b" % a, ln) or re.search(r"\b%s\b.*\b(?:LL128|LL|Simple)\b" % a, ln):
+                if a not in info["algorithms"]:
+                    info["algorithms"].append(a)
+        for pr in ("LL128", "LL", "Simple"):
+            if (re.search(r"(?:Proto|proto|protocol)\W+%s\b" % pr, ln) or re.search(r"\b(?:Ring|Tree|CollNet|NVLS|PAT)\b\W+%s\b" % pr, ln)) and pr not in info["protocols"]:
+                info["protocols"].append(pr)
+        for tr in ("P2P/IPC", "P2P/direct", "SHM", "NET/", "XGMI", "via P2P"):
+            if tr in ln and tr not in info["transports"]:
+                info["transports"].append(tr)
+        if "AllReduce" in ln or "ReduceScatter" in ln or "AllGather" in ln:
+            info["collective_lines"] += 1
+    if info["channels"] is None and chans:
+        info["channels"] = max(chans) + 1
+    return info
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -313,6 +354,24 @@ def _traffic_from_profiles(dom):
     return pmc[dom + "_kernel"]["hbm_bytes_per_launch"], "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, csrc hash %s, commit %s)" % (rel, sha, pmc.get("_commit", "?"))
 
 
+def _hbm_fractions_from_profiles():
+    """per-kernel rate against the 8 TB/s HBM peak for the HBM-bound kernels of this workload, from the committed table of
+    tools/hbm_fractions.py (rocprofv3 single-stream kernel statistics joined with the PMC passes) -- quoted only when it was taken at the kernel sources
+    that are running, like `traffic`"""
+    import glob
+    from tools.pmc_hbm import csrc_sha
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_fractions.json")))
+    if not files:
+        return None
+    tab = json.load(open(files[-1]))
+    rel = os.path.relpath(files[-1], ROOT)
+    if tab.get("_csrc_sha") != csrc_sha():
+        return "%s was taken at other kernel sources (csrc hash %s): not quoted" % (rel, tab.get("_csrc_sha", "none"))
+    return dict(source=rel, peak_TBps=tab["peak_TBps"], unit="TB/s on the algorithmic bytes of one launch",
+                kernels={k: dict(us=v["us_per_launch"], TBps=v["TBps"], frac=v["frac"], counter_over_algorithmic=(round(v["counter_bytes"] / v["algorithmic_bytes"], 2) if v.get("counter_bytes") else None))
+                         for k, v in tab["kernels"].items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,7 +448,14 @@ def main():
         BackboneEngine.wgrad_max_jobs = InternEngine.wgrad_max_jobs = args.wgrad_max_jobs
     import torch.distributed as dist
     force_comm = os.environ.get("MTP_FORCE_COMM") == "1"     # debugging aid: run the RCCL path on a single GPU
+    rccl_log = None
     if world > 1 or force_comm:
+        if "NCCL_DEBUG" not in os.environ:      # what RCCL chose (algorithm / protocol / channels) goes into `comm.rccl`: rank 0's INFO log, parsed after the run
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), "mtp_rccl_%d.%d.log" % (os.getpid(), rank))
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,COLL,GRAPH,TUNING"
+            os.environ["NCCL_DEBUG_FILE"] = rccl_log
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -488,29 +554,39 @@ def main():
         sampler.start()
     t0 = time.perf_counter()
     timed_steps = 0
-    # Instrumented steps alternate: the first (third, ...) runs every launch on the one compute stream, so that the events around a GEMM launch time
-    # that kernel alone -- `roofline`; the second (fourth, ...) runs as every other step does, the weight-gradient bursts on their side stream, where a
-    # data-gradient GEMM shares the CUs with weight-gradient tiles and its events measure the pair -- `roofline.concurrent`.
+    # Instrumented steps INSIDE the timed region (every --timer-every-th) run exactly as every other step does -- the weight-gradient bursts on their side
+    # stream, where a data-gradient GEMM shares the CUs with weight-gradient tiles and its events measure the pair: `roofline.concurrent`.  The steps behind
+    # `roofline` proper run every launch on the one compute stream, so that the events around a GEMM launch time that kernel alone; they change how the step
+    # runs and therefore come AFTER the timed region (the timed loop used to mix the two and flip a class attribute mid-run).
     eng_cls = type(trainer.engine)
     side_default = getattr(eng_cls, "wgrad_side_stream", False)
     conc_steps = 0
     for i in range(args.steps):
         timer.on = (not args.no_gemm_timer) and i % max(1, args.timer_every) == 0
         if timer.on:
-            k = (timed_steps + conc_steps) % 2 if side_default else 0
-            timer.use(k)
-            if k == 0:
-                eng_cls.wgrad_side_stream = False
-                timed_steps += 1
-            else:
+            timer.use(1 if side_default else 0)
+            if side_default:
                 conc_steps += 1
+            else:
+                timed_steps += 1
         loss = trainer.step(img, loss_and_grads)
-        if timer.on:
-            eng_cls.wgrad_side_stream = side_default
     sync()
     dt = time.perf_counter() - t0
     clocks = sampler.stop() if sampler is not None else None
     timer.on = False
+    if side_default and not args.no_gemm_timer:
+        n_inst = max(2, args.steps // max(1, args.timer_every))
+        eng_cls.wgrad_side_stream = False
+        try:
+            timer.on = True
+            timer.use(0)
+            for _ in range(n_inst):
+                trainer.step(img, loss_and_grads)
+            sync()
+            timed_steps = n_inst
+        finally:
+            eng_cls.wgrad_side_stream = side_default
+            timer.on = False
     tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -543,7 +619,8 @@ def main():
         red.active = True
         ms_nocomm = float(tnc.item()) / args.steps * 1e3
         busf = 2.0 * (world - 1) / world if world > 1 else 1.0
-        comm = dict(ranks=dist.get_world_size(), backend=dist.get_backend(), collectives_per_step=ncoll, bytes_per_step=int(nbytes),
+        rccl = parse_rccl_log(rccl_log) if (rank == 0 and rccl_log) else None
+        comm = dict(ranks=dist.get_world_size(), backend=dist.get_backend(), collectives_per_step=ncoll, bytes_per_step=int(nbytes), exposed_ms=round(ms - ms_nocomm, 3), rccl=rccl,
                     wire_bytes_per_step=int(wire), exchange=red.describe(),
                     allreduce_ms_per_step=round(secs * 1e3, 3), bus_GBps=round(wire * busf / max(secs, 1e-9) / 1e9, 1),
                     xgmi_peak_GBps=7 * 153, ms_per_step_without_comm=round(ms_nocomm, 3), exposed_comm_ms=round(ms - ms_nocomm, 3),
@@ -615,6 +692,8 @@ def main():
                         flops_per_launch=round(d["flops"] / d["launches"]),
                         avg_launch_us=round(d["seconds"] / d["launches"] * 1e6, 1), launches_per_step=d["launches"] // max(1, timed_steps),
                         instrumented_steps=timed_steps,
+                        instrumented_where=("steps run right after the timed region with every launch on ONE stream (a launch's events then time that kernel alone); "
+                                            "`concurrent` = events of steps inside the timed region, run as all timed steps are") if side_default else "inside the timed region",
                         families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / max(1, timed_steps) * 1e3, 2))
                                   for k, v in fams.items()})
             if conc_steps:
@@ -626,6 +705,17 @@ def main():
                     families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / conc_steps * 1e3, 2),
                                       avg_launch_us=round(v["seconds"] / v["launches"] * 1e6, 1)) for k, v in fc.items()})
         gf = FWD_GF_PER_IMAGE.get(args.model, 0.0) * 3.0
+        step_frac = round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if (args.image_size == 224 and gf and args.precision == "bf16") else None
+        if roof is not None:
+            # the number north_star targets (>= 0.70): the whole step's algorithmic flops (389.9 GF per image: forward + dgrad + wgrad of every dense contraction) over
+            # the measured step time, against the dense bf16 MFMA peak -- `frac` above is the dominant kernel family alone
+            roof["step_frac"] = step_frac
+            roof["step_flops_per_image"] = gf * 1e9 if gf else None
+            if args.model == "vit_l" and args.precision == "bf16" and B == 64 and args.image_size == 224:
+                try:
+                    roof["hbm_bound_kernels"] = _hbm_fractions_from_profiles()
+                except Exception as e:
+                    roof["hbm_bound_kernels"] = "unreadable: %s" % e
         label = {"vit_l": "ViT-L + RVSA", "vit_b": "ViT-B + RVSA", "internimage_xl": "InternImage-XL (DCNv3)"}[args.model]
         out = {
             "metric": ("images/sec pretrain step (ViT-L+RVSA, %d^2, bf16)" if args.model == "vit_l" else "images/sec pretrain step (ViT-B+RVSA, %d^2)" if args.model == "vit_b"
@@ -643,7 +733,7 @@ def main():
                        "heads": ("3 stand-in task heads (per-map 1x1 projection + mean each; the mm* decoders are not vendored)" if args.heads == "standin3"
                                  else "1 stand-in segmentation head (per-map 1x1 projection to 7 classes + per-pixel cross-entropy vs fixed random labels, torch autograd; "
                                       "mmseg's UperNet is not vendored)" if args.heads == "standin_seg" else "sum_i mean(f_i)")},
-            "step_mfma_frac": round(value / world * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4) if (args.image_size == 224 and gf) else None,
+            "step_mfma_frac": step_frac,
             "roofline": roof,
         }
         if clocks is not None:

@@ -1115,7 +1115,8 @@ extern "C" int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, c
 
 // 0.4: round 4 -- mtp_gemm_args as of round 3 (workspace / workspace_bytes trailing fields; now ignored: the stream-K form is gone),
 // mtp_gemm_tn_grouped honours split_k / aux.  Bump whenever a struct in include/mtp_hip.h changes size or a field changes meaning.
-extern "C" const char* mtp_version(void) { return "mtp_hip 0.4 (gfx950)"; }
+// 0.5: round 5 -- no struct changed; mtp_gemm_args.variant gained bits 17 / 18 (strip kernel) and 19 (grouped TN: plain phases), mtp_gemm_nt_tile may answer 64.
+extern "C" const char* mtp_version(void) { return "mtp_hip 0.5 (gfx950)"; }
 
 // A stream of the LOWEST priority the device offers (non-blocking), for work that is off the critical path and should only take the CUs
 // the main stream leaves idle: the grouped weight-gradient launches next to under-filled data-gradient GEMMs (engine_intern.py).

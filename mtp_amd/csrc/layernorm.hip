@@ -244,6 +244,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_res_bwd_kernel(const float* __r
                                                                const float* __restrict__ ls, const float* __restrict__ sample_scale, int rows_per_sample,
                                                                Th* __restrict__ dh, float* __restrict__ part, int64_t rows, int C) {
     __shared__ float4 red[3][3][64 * MV];   // [dgamma | dbeta | dls] of waves 1..3 -> wave 0
+    // MV = 8 (C up to 2048: InternImage-XL's 1536-channel level) makes this 72 KiB of STATIC LDS -- above the 64 KiB most targets allow, inside gfx950's
+    // 160 KiB (the only target of this library), and two such workgroups still share a CU
+    static_assert(sizeof(float4) * 3 * 3 * 64 * MV <= 80 * 1024, "ln_res_bwd_kernel: two workgroups per CU need <= 80 KiB of LDS each (gfx950: 160 KiB per CU)");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
     float4 gacc[MV], bacc[MV], lacc[MV], g[MV], bt[MV], lv[MV];

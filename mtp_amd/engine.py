@@ -127,6 +127,11 @@ class BackboneEngine:
     def _wgrad_stream(self):
         if not self.wgrad_side_stream:
             return None
+        import mtp_amd
+        note = mtp_amd.hw_queue_note()        # once per process: the side stream needs a hardware queue of its own (mtp_amd/__init__.py)
+        if note:
+            import warnings
+            warnings.warn(note, RuntimeWarning, stacklevel=2)
         if int(self.wgrad_side_stream) == 2:      # a stream of the device's lowest priority
             return ops.low_priority_stream(self.dev)
         st = getattr(self, "_wstream", None)

@@ -104,3 +104,31 @@ def test_grouped_weight_gradient_planning():
     assert ops.grouped_splits(50176, 64) == 4                                                    # ViT FPN, second deconvolution: 4 x 64 tiles = one round
     assert ops.grouped_splits(131072, 1) == 32 and ops.grouped_splits(32768, 4) == 8           # InternImage levels 0 / 1
     assert ops.grouped_splits(524288, 1) == 64                                                   # the stem: capped
+
+
+def test_rccl_log_parser_and_report_order():
+    """`comm.rccl` is a tolerant scan of rank 0's NCCL_DEBUG=INFO log (what RCCL chose: channels, algorithm, protocol, transport); and the passes behind
+    the `comm` object (timed collectives, the same steps without them) and behind `roofline` (single-stream instrumented steps) run AFTER the timed region
+    whose time `value` is computed from -- they cannot change it (VERDICT r04 next #8, ADVICE r04 #1)"""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    with tempfile.NamedTemporaryFile("w", suffix=".log", delete=False) as f:
+        f.write("h:1:1 [0] NCCL INFO RCCL version 2.22.3+hip7.0\n"
+                "h:1:2 [0] NCCL INFO Channel 00/16 : 0 1 2 3 4 5 6 7\nh:1:2 [0] NCCL INFO Channel 15/16 : 0 1 2 3 4 5 6 7\n"
+                "h:1:2 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via P2P/IPC\n"
+                "h:1:2 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels\n"
+                "h:1:2 [0] NCCL INFO AllReduce: 209715200 Bytes -> Algo 1 proto 2 time 0.1 Ring Simple\n")
+    info = b.parse_rccl_log(f.name)
+    os.unlink(f.name)
+    assert info["version"].startswith("2.22") and info["channels"] == 16 and info["algorithms"] == ["Ring"] and info["protocols"] == ["Simple"]
+    assert "P2P/IPC" in info["transports"] and info["collective_lines"] == 1
+    assert b.parse_rccl_log("/nonexistent/file") is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    i_value = main.index("value = world * B * args.steps / dt")
+    assert i_value < main.index("red.timing, red.timed = True, []") and i_value < main.index("forward_only = None")
+    assert main.index("dt = time.perf_counter() - t0") < main.index("eng_cls.wgrad_side_stream = False")     # the attribute is only touched after the timed region ...
+    assert "finally:\n            eng_cls.wgrad_side_stream = side_default" in main                             # ... and always restored

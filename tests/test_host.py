@@ -237,3 +237,24 @@ def test_import_sets_the_hardware_queue_count_unless_the_user_did():
     assert out.returncode == 0 and out.stdout.strip() == "8", out.stderr[-500:]
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "4", out.stderr[-500:]
+
+
+def test_hw_queue_note_is_given_once_and_only_when_the_setting_cannot_work(monkeypatch):
+    """`import mtp_amd` sets GPU_MAX_HW_QUEUES=8 for the process; when that cannot have worked (HIP initialised earlier, or a smaller value from
+    the environment) the engines say so once instead of silently running the side stream on the compute stream's queue"""
+    import mtp_amd
+    monkeypatch.setattr(mtp_amd, "_warned_hwq", False)
+    monkeypatch.setattr(mtp_amd, "_HIP_INIT_BEFORE_IMPORT", False)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert mtp_amd.hw_queue_note() is None
+    monkeypatch.setattr(mtp_amd, "_warned_hwq", False)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    note = mtp_amd.hw_queue_note()
+    assert note and "GPU_MAX_HW_QUEUES=4" in note
+    assert mtp_amd.hw_queue_note() is None                       # once per process
+    monkeypatch.setattr(mtp_amd, "_warned_hwq", False)
+    monkeypatch.setattr(mtp_amd, "_HIP_INIT_BEFORE_IMPORT", True)
+    monkeypatch.setattr(mtp_amd, "_HWQ_BEFORE_IMPORT", None)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert "before `import mtp_amd`" in mtp_amd.hw_queue_note()
+    assert mtp_amd.__version__.startswith("0.5")
