@@ -354,6 +354,59 @@ def _traffic_from_profiles(dom):
     return pmc[dom + "_kernel"]["hbm_bytes_per_launch"], "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, csrc hash %s, commit %s)" % (rel, sha, pmc.get("_commit", "?"))
 
 
+def make_loss_and_grads(heads, chans, device="cuda"):
+    """the loss that stands in for the task decoders and the cotangents of the four maps it hands to the backbone's backward (`--heads`).
+    Returns f(feats) -> (loss, [d loss / d f_i]); tests/test_hip_backbone.py checks every variant's cotangents against torch autograd on the same maps."""
+    if heads == "standin3":
+        # Three STAND-IN task heads (semantic segmentation / instance segmentation / rotated detection of models.py:112-179, 329-335,
+        # which call mmseg / mmdet / mmrotate decoders that are not vendored): head t scores every pixel of every map with its own
+        # 1x1 projection w[t][i] (C -> 1) and averages -- three consumers of the four maps with their own parameters and a
+        # per-channel cotangent, nothing more.  Labelled as stand-ins in `config`.
+        gh = torch.Generator(device=device).manual_seed(7)
+        head_w = [[torch.randn(c, device=device, generator=gh) / c ** 0.5 for c in chans] for _ in range(3)]
+
+        def loss_and_grads(feats):
+            loss, grads = 0.0, []
+            for i, f in enumerate(feats):
+                wsum = head_w[0][i] + head_w[1][i] + head_w[2][i]
+                pix = f.shape[0] * f.shape[2] * f.shape[3]
+                loss = loss + (f.sum(dim=(0, 2, 3), dtype=torch.float32) * wsum).sum() / pix
+                grads.append((wsum / pix).to(f.dtype).view(1, -1, 1, 1).expand_as(f).contiguous())
+            return loss, grads
+        loss_and_grads.head_w = head_w
+        return loss_and_grads
+    if heads == "standin_seg":
+        # ONE stand-in segmentation head (the UperNet decoder of FT/Semantic_Segmentation/configs/mtp/loveda/*.py lives in un-vendored mmseg): every map gets
+        # its own 1x1 projection to 7 classes (LoveDA) and a per-pixel cross-entropy against fixed random labels at its own resolution; the cotangents
+        # of the maps come from torch autograd, so -- unlike `mean` -- they differ from pixel to pixel.  Labelled as a stand-in in `config`.
+        gh = torch.Generator(device=device).manual_seed(11)
+        seg = {}
+
+        def loss_and_grads(feats):
+            loss, leaves = 0.0, []
+            for i, f in enumerate(feats):
+                if i not in seg:
+                    c = f.shape[1]
+                    seg[i] = (torch.randn(7, c, device=device, generator=gh) / c ** 0.5,
+                              torch.randint(0, 7, (f.shape[0], f.shape[2], f.shape[3]), device=device, generator=gh))
+                w, y = seg[i]
+                fl = f.detach().requires_grad_(True)
+                logits = torch.einsum("bchw,kc->bkhw", fl.float(), w)
+                loss = loss + torch.nn.functional.cross_entropy(logits, y)
+                leaves.append(fl)
+            grads = torch.autograd.grad(loss, leaves)
+            return loss.detach(), [g.to(f.dtype).contiguous() for g, f in zip(grads, feats)]
+        loss_and_grads.seg = seg
+        return loss_and_grads
+
+    def loss_and_grads(feats):
+        # stand-in for the three task decoders: loss = sum_i mean(f_i), d loss / d f_i = 1 / numel(f_i), written out by hand
+        # (one f32-accumulating reduction + one fill per map, every step) instead of through autograd's f32 copies of the maps
+        loss = sum(f.sum(dtype=torch.float32) / f.numel() for f in feats)
+        return loss, [torch.full_like(f, 1.0 / f.numel()) for f in feats]
+    return loss_and_grads
+
+
 def _hbm_fractions_from_profiles():
     """per-kernel rate against the 8 TB/s HBM peak for the HBM-bound kernels of this workload, from the committed table of
     tools/hbm_fractions.py (rocprofv3 single-stream kernel statistics joined with the PMC passes) -- quoted only when it was taken at the kernel sources
@@ -492,50 +545,7 @@ def main():
     B = args.batch
     img = torch.randn(B, 3, args.image_size, args.image_size, device="cuda")
 
-    if args.heads == "standin3":
-        # Three STAND-IN task heads (semantic segmentation / instance segmentation / rotated detection of models.py:112-179, 329-335,
-        # which call mmseg / mmdet / mmrotate decoders that are not vendored): head t scores every pixel of every map with its own
-        # 1x1 projection w[t][i] (C -> 1) and averages -- three consumers of the four maps with their own parameters and a
-        # per-channel cotangent, nothing more.  Labelled as stand-ins in `config`.
-        gh = torch.Generator(device="cuda").manual_seed(7)
-        chans = [net.embed_dim] * 4 if hasattr(net, "embed_dim") else list(net.out_channels)      # (InternImage: 192 / 384 / 768 / 1536)
-        head_w = [[torch.randn(c, device="cuda", generator=gh) / c ** 0.5 for c in chans] for _ in range(3)]
-
-        def loss_and_grads(feats):
-            loss, grads = 0.0, []
-            for i, f in enumerate(feats):
-                wsum = head_w[0][i] + head_w[1][i] + head_w[2][i]
-                pix = f.shape[0] * f.shape[2] * f.shape[3]
-                loss = loss + (f.sum(dim=(0, 2, 3), dtype=torch.float32) * wsum).sum() / pix
-                grads.append((wsum / pix).to(f.dtype).view(1, -1, 1, 1).expand_as(f).contiguous())
-            return loss, grads
-    elif args.heads == "standin_seg":
-        # ONE stand-in segmentation head (the UperNet decoder of FT/Semantic_Segmentation/configs/mtp/loveda/*.py lives in un-vendored mmseg): every map gets
-        # its own 1x1 projection to 7 classes (LoveDA) and a per-pixel cross-entropy against fixed random labels at its own resolution; the cotangents
-        # of the maps come from torch autograd, so -- unlike `mean` -- they differ from pixel to pixel.  Labelled as a stand-in in `config`.
-        gh = torch.Generator(device="cuda").manual_seed(11)
-        seg = {}
-
-        def loss_and_grads(feats):
-            loss, leaves = 0.0, []
-            for i, f in enumerate(feats):
-                if i not in seg:
-                    c = f.shape[1]
-                    seg[i] = (torch.randn(7, c, device="cuda", generator=gh) / c ** 0.5,
-                              torch.randint(0, 7, (f.shape[0], f.shape[2], f.shape[3]), device="cuda", generator=gh))
-                w, y = seg[i]
-                fl = f.detach().requires_grad_(True)
-                logits = torch.einsum("bchw,kc->bkhw", fl.float(), w)
-                loss = loss + torch.nn.functional.cross_entropy(logits, y)
-                leaves.append(fl)
-            grads = torch.autograd.grad(loss, leaves)
-            return loss.detach(), [g.to(f.dtype).contiguous() for g, f in zip(grads, feats)]
-    else:
-        def loss_and_grads(feats):
-            # stand-in for the three task decoders: loss = sum_i mean(f_i), d loss / d f_i = 1 / numel(f_i), written out by hand
-            # (one f32-accumulating reduction + one fill per map, every step) instead of through autograd's f32 copies of the maps
-            loss = sum(f.sum(dtype=torch.float32) / f.numel() for f in feats)
-            return loss, [torch.full_like(f, 1.0 / f.numel()) for f in feats]
+    loss_and_grads = make_loss_and_grads(args.heads, [net.embed_dim] * 4 if hasattr(net, "embed_dim") else list(net.out_channels))      # (InternImage: 192 / 384 / 768 / 1536)
 
     timer = GemmTimer(ops)
     if not args.no_gemm_timer:

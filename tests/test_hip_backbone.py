@@ -147,20 +147,42 @@ def test_drop_path_training_matches_oracle_with_same_masks():
         assert rel_err(a.cpu(), b) < 1e-3
 
 
-def test_padded_resolution_512_forward_vs_oracle():
-    """512x512 input: 32x32 tokens -> RVSA pads to 35x35 (25 windows).  Window blocks only (full attention at N=1024 is
-    SURVEY 8f-4); compared against the oracle."""
+def test_padded_resolution_512_forward_and_gradients_vs_oracle():
+    """512x512 input: 32x32 tokens -> RVSA pads to 35x35 (25 windows, VIT:298-310).  Window blocks only (full attention at N=1024 is
+    SURVEY 8f-4); features, the input gradient and EVERY parameter gradient against the oracle's autograd at north_star's 1e-3 (round 5, VERDICT r04 #4b:
+    the backward of the padded geometry was covered at op level only).  Input seed 6 has no sample within 4e-5 px of a cell edge of the bilinear
+    interpolation (tests/golden/kinks.py: 6.7e-5 px over 19600 coordinates; the test asserts it)."""
+    import kinks
     net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=512, embed_dim=128, depth=4, num_heads=2, interval=5, qkv_bias=True, use_abs_pos_emb=True,
-                                       out_indices=[0, 1, 2, 3], precision="fp32", feature_dtype=torch.float32)
+                                       out_indices=[0, 1, 2, 3], precision="fp32", feature_dtype=torch.float32, drop_path_rate=0.0)
     sd = recipe.make_params({k: v.shape for k, v in net.state_dict().items() if v.dtype.is_floating_point}, seed=11)
     net.load_state_dict(sd, strict=False)
-    net = net.cuda().eval()
+    net = net.cuda().train()
     img = recipe.make_input(1, 512, 512, seed=6)
-    with torch.no_grad():
-        feats = net(img.cuda())
-    ref = O.backbone_forward(img, {k: v.cpu() for k, v in net.state_dict().items()}, 4, 2, 5, [0, 1, 2, 3])
-    for a, b in zip(feats, ref):
-        assert rel_err(a.cpu(), b) < 1e-3
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in net.state_dict().items()}
+    d, _ = kinks.min_edge_distance(img, {k: v.detach() for k, v in p.items()}, 4, 2, 5, [0, 1, 2, 3])
+    assert d >= 4e-5, d
+    x = img.cuda().requires_grad_(True)
+    feats = net(x)
+    xr = img.clone().requires_grad_(True)
+    ref = O.backbone_forward(xr, p, 4, 2, 5, [0, 1, 2, 3])
+    for i, (a, b) in enumerate(zip(feats, ref)):
+        v = rel_err(a.detach().cpu(), b.detach())
+        record_parity("vit_512_fp32_bwd", "f%d" % i, v)
+        assert v < 1e-3
+    ws = [recipe.loss_weights(f.shape, 900 + i) for i, f in enumerate(ref)]
+    sum((f * w.cuda()).sum() for f, w in zip(feats, ws)).backward()
+    sum((f * w).sum() for f, w in zip(ref, ws)).backward()
+    v = rel_err(x.grad.cpu(), xr.grad)
+    record_parity("vit_512_fp32_bwd", "dimg", v)
+    assert v < 1e-3
+    for n, q in net.named_parameters():
+        if p[n].grad is None:
+            assert q.grad is None, n
+        else:
+            v = rel_err(q.grad.cpu(), p[n].grad)
+            record_parity("vit_512_fp32_bwd", n, v)
+            assert v < 1e-3, (n, v)
 
 
 def test_full_size_roundtrip_properties_vit_l_shapes():
@@ -456,32 +478,46 @@ def test_tap_only_finetune_variant_vs_reference(golden, precision, tol):
     assert net.blocks[1].attn.qkv.weight.grad is not None and not net.blocks[0].training and net.blocks[1].training
 
 
-def test_448_pretraining_resolution_forward_and_gradients_vs_oracle():
+@pytest.mark.parametrize("seed,tol,case", [(8, 1e-3, "kink_free"), (6, 5e-3, "hard")])
+def test_448_pretraining_resolution_forward_and_gradients_vs_oracle(seed, tol, case):
     """448x448 (the resolution MTP really pretrains at): 28x28 = 784 tokens per image -> RVSA with 16 windows and
-    full attention beyond one workgroup (generic forward + three-pass backward kernels); fp32 mode vs the oracle's autograd."""
+    full attention beyond one workgroup (generic forward + three-pass backward kernels); fp32 mode vs the oracle's autograd.
+    kink_free (input seed 8: no RVSA sample within 1e-4 px of a cell edge of the bilinear interpolation, tests/golden/kinks.py -- asserted): the input
+    gradient and every parameter gradient at north_star's 1e-3, values into the parity table (VERDICT r04 #4a).  hard (input seed 6: one sample 2.4e-6 px
+    from an edge, i.e. within a few f32 ulps -- its one-sided derivative may flip): gradients at 5e-3."""
+    import kinks
     kw = dict(img_size=448, embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True, out_indices=[0, 1, 2, 3])
     net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(precision="fp32", feature_dtype=torch.float32, **kw)
     sd = recipe.make_params({k: v.shape for k, v in net.state_dict().items() if v.dtype.is_floating_point}, seed=21)
     net.load_state_dict(sd, strict=False)
     net = net.cuda().train()
-    img = recipe.make_input(1, 448, 448, seed=8)
+    img = recipe.make_input(1, 448, 448, seed=seed)
     x = img.cuda().requires_grad_(True)
     feats = net(x)
     assert [tuple(f.shape) for f in feats] == [(1, 128, 112, 112), (1, 128, 56, 56), (1, 128, 28, 28), (1, 128, 14, 14)]
     p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in net.state_dict().items()}
+    d, _ = kinks.min_edge_distance(img, {k: v.detach() for k, v in p.items()}, 4, 2, 2, [0, 1, 2, 3])
+    assert (d >= 1e-4) if case == "kink_free" else (d < 1e-5), d
+    group = "vit_448_fp32" if case == "kink_free" else "vit_448_fp32_hard"
     xr = img.clone().requires_grad_(True)
     ref = O.backbone_forward(xr, p, 4, 2, 2, [0, 1, 2, 3])
     ws = [recipe.loss_weights(f.shape, 500 + i) for i, f in enumerate(ref)]
-    for a, b in zip(feats, ref):
-        assert rel_err(a.cpu(), b) < 1e-3
+    for i, (a, b) in enumerate(zip(feats, ref)):
+        v = rel_err(a.detach().cpu(), b.detach())
+        record_parity(group, "f%d" % i, v)
+        assert v < 1e-3
     sum((f * w.cuda()).sum() for f, w in zip(feats, ws)).backward()
     sum((f * w).sum() for f, w in zip(ref, ws)).backward()
-    assert rel_err(x.grad.cpu(), xr.grad) < 5e-3
+    v = rel_err(x.grad.cpu(), xr.grad)
+    record_parity(group, "dimg", v)
+    assert v < tol
     for n, q in net.named_parameters():
         if p[n].grad is None:
             assert q.grad is None, n
         else:
-            assert rel_err(q.grad.cpu(), p[n].grad) < 5e-3, n
+            v = rel_err(q.grad.cpu(), p[n].grad)
+            record_parity(group, n, v)
+            assert v < tol, (n, v)
 
 
 def test_non_square_input_taller_rel_pos_table_through_autograd_and_trainer():
@@ -595,3 +631,45 @@ def test_weight_gradients_on_a_side_stream_give_the_same_gradients(monkeypatch):
     assert a.keys() == b.keys()
     for n in a:
         assert rel_err(b[n], a[n]) < 1e-5, n
+
+
+@pytest.mark.parametrize("heads", ["standin3", "standin_seg", "mean"])
+def test_bench_stand_in_heads_hand_the_backward_the_cotangents_of_their_loss(heads):
+    """bench.py's stand-in task heads (`--heads standin3` = BASELINE configs[1]'s three heads, `--heads standin_seg` = configs[4]'s segmentation decoder,
+    default sum of means): the cotangents they hand to the backbone's backward are the gradients of the loss they report -- checked against torch autograd on
+    the same four maps (a small backbone's real outputs), and one trainer step through each runs (VERDICT r04 missing #5)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from mtp_amd.parallel import DataParallelTrainer
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    net = build(128, 4, 2, 3, [0, 1, 2, 3], "bf16").train()
+    img = recipe.make_input(2, 224, 224, seed=3).cuda()
+    with torch.no_grad():
+        feats = [f.float() for f in net(img)]
+    fn = bench.make_loss_and_grads(heads, [128] * 4)
+    loss, grads = fn(feats)
+    leaves = [f.clone().requires_grad_(True) for f in feats]
+    if heads == "standin3":
+        ref = 0.0
+        for i, f in enumerate(leaves):
+            for t_ in range(3):                                   # three heads: each scores every pixel with its own 1x1 projection and averages
+                ref = ref + (f * fn.head_w[t_][i].view(1, -1, 1, 1)).sum(1).mean()
+    elif heads == "standin_seg":
+        ref = 0.0
+        for i, f in enumerate(leaves):
+            w, y = fn.seg[i]
+            ref = ref + torch.nn.functional.cross_entropy(torch.einsum("bchw,kc->bkhw", f, w), y)
+    else:
+        ref = sum(f.mean() for f in leaves)
+    rg = torch.autograd.grad(ref, leaves)
+    assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    for g, r, f in zip(grads, rg, feats):
+        assert g.shape == f.shape and g.is_contiguous() and rel_err(g.float().cpu(), r.cpu()) < 1e-5
+    if heads != "mean":
+        assert float(grads[0].std()) > 0        # not the constant cotangent of the default loss
+    tr = DataParallelTrainer(net, total_steps=10, feature_dtype=torch.float32)
+    l0 = tr.step(img, fn)
+    assert torch.isfinite(torch.as_tensor(float(l0)))

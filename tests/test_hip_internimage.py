@@ -315,7 +315,8 @@ def test_internimage_xl_one_step_shapes():
     assert float(dict(net.named_parameters())["levels.0.blocks.0.dcn.input_proj.weight"].grad.abs().max()) > 0
 
 
-def test_internimage_weight_gradients_on_a_side_stream_give_the_same_gradients(monkeypatch):
+@pytest.mark.parametrize("side", [True, 2])      # an ordinary side stream; InternEngine's default: a stream of the device's lowest priority (mtp_stream_create_low_priority)
+def test_internimage_weight_gradients_on_a_side_stream_give_the_same_gradients(monkeypatch, side):
     """InternEngine.wgrad_side_stream: the grouped weight-gradient launches (edge tiles, pieces, padded heads with their copy-back) go to a side stream
     next to the under-filled Linear layers of the deep levels; ordered by events, operands referenced until the main stream has waited.  Same gradients
     as the single-stream schedule (the bias-gradient by-product's f32 atomics reorder sums: 1e-5)."""
@@ -331,7 +332,7 @@ def test_internimage_weight_gradients_on_a_side_stream_give_the_same_gradients(m
         return {n: q.grad.clone() for n, q in net.named_parameters() if q.grad is not None}
     monkeypatch.setattr(InternEngine, "wgrad_side_stream", False)
     a = grads()
-    monkeypatch.setattr(InternEngine, "wgrad_side_stream", True)
+    monkeypatch.setattr(InternEngine, "wgrad_side_stream", side)
     b = grads()
     c = grads()      # a second pass: the side stream and its event bookkeeping are reused
     assert a.keys() == b.keys() == c.keys() and len(a) > 300

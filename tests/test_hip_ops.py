@@ -734,6 +734,66 @@ def test_rvsa_pool_and_small_linear(ops, dtype, Hp, Wp):
         r0 += r
 
 
+def test_batched_small_linear_wgrad_and_deferred_reductions_equal_their_unbatched_forms(ops):
+    """the batched kernels of round 4 against the one-problem launches they replace -- mtp_small_linear_dw_segments_batched (the stacked
+    sampling heads of a burst of blocks; more jobs than SL_BATCH so the flush is cut into several launches), mtp_reduce_rows_batched_f32 and the
+    column-major mtp_reduce_rows_t_batched_f32 (more buffers than REDUCE_BATCH_MAX), each with and without accumulation"""
+    R, K, heads = 256, 256, 4
+    rows = [2 * heads, 2 * heads, heads]
+    N = sum(rows)
+    njobs = ops.SL_BATCH + 3
+    refs = []
+    for j in range(njobs):
+        x, dy = dev(rnd(R, K, seed=100 + j)), dev(rnd(R, N, seed=200 + j))
+        rw = [dev(rnd(r, K, seed=300 + 7 * j + i)) for i, r in enumerate(rows)]
+        rb = [dev(rnd(r, seed=400 + 7 * j + i)) for i, r in enumerate(rows)]
+        ops.small_linear_dw_segments(x, dy, rw, rb)            # the unbatched form, accumulating into the same starting values
+        refs.append((rw, rb))
+    kept = []
+    jobs = []
+    for j in range(njobs):
+        x, dy = dev(rnd(R, K, seed=100 + j)), dev(rnd(R, N, seed=200 + j))
+        gw = [dev(rnd(r, K, seed=300 + 7 * j + i)) for i, r in enumerate(rows)]
+        gb = [dev(rnd(r, seed=400 + 7 * j + i)) for i, r in enumerate(rows)]
+        jobs.append((x, dy, gw, gb))
+        kept.append((gw, gb))
+    ops.small_linear_dw_segments_flush(jobs)
+    for (gw, gb), (rw, rb) in zip(kept, refs):
+        for a, b in zip(gw + gb, rw + rb):
+            assert rel_err(a, b) < 1e-6
+    # deferred row reductions: row-major partial buffers -> contiguous outputs
+    nbuf, prow, cols = ops.REDUCE_BATCH_MAX + 5, 37, 768
+    for acc in (False, True):
+        items, outs, refs = [], [], []
+        for i in range(nbuf):
+            part = dev(rnd(prow, cols, seed=500 + i))
+            base = rnd(cols, seed=600 + i)
+            o, r = dev(base), dev(base)
+            ops.reduce_rows(part, r, accumulate=acc)
+            items.append((part, o, acc))
+            outs.append(o)
+            refs.append(r)
+        ops.reduce_rows_deferred(items)
+        assert not items
+        for o, r in zip(outs, refs):
+            assert torch.equal(o, r)
+    # ... and the transposed form: column a * C + b of the partial rows -> out[b * R + a] (the attention kernels' per-workgroup table partials)
+    Rt, Ct = 26, 64
+    for acc in (False, True):
+        items, outs, refs = [], [], []
+        for i in range(nbuf):
+            part = rnd(prow, Rt * Ct, seed=700 + i)
+            base = rnd(Ct * Rt, seed=800 + i)
+            o = dev(base)
+            items.append((dev(part), o, acc, (Rt, Ct)))
+            outs.append(o)
+            ref = part.sum(0).view(Rt, Ct).t().contiguous().view(-1)
+            refs.append(ref + base if acc else ref)
+        ops.reduce_rows_deferred(items)
+        for o, r in zip(outs, refs):
+            assert rel_err(o.cpu(), r) < 1e-6
+
+
 @pytest.mark.parametrize("R,N,K", [(1024, 80, 1024), (37, 10, 128), (130, 5, 1100 * 4), (6, 83, 768), (67, 12, 1536), (300, 80, 256)])
 def test_small_linear_shapes(ops, R, N, K):
     """ragged rows / outputs, the ViT-L head shape, and K above the register path (generic forward kernel)"""
