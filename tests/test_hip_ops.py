@@ -787,7 +787,7 @@ def test_batched_small_linear_wgrad_and_deferred_reductions_equal_their_unbatche
         ops.reduce_rows_deferred(items)
         assert not items
         for o, r in zip(outs, refs):
-            assert torch.equal(o, r)
+            assert rel_err(o, r) < 1e-6           # (the batched kernel walks the rows in a different order: f32 rounding only)
     # ... and the transposed form: column a * C + b of the partial rows -> out[b * R + a] (the attention kernels' per-workgroup table partials)
     Rt, Ct = 26, 64
     for acc in (False, True):
