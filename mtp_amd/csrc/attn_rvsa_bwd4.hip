@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     const int64_t ld = 3 * (int64_t)C;
     const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
     const bf16_t* dob = dout + (int64_t)b * N * C + h * HD;
+    const uint32_t ld2 = (uint32_t)(6 * C);      // bytes per qkv row
 
     if (tid < 176) {
         tab[tid] = tid < 169 ? bias_table[tid * H + h] : 0.f;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     // they cost one latency each (phase timing, MTP_RVSA_STOP).
     {
         const int kl = lane >> 3, ch = lane & 7;
+        const uint32_t ch16 = (uint32_t)(16 * ch);
         uint4 kq[2][4], vq[2][4], da[2], oc[2];
         float wq[2][4];
         int qtok[2];
@@ -217,14 +219,15 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 const int tok = neighbour(g, x0, y0, fx, fy, k, w);      // (keys >= 49: x0 = -100 -> outside -> weight 0)
                 const int tc = tok >= 0 ? tok : 0;
                 wq[gi][k] = tok >= 0 ? w : 0.f;
-                kq[gi][k] = ldg16(base + C + (int64_t)tc * ld + 8 * ch);
-                vq[gi][k] = ldg16(base + 2 * C + (int64_t)tc * ld + 8 * ch);
+                const uint32_t roff = (uint32_t)tc * ld2 + ch16;      // 32-bit byte offsets off the (image, head) base: no 64-bit address arithmetic
+                kq[gi][k] = ldg16_at(base + C, roff);
+                vq[gi][k] = ldg16_at(base + 2 * C, roff);
             }
             const int n = (wave + 4 * gi) * 8 + kl;
             qtok[gi] = n < 49 ? query_token(g, n, wi, wj) : -1;
             const int tc = qtok[gi] >= 0 ? qtok[gi] : 0;
-            da[gi] = ldg16(dob + (int64_t)tc * C + 8 * ch);
-            oc[gi] = ldg16(o + ((int64_t)b * N + tc) * C + h * HD + 8 * ch);
+            da[gi] = ldg16_at(dob, (uint32_t)tc * (uint32_t)(2 * C) + ch16);
+            oc[gi] = ldg16_at(o + (int64_t)b * N * C + h * HD, (uint32_t)tc * (uint32_t)(2 * C) + ch16);
         }
         // QR = tables x Q^T of this wave's query tile, while the gather's loads are in flight
     #pragma unroll
@@ -482,6 +485,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     {   // ---- coordinate gradients: lane = (key of a group of 8, 16-B chunk): d(K_sel, V_sel)/d(ix, iy) needs the four neighbour rows
         // (all neighbour loads of the wave's two key groups issued before the first use, as in the gather)
         const int kl = lane >> 3, ch = lane & 7;
+        const uint32_t ch16 = (uint32_t)(16 * ch);
         uint4 kq[2][4], vq[2][4];
         bool live[2][4];
 #pragma unroll
@@ -495,8 +499,9 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
                 const int tok = key < 49 ? neighbour(g, x0, y0, fx, fy, k, w) : -1;
                 const int tc = tok >= 0 ? tok : 0;
                 live[gi][k] = tok >= 0;
-                kq[gi][k] = ldg16(base + C + (int64_t)tc * ld + 8 * ch);
-                vq[gi][k] = ldg16(base + 2 * C + (int64_t)tc * ld + 8 * ch);
+                const uint32_t roff = (uint32_t)tc * ld2 + ch16;      // 32-bit byte offsets off the (image, head) base: no 64-bit address arithmetic
+                kq[gi][k] = ldg16_at(base + C, roff);
+                vq[gi][k] = ldg16_at(base + 2 * C, roff);
             }
         }
 #pragma unroll

@@ -91,6 +91,19 @@ __device__ __forceinline__ uint4 ldg16(const void* p) {
 #endif
 }
 
+// 16-byte global load at a WAVE-UNIFORM base plus a 32-bit per-lane byte offset: the compiler selects `global_load_dwordx4 v, v_off, s[base]`,
+// so the per-lane address costs one 32-bit multiply-add instead of a 64-bit one (v_mad_u64_u32 + v_lshl_add_u64) -- for gathers of token rows out of
+// buffers smaller than 4 GiB (every activation of the path)
+__device__ __forceinline__ uint4 ldg16_at(const void* base, uint32_t byte_off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const u32x4_t v = *(const __attribute__((address_space(1))) u32x4_t*)((uintptr_t)base + (uintptr_t)byte_off);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + byte_off);
+#endif
+}
+
 // exact-erf GELU (nn.GELU default) and its derivative
 // erf via Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. f32-roundoff class like erff itself) -- 1 rcp + 1 exp + 5 fma
 // instead of ocml's ~35-instruction erff: the GELU / GELU' GEMM epilogues were spending ~65 us per fc1-sized launch in erff.
