@@ -102,8 +102,11 @@ class RotatedVariedSizeWindowAttention(_NoCall):
 class Block(_NoCall):
     """VIT:479-504 parameter layout."""
 
-    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, norm_layer, window_size, window, drop_path=0.0, full_rel_pos=True):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, norm_layer, window_size, window, drop_path=0.0, full_rel_pos=True, init_values=None):
         super().__init__()
+        if init_values is not None:     # layer scale (VIT:500-502); a module's own parameters precede its children's in state_dict(), as in the reference
+            self.gamma_1 = nn.Parameter(init_values * torch.ones(dim))
+            self.gamma_2 = nn.Parameter(init_values * torch.ones(dim))
         self.norm1 = norm_layer(dim)
         if window:
             self.attn = RotatedVariedSizeWindowAttention(dim, num_heads, qkv_bias, window_size[0])
@@ -180,8 +183,6 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
         super().__init__()
         if hybrid_backbone is not None:
             raise NotImplementedError("hybrid_backbone (VIT:542-574) is not part of the MTP hot path")
-        if init_values is not None:
-            raise NotImplementedError("layer-scale (init_values, VIT:500-504) is unused by MTP's factories")
         if drop_rate != 0. or attn_drop_rate != 0.:
             raise NotImplementedError("dropout is p=0 in both MTP factories (VIT:833-834)")
         if (embed_dim // num_heads) != 64:
@@ -206,7 +207,7 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
         self.blocks = nn.ModuleList([
             Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer,
                   window_size=(7, 7) if self.window_blocks[i] else self.patch_embed.patch_shape,
-                  window=self.window_blocks[i], drop_path=dpr[i], full_rel_pos=not self._vitdet)
+                  window=self.window_blocks[i], drop_path=dpr[i], full_rel_pos=not self._vitdet, init_values=init_values)
             for i in range(depth)])
         self.interval = interval
         if self.pos_embed is not None:
@@ -218,8 +219,14 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
             self.fpn2 = nn.Sequential(nn.ConvTranspose2d(embed_dim, embed_dim, kernel_size=2, stride=2))
             self.fpn3 = nn.Identity()
             self.fpn4 = nn.MaxPool2d(kernel_size=2, stride=2)
+        elif patch_size == 8:       # VIT:656-670 (unused by MTP's factories; fixture f14)
+            self.fpn1 = nn.Sequential(nn.ConvTranspose2d(embed_dim, embed_dim, kernel_size=2, stride=2))
+            self.fpn2 = nn.Identity()
+            self.fpn3 = nn.Sequential(nn.MaxPool2d(kernel_size=2, stride=2))
+            self.fpn4 = nn.Sequential(nn.MaxPool2d(kernel_size=4, stride=4))
         else:
-            raise NotImplementedError("only patch_size == 16 (both MTP factories) is implemented")
+            raise NotImplementedError("patch_size must be 16 or 8 (the reference defines no FPN tail for anything else, VIT:640-670)")
+        self.init_values = init_values
         self.apply(self._init_weights)
         self.fix_init_weight()
         self.pretrained = pretrained

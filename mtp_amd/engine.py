@@ -21,7 +21,7 @@ F32 = torch.float32
 
 class _Blk:
     """Per-block prepared weights (ACT-dtype copies, transposes) and parameter handles."""
-    __slots__ = ("window", "pre", "wqkv", "wqkvT", "wproj", "wprojT", "w1", "w1T", "w2", "w2T", "wsamp", "bsamp")
+    __slots__ = ("window", "pre", "wqkv", "wqkvT", "wproj", "wprojT", "w1", "w1T", "w2", "w2T", "wsamp", "bsamp", "bproj", "b2", "wproj_s", "w2_s")
 
 
 class BackboneEngine:
@@ -43,6 +43,7 @@ class BackboneEngine:
         self._pe = None
         self._wimg = None
         self._wimg_ptrs = None
+        self._ls = []
         self._zero_rel = {}
 
     # ------------------------------------------------------------------ parameters
@@ -65,6 +66,13 @@ class BackboneEngine:
         if self._wimg is None or ptrs != self._wimg_ptrs:
             self._build_weight_images(P)
             self._wimg_ptrs = ptrs
+        with torch.no_grad():
+            for pre, b in self._ls:       # layer scale folded into the sources of the proj / fc2 images and their biases
+                g1, g2 = P[pre + "gamma_1"].detach(), P[pre + "gamma_2"].detach()
+                torch.mul(P[pre + "attn.proj.weight"].detach(), g1[:, None], out=b.wproj_s)
+                torch.mul(P[pre + "mlp.fc2.weight"].detach(), g2[:, None], out=b.w2_s)
+                torch.mul(P[pre + "attn.proj.bias"].detach(), g1, out=b.bproj)
+                torch.mul(P[pre + "mlp.fc2.bias"].detach(), g2, out=b.b2)
         self._wimg.refresh()
         for name, (wg, wgT) in self._fpn.items():
             ops.convt_pack(P[name + ".weight"].detach().contiguous(), wg, wgT)
@@ -84,15 +92,28 @@ class BackboneEngine:
             entries.append((w2d, None if act == F32 else w, wt, False))
             return w, wt
 
+        # Layer scale (init_values, VIT:500-512): x + gamma * (W y + b) = x + (diag(gamma) W) y + gamma * b -- the factor is folded into the images of the
+        # two branch-closing projections and into their biases (f32 temporaries refreshed with the images), so the forward and the data gradients run the
+        # unscaled schedule; the weight gradients are un-folded after their launch (_layer_scale_grads).  None of MTP's factories uses it.
+        ls = getattr(self.m, "init_values", None) is not None
+        self._ls = []
+
         blks = []
         for i in range(self.depth):
             b = _Blk()
             b.window = self.window[i]
             b.pre = pre = "blocks.%d." % i
             b.wqkv, b.wqkvT = both(P[pre + "attn.qkv.weight"])
-            b.wproj, b.wprojT = both(P[pre + "attn.proj.weight"])
+            b.bproj, b.b2 = P[pre + "attn.proj.bias"].detach(), P[pre + "mlp.fc2.bias"].detach()
+            if ls:
+                b.wproj_s, b.w2_s = torch.empty_like(P[pre + "attn.proj.weight"]), torch.empty_like(P[pre + "mlp.fc2.weight"])
+                b.bproj, b.b2 = torch.empty_like(P[pre + "attn.proj.bias"]), torch.empty_like(P[pre + "mlp.fc2.bias"])
+                self._ls.append((pre, b))
+                b.wproj, b.wprojT = both(b.wproj_s)
+            else:
+                b.wproj, b.wprojT = both(P[pre + "attn.proj.weight"])
             b.w1, b.w1T = both(P[pre + "mlp.fc1.weight"])
-            b.w2, b.w2T = both(P[pre + "mlp.fc2.weight"])
+            b.w2, b.w2T = both(b.w2_s if ls else P[pre + "mlp.fc2.weight"])
             if b.window:
                 b.wsamp = torch.empty(5 * H, C, device=dev, dtype=F32)
                 b.bsamp = torch.empty(5 * H, device=dev, dtype=F32)
@@ -216,17 +237,26 @@ class BackboneEngine:
             lse = self._e(B * self.heads * N, dtype=F32)
             rel_h, rel_w = self._full_rel(pre, Hp, Wp)
             ops.full_attn_fwd(qkv, o, lse, rel_h, rel_w, B, Hp, Wp, self.heads, self.scale)
-        x1 = ops.gemm_nt(o, b.wproj, self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=P[pre + "attn.proj.bias"], res=x,
+        x1 = ops.gemm_nt(o, b.wproj, self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=b.bproj, res=x,
                          rowscale=dps[0], rows_per_sample=N)
         mean2, rstd2 = self._e(T, dtype=F32), self._e(T, dtype=F32)
         ln2 = ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], self._e(T, C), mean2, rstd2)
         u = self._e(T, 4 * C)     # gelu'(fc1 pre-activation): all the MLP backward needs of it (one multiplication in the dgrad epilogue)
         h = ops.gemm_nt(ln2, b.w1, self._e(T, 4 * C), epi=ops.EPI_BIAS_GELU_DG, bias=P[pre + "mlp.fc1.bias"], aux=u)
-        x2 = ops.gemm_nt(h, b.w2, self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=P[pre + "mlp.fc2.bias"], res=x1,
+        x2 = ops.gemm_nt(h, b.w2, self._e(T, C, dtype=F32), epi=ops.EPI_BIAS_RES, bias=b.b2, res=x1,
                          rowscale=dps[1], rows_per_sample=N)
         if save:
             s.update(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, o=o, lse=lse, x1=x1, mean2=mean2, rstd2=rstd2, ln2=ln2, u=u, h=h)
         return x2, s
+
+    def _layer_scale_grads(self, pre, lin, gname, G):
+        """un-fold the layer scale: the launch just left d/d(diag(gamma) W) in G[W] and d/d(gamma * b) in G[b] (runs on the launch's stream, right behind it):
+        d gamma = rowsum(G_W' * W) + G_b' * b;  d W = gamma (rows) * G_W';  d b = gamma * G_b'"""
+        P = self.P
+        gw, gb, gam = G[pre + lin + ".weight"], G[pre + lin + ".bias"], P[pre + gname]
+        G[pre + gname].add_((gw * P[pre + lin + ".weight"]).sum(1) + gb * P[pre + lin + ".bias"])
+        gw.mul_(gam[:, None])
+        gb.mul_(gam)
 
     # ------------------------------------------------------------------ block backward
     def _block_bwd(self, i, s, dx2, dx2_act, B, Hp, Wp, dps, G, extra, prev_scale):
@@ -239,7 +269,8 @@ class BackboneEngine:
         # (bias gradients = column sums of dY: by-product of the dW GEMM that streams dY anyway)
         # (weight gradients: queued, launched together with those of the neighbouring blocks -- ops.WgradQueue)
         wq = self._wq
-        wq.add(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], G[pre + "mlp.fc2.bias"])
+        ls = pre + "gamma_1" in G
+        wq.add(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], G[pre + "mlp.fc2.bias"], after=(lambda: self._layer_scale_grads(pre, "mlp.fc2", "gamma_2", G)) if ls else None)
         du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_MUL, aux=s["u"])
         wq.add(du, s["ln2"], G[pre + "mlp.fc1.weight"], G[pre + "mlp.fc1.bias"])
         dln2 = ops.gemm_nt(du, b.w1T, self._e(T, C))
@@ -248,7 +279,7 @@ class BackboneEngine:
         self._ln_bwd(dln2, s["x1"], s["mean2"], s["rstd2"], P[pre + "norm2.weight"], dx1, G[pre + "norm2.weight"], G[pre + "norm2.bias"],
                           dres=dx2, dx_copy=dx1_act, copy_scale=dps[0], rows_per_sample=N)
         # ---- attention branch
-        wq.add(dx1_act, s["o"], G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"])
+        wq.add(dx1_act, s["o"], G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], after=(lambda: self._layer_scale_grads(pre, "attn.proj", "gamma_1", G)) if ls else None)
         do = ops.gemm_nt(dx1_act, b.wprojT, self._e(T, C))
         dqkv = self._e(T, 3 * C)
         if b.window:
@@ -363,8 +394,23 @@ class BackboneEngine:
         P, C, T = self.P, self.C, B * Hp * Wp
         m = self.m
         feats, fctx = [], {}
+        if m.patch_size == 8:
+            # VIT:656-670: fpn1 = ConvT, fpn2 = identity, fpn3 = MaxPool 2, fpn4 = MaxPool 4 (= two 2 x 2 pools: the maximum of maxima)
+            t0 = taps[0] if self.act == F32 else ops.cast(taps[0], self._e(T, C))
+            z = ops.gemm_nt(t0, self._fpn["fpn1.0"][0], self._e(T, 4 * C), bias=P["fpn1.0.bias"], bias_mod=C)
+            feats.append(ops.tokens_to_nchw(z.view(4 * T, C), self._e(B, C, 2 * Hp, 2 * Wp, dtype=fdt), B, Hp, Wp, 1))
+            feats.append(ops.tokens_to_nchw(taps[1], self._e(B, C, Hp, Wp, dtype=fdt), B, Hp, Wp, 0))
+            H2, W2, H4, W4 = Hp // 2, Wp // 2, Hp // 4, Wp // 4
+            p3 = ops.maxpool2_tokens_fwd(taps[2], self._e(B * H2 * W2, C), B, Hp, Wp)
+            feats.append(ops.tokens_to_nchw(p3, self._e(B, C, H2, W2, dtype=fdt), B, H2, W2, 0))
+            q1 = ops.maxpool2_tokens_fwd(taps[3], self._e(B * H2 * W2, C, dtype=F32), B, Hp, Wp)
+            q2 = ops.maxpool2_tokens_fwd(q1, self._e(B * H4 * W4, C), B, H2, W2)
+            feats.append(ops.tokens_to_nchw(q2, self._e(B, C, H4, W4, dtype=fdt), B, H4, W4, 0))
+            if need_grad:
+                fctx = dict(p8=True, t0=t0, tap2=taps[2], tap3=taps[3], q1=q1)
+            return feats, fctx
         if m.patch_size != 16:
-            raise NotImplementedError("only the patch_size == 16 FPN tail (VIT:640-654) is implemented")
+            raise NotImplementedError("the reference defines the FPN tail for patch_size 16 and 8 only (VIT:640-670)")
         # fpn1: ConvT -> Norm2d -> GELU -> ConvT
         t0 = taps[0] if self.act == F32 else ops.cast(taps[0], self._e(T, C))
         y1 = ops.gemm_nt(t0, self._fpn["fpn1.0"][0], self._e(T, 4 * C), bias=P["fpn1.0.bias"], bias_mod=C)
@@ -399,6 +445,24 @@ class BackboneEngine:
         def as_in(df):
             df = df.contiguous()
             return df if df.dtype in (F32, torch.bfloat16) else df.float()
+
+        if fctx.get("p8"):       # patch_size == 8 tail: ConvT | identity | MaxPool 2 | MaxPool 4
+            H2, W2, H4, W4 = Hp // 2, Wp // 2, Hp // 4, Wp // 4
+            if dfeats[0] is not None:
+                dz = ops.nchw_to_tokens(as_in(dfeats[0]), self._e(4 * T, C), B, Hp, Wp, 1)
+                self._convt_wgrad(dz.view(T, 4 * C), fctx["t0"], G["fpn1.0.weight"])
+                self._colsum(dz, G["fpn1.0.bias"])
+                out[0] = ops.gemm_nt(dz.view(T, 4 * C), self._fpn["fpn1.0"][1], self._e(T, C, dtype=F32))
+            if dfeats[1] is not None:
+                out[1] = ops.nchw_to_tokens(as_in(dfeats[1]), self._e(T, C, dtype=F32), B, Hp, Wp, 0)
+            if dfeats[2] is not None:
+                dp = ops.nchw_to_tokens(as_in(dfeats[2]), self._e(B * H2 * W2, C, dtype=F32), B, H2, W2, 0)
+                out[2] = ops.maxpool2_tokens_bwd(fctx["tap2"], dp, self._e(T, C, dtype=F32), B, Hp, Wp)
+            if dfeats[3] is not None:
+                dq2 = ops.nchw_to_tokens(as_in(dfeats[3]), self._e(B * H4 * W4, C, dtype=F32), B, H4, W4, 0)
+                dq1 = ops.maxpool2_tokens_bwd(fctx["q1"], dq2, self._e(B * H2 * W2, C, dtype=F32), B, H2, W2)
+                out[3] = ops.maxpool2_tokens_bwd(fctx["tap3"], dq1, self._e(T, C, dtype=F32), B, Hp, Wp)
+            return out
 
         if dfeats[0] is not None:
             dy2 = ops.nchw_to_tokens(as_in(dfeats[0]), self._e(16 * T, C), B, Hp, Wp, 2)

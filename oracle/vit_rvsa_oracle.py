@@ -437,7 +437,14 @@ def nchw_to_tokens(f, B, Hp, Wp, levels):
 
 
 def fpn(taps, B, Hp, Wp, p):
-    """VIT:807-811.  taps: 4 token-major (T,C) tensors; p: dict of fpn params with reference key names."""
+    """VIT:807-811.  taps: 4 token-major (T,C) tensors; p: dict of fpn params with reference key names.
+    The patch_size == 8 tail (VIT:656-670: one ConvT, identity, MaxPool 2, MaxPool 4) is recognised by the absence of fpn1's second ConvT."""
+    if "fpn1.3.weight" not in p:
+        f1 = tokens_to_nchw(convT_tokens(taps[0], p["fpn1.0.weight"], p["fpn1.0.bias"]), B, Hp, Wp, 1)
+        f2 = tokens_to_nchw(taps[1], B, Hp, Wp, 0)
+        f3 = F.max_pool2d(tokens_to_nchw(taps[2], B, Hp, Wp, 0), 2, 2)
+        f4 = F.max_pool2d(tokens_to_nchw(taps[3], B, Hp, Wp, 0), 4, 4)
+        return [f1, f2, f3, f4]
     y = convT_tokens(taps[0], p["fpn1.0.weight"], p["fpn1.0.bias"])
     y = gelu(layernorm_fwd(y, p["fpn1.1.ln.weight"], p["fpn1.1.ln.bias"])[0])
     y = convT_tokens(y, p["fpn1.3.weight"], p["fpn1.3.bias"])
@@ -474,11 +481,15 @@ def block_forward(x, p, pre, window, B, Hp, Wp, heads, dp_scale=None):
     else:
         a, _ = full_attn_fwd(qkv, B, Hp, Wp, heads, *_full_rel_tables(p, pre, Hp, Wp, x.shape[1] // heads))
     a = a @ p[pre + "attn.proj.weight"].t() + p[pre + "attn.proj.bias"]
+    if pre + "gamma_1" in p:          # layer scale (init_values is not None, VIT:500-504, 510-512): per-channel factor on each residual branch
+        a = a * p[pre + "gamma_1"]
     if dp_scale is not None:
         a = a * dp_scale.repeat_interleave(N)[:, None]
     x = x + a
     h2 = layernorm_fwd(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"])[0]
     m = mlp(h2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+    if pre + "gamma_2" in p:
+        m = m * p[pre + "gamma_2"]
     if dp_scale is not None:
         m = m * dp_scale.repeat_interleave(N)[:, None]
     return x + m
@@ -547,9 +558,12 @@ def block_forward_parts(x, p, pre, window, B, Hp, Wp, heads):
     else:
         a, _ = full_attn_fwd(qkv, B, Hp, Wp, heads, *_full_rel_tables(p, pre, Hp, Wp, x.shape[1] // heads))
     a = a @ p[pre + "attn.proj.weight"].t() + p[pre + "attn.proj.bias"]
+    if pre + "gamma_1" in p:
+        a = a * p[pre + "gamma_1"]
 
     def fn_mlp(xm):
         h2 = layernorm_fwd(xm, p[pre + "norm2.weight"], p[pre + "norm2.bias"])[0]
-        return mlp(h2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+        m = mlp(h2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+        return m * p[pre + "gamma_2"] if pre + "gamma_2" in p else m
 
     return a, fn_mlp

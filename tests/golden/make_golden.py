@@ -500,7 +500,43 @@ def f13_hard():
     save("f13_vitl_hard.npz", **out)
 
 
+# ------------------------------------------------------------------ f14: the two remaining constructor options in one small model
+def f14():
+    """patch_size = 8 (VIT:656-670: FPN tail = ConvT | identity | MaxPool 2 | MaxPool 4) and init_values (layer scale gamma_1 / gamma_2, VIT:500-512) -- options
+    MTP's two factories do not use but the reference class accepts.  112 x 112 input -> 14 x 14 tokens; forward + every gradient, and the state-dict key order."""
+    net = quiet(ref.ViT_Win_RVSA_V3_WSZ7, img_size=112, patch_size=8, drop_path_rate=0.0, out_indices=[0, 1, 2, 3], embed_dim=128, depth=4, num_heads=2,
+                mlp_ratio=4, qkv_bias=True, use_abs_pos_emb=True, interval=2, use_rel_pos_bias=True, init_values=0.1)
+    shapes = recipe.state_shapes(128, 4, 2, 2, 112, patch_size=8, layer_scale=True)
+    sd = net.state_dict()
+    float_keys = [k for k, v in sd.items() if v.dtype.is_floating_point]
+    assert float_keys == list(shapes.keys()), (float_keys[:8], list(shapes.keys())[:8])
+    for k in float_keys:
+        assert tuple(sd[k].shape) == tuple(shapes[k]), k
+    assert abs(float(sd["blocks.0.gamma_1"][0]) - 0.1) < 1e-7          # init_values * ones
+    msg = net.load_state_dict(recipe.make_params(shapes, 2023), strict=False)
+    assert not msg.unexpected_keys and all("relative_position_index" in k for k in msg.missing_keys), msg
+    net.train()
+    img = recipe.make_input(2, 112, 112, seed=41).requires_grad_(True)
+    feats = net(img)
+    assert [tuple(f.shape) for f in feats] == [(2, 128, 28, 28), (2, 128, 14, 14), (2, 128, 7, 7), (2, 128, 3, 3)]
+    out = {"keys": np.array(float_keys)}
+    loss = 0
+    for i, f in enumerate(feats):
+        out["f%d" % i] = f
+        loss = loss + (f * recipe.loss_weights(f.shape, 800 + i)).sum()
+    loss.backward()
+    out["dimg_sum"], out["dimg_samples"] = recipe.summarize(img.grad, 2048)
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            out["nograd_" + n] = np.array([1])
+        elif p.numel() <= 4096:
+            out["g_" + n] = p.grad
+        else:
+            out["gs_%s_sum" % n], out["gs_%s_samples" % n] = recipe.summarize(p.grad, 1024)
+    save("f14_patch8_layerscale.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f13_hard"]
+    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f13_hard", "f14"]
     for w in which:
         globals()[w]()

@@ -16,15 +16,18 @@ F13_MIN_EDGE_DISTANCE = 1e-5
 F13_HARD_INPUT_SEED = 2023      # round 2's input: one sample 3.3e-6 px from an edge (fixture f13_vitl_hard.npz, looser gradient bound)
 
 
-def state_shapes(embed_dim=768, depth=12, heads=12, interval=3, img_size=224, mlp_ratio=4):
+def state_shapes(embed_dim=768, depth=12, heads=12, interval=3, img_size=224, mlp_ratio=4, patch_size=16, layer_scale=False):
     """Reference state-dict keys and shapes (float tensors only), in the reference's order
-    (checked against the reference's own state_dict() in make_golden.py -> f0_state_keys.json)."""
+    (checked against the reference's own state_dict() in make_golden.py -> f0_state_keys.json; patch_size = 8 / layer_scale: fixture f14)."""
     C, hd = embed_dim, embed_dim // heads
-    Hp = img_size // 16
-    s = {"pos_embed": (1, Hp * Hp, C), "patch_embed.proj.weight": (C, 3, 16, 16), "patch_embed.proj.bias": (C,)}
+    Hp = img_size // patch_size
+    s = {"pos_embed": (1, Hp * Hp, C), "patch_embed.proj.weight": (C, 3, patch_size, patch_size), "patch_embed.proj.bias": (C,)}
     for i in range(depth):
         p = "blocks.%d." % i
         window = (i + 1) % interval != 0
+        if layer_scale:     # a module's own parameters precede its children's in state_dict(): gamma_1 / gamma_2 (VIT:500-502) come first
+            s[p + "gamma_1"] = (C,)
+            s[p + "gamma_2"] = (C,)
         s[p + "norm1.weight"] = (C,)
         s[p + "norm1.bias"] = (C,)
         if window:
@@ -54,6 +57,8 @@ def state_shapes(embed_dim=768, depth=12, heads=12, interval=3, img_size=224, ml
     s["norm.bias"] = (C,)
     s["fpn1.0.weight"] = (C, C, 2, 2)
     s["fpn1.0.bias"] = (C,)
+    if patch_size == 8:      # VIT:656-670: fpn1 = one ConvT; fpn2 identity; fpn3 / fpn4 max pools
+        return s
     s["fpn1.1.ln.weight"] = (C,)
     s["fpn1.1.ln.bias"] = (C,)
     s["fpn1.3.weight"] = (C, C, 2, 2)
@@ -68,6 +73,8 @@ def _std_for(name):
         return None  # 1 + 0.1 N
     if "sampling_" in name:
         return 0.04
+    if name.endswith("gamma_1") or name.endswith("gamma_2"):
+        return None    # layer scale: 1 + 0.1 N (init_values * ones in the reference; randomised so that its gradient is exercised)
     if "rel_pos" in name or "relative_position_bias_table" in name:
         return 0.1     # zero at init in the reference; randomised so the branch is exercised
     if name.endswith(".bias"):

@@ -673,3 +673,37 @@ def test_bench_stand_in_heads_hand_the_backward_the_cotangents_of_their_loss(hea
     tr = DataParallelTrainer(net, total_steps=10, feature_dtype=torch.float32)
     l0 = tr.step(img, fn)
     assert torch.isfinite(torch.as_tensor(float(l0)))
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 6e-2)])
+def test_patch_size_8_and_layer_scale_vs_reference(golden, precision, tol):
+    """fixture f14 = the reference class with patch_size = 8 (FPN tail ConvT | identity | MaxPool 2 | MaxPool 4, VIT:656-670) and init_values (layer scale,
+    VIT:500-512) -- folded into the proj / fc2 weight images and un-folded in their weight gradients (engine.py): four maps, the input gradient and EVERY
+    parameter gradient, gamma_1 / gamma_2 included"""
+    g = golden("f14_patch8_layerscale.npz")
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=112, patch_size=8, drop_path_rate=0.0, out_indices=[0, 1, 2, 3], embed_dim=128, depth=4, num_heads=2, mlp_ratio=4,
+                                       qkv_bias=True, use_abs_pos_emb=True, interval=2, use_rel_pos_bias=True, init_values=0.1, precision=precision,
+                                       feature_dtype=torch.float32)
+    net.load_state_dict(recipe.make_params(recipe.state_shapes(128, 4, 2, 2, 112, patch_size=8, layer_scale=True)), strict=False)
+    net = net.cuda().train()
+    x = recipe.make_input(2, 112, 112, seed=41).cuda().requires_grad_(True)
+    feats = net(x)
+    loss = 0
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(g["f%d" % i].shape)
+        v = rel_err(f.detach().cpu(), t(g["f%d" % i]))
+        record_parity("f14_patch8_layerscale_%s" % precision, "f%d" % i, v)
+        assert v < tol, (i, v)
+        loss = loss + (f * recipe.loss_weights(f.shape, 800 + i).cuda()).sum()
+    loss.backward()
+    gtol = tol if precision == "fp32" else 0.3
+    _check_summary(x.grad, g["dimg_sum"], g["dimg_samples"], gtol, 2048, "dimg")
+    for n, q in net.named_parameters():
+        if "nograd_" + n in g:
+            assert q.grad is None, n
+        elif "g_" + n in g:
+            v = rel_err(q.grad.cpu(), t(g["g_" + n]))
+            record_parity("f14_patch8_layerscale_%s" % precision, n, v)
+            assert v < gtol, (n, v)
+        else:
+            _check_summary(q.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], gtol, 1024, n)

@@ -258,3 +258,22 @@ def test_hw_queue_note_is_given_once_and_only_when_the_setting_cannot_work(monke
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
     assert "before `import mtp_amd`" in mtp_amd.hw_queue_note()
     assert mtp_amd.__version__.startswith("0.5")
+
+
+def test_patch_size_8_and_layer_scale_state_dict_matches_the_reference(golden):
+    """the two constructor options MTP's factories do not use: same keys, order and shapes as the reference's state_dict (fixture f14),
+    init_values * ones in gamma_1 / gamma_2 (VIT:500-502), the patch-8 FPN tail's modules (VIT:656-670)"""
+    import mtp_amd
+    g = golden("f14_patch8_layerscale.npz")
+    net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=112, patch_size=8, drop_path_rate=0.0, out_indices=[0, 1, 2, 3], embed_dim=128, depth=4, num_heads=2, mlp_ratio=4,
+                                       qkv_bias=True, use_abs_pos_emb=True, interval=2, use_rel_pos_bias=True, init_values=0.1)
+    keys = [k for k, v in net.state_dict().items() if v.dtype.is_floating_point]
+    assert keys == [str(k) for k in g["keys"]]
+    shapes = recipe.state_shapes(128, 4, 2, 2, 112, patch_size=8, layer_scale=True)
+    sd = net.state_dict()
+    for k in keys:
+        assert tuple(sd[k].shape) == tuple(shapes[k]), k
+    assert torch.allclose(sd["blocks.2.gamma_2"], torch.full((128,), 0.1)) and net.patch_embed.patch_shape == (14, 14)
+    assert isinstance(net.fpn2, torch.nn.Identity) and isinstance(net.fpn4[0], torch.nn.MaxPool2d) and net.fpn4[0].kernel_size == 4
+    with pytest.raises(NotImplementedError):
+        mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=96, patch_size=32, embed_dim=128, depth=2, num_heads=2)

@@ -224,6 +224,30 @@ def test_f8_small_whole_model_fwd_and_grads(golden):
             _check_summary(v.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], 5 * TOL, 1024)
 
 
+def test_f14_patch_size_8_and_layer_scale_fwd_and_grads(golden):
+    """fixture f14 = the reference class with patch_size = 8 (FPN tail ConvT | identity | MaxPool 2 | MaxPool 4, VIT:656-670) and init_values (layer scale
+    gamma_1 / gamma_2 on the two residual branches, VIT:500-512): options MTP's factories do not use but the reference constructor accepts (VERDICT r04 next #9)"""
+    g = golden("f14_patch8_layerscale.npz")
+    shapes = recipe.state_shapes(128, 4, 2, 2, 112, patch_size=8, layer_scale=True)
+    assert list(shapes) == [str(k) for k in g["keys"]]
+    p = {k: v.requires_grad_(True) for k, v in recipe.make_params(shapes).items()}
+    img = recipe.make_input(2, 112, 112, seed=41).requires_grad_(True)
+    feats = O.backbone_forward(img, p, 4, 2, 2, [0, 1, 2, 3])
+    loss = 0
+    for i, f in enumerate(feats):
+        assert f.shape == g["f%d" % i].shape and rel_err(f, g["f%d" % i]) < TOL, i
+        loss = loss + (f * recipe.loss_weights(f.shape, 800 + i)).sum()
+    loss.backward()
+    _check_summary(img.grad, g["dimg_sum"], g["dimg_samples"], 5 * TOL, 2048)
+    for n, v in p.items():
+        if "nograd_" + n in g:
+            assert v.grad is None
+        elif "g_" + n in g:
+            assert rel_err(v.grad, g["g_" + n]) < 5 * TOL, n
+        else:
+            _check_summary(v.grad, g["gs_%s_sum" % n], g["gs_%s_samples" % n], 5 * TOL, 1024)
+
+
 def test_f9_vitdet_style_finetune_copy_fwd_and_grads(golden):
     """fixture f9 = the reference's mmdet `RVSA_MTP` (RS_Tasks_Finetune/Horizontal_Detection/mmdet/models/backbones/
     vit_rvsa_mtp.py): full attention without rel-pos, last block -> final norm -> fpn1-4 on that one map.  Every parameter
