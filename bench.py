@@ -526,7 +526,9 @@ def main():
         precision = args.precision
     torch.manual_seed(2023)    # identical initial replicas (main_pretrain.py:107)
     if args.model == "internimage_xl":
-        net = mtp_amd.internimage_xl(precision=args.precision)       # models.py:92-104 (drop_path 0.2)
+        # models.py:92-104 (drop_path 0.2).  The reference's factory checkpoints every layer (with_cp=True) to fit its 16-GB devices; like the ViT lines, the
+        # benchmark keeps the activations (288 GB of HBM) unless --use-ckpt asks for the reference's memory recipe -- `config.activation_checkpointing` says which
+        net = mtp_amd.internimage_xl(precision=args.precision, with_cp=bool(args.use_ckpt))
         with torch.no_grad():      # the zero-initialised offset / mask heads re-drawn so the sampling really deforms (as fixture f12 does)
             for n, p in net.named_parameters():
                 if ".dcn.offset.weight" in n or ".dcn.mask.weight" in n:

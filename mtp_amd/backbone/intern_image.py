@@ -11,8 +11,9 @@ Mirrors Multi-Task_Pretrain/backbone/intern_image.py ("II"):
     `layer_scale * ones`, convolutions with nn.Conv2d's default init.
 The configuration family MTP uses (models.py:92-104: norm 'LN', act 'GELU', layer_scale set, post_norm=True) is what the engine
 schedules; the InternImage-H/G options (dw_kernel_size, level2_post_norm, res_post_norm, center_feature_scale), pre-norm and
-`layer_scale=None` raise NotImplementedError instead of silently running something else.  `with_cp` (activation checkpointing)
-is accepted and ignored: it changes memory, not results.
+`layer_scale=None` raise NotImplementedError instead of silently running something else.  `with_cp` (activation checkpointing,
+II:429-430) is honoured since round 5: a layer keeps its input only and its forward is run again inside the backward (same results, bit for bit;
+2 instead of 12 saved row tensors per layer, one more forward of time) -- `internimage_xl()` sets it, as models.py:92-104 does.
 All compute runs in libmtp_hip.so (mtp_amd/engine_intern.py); there is no CPU / eager fallback.
 """
 import math

@@ -280,6 +280,7 @@ class InternEngine:
         if img.dtype not in (F32, torch.bfloat16) or not img.is_contiguous() or (self.act == F32 and img.dtype != F32):
             img = img.float().contiguous()
         save = need_grad
+        ckpt = bool(getattr(m, "with_cp", False))
         fdt = feature_dtype or self.act
         ch = m.channels
         # ---- StemLayer: conv3x3 s2 -> LN -> GELU -> conv3x3 s2 -> LN
@@ -299,7 +300,14 @@ class InternEngine:
             lctx = []
             for j in range(depth):
                 sc = (scales[2 * li], scales[2 * li + 1]) if scales is not None else None
-                x32, xa, c = self._layer_fwd("levels.%d.blocks.%d." % (i, j), x32, xa, N, Hc, Wc, C, G, sc, save)
+                if save and ckpt:
+                    # with_cp (II:429-430: checkpoint.checkpoint(_inner_forward, x)): keep the layer's input only -- two row tensors instead of twelve and
+                    # the 4C-wide GELU pair -- and run its forward again inside the backward (same drop-path factors: they are explicit tensors here)
+                    xin32, xina = x32, xa
+                    x32, xa, _ = self._layer_fwd("levels.%d.blocks.%d." % (i, j), x32, xa, N, Hc, Wc, C, G, sc, False)
+                    c = dict(ckpt=True, x32=xin32, xa=xina, sc=sc)
+                else:
+                    x32, xa, c = self._layer_fwd("levels.%d.blocks.%d." % (i, j), x32, xa, N, Hc, Wc, C, G, sc, save)
                 lctx.append(c)
                 li += 1
             if i in m.out_indices:
@@ -357,7 +365,10 @@ class InternEngine:
             if dx32 is None:      # nothing downstream of this level has a gradient
                 continue
             for j in range(len(lv["layers"]) - 1, -1, -1):
-                dx32 = self._layer_bwd("levels.%d.blocks.%d." % (i, j), lv["layers"][j], dx32, N, Hc, Wc, C, Gr, G)
+                c = lv["layers"][j]
+                if c.get("ckpt"):      # with_cp: the layer's forward once more, this time keeping what its backward needs
+                    c = self._layer_fwd("levels.%d.blocks.%d." % (i, j), c["x32"], c["xa"], N, Hc, Wc, C, Gr, c["sc"], True)[2]
+                dx32 = self._layer_bwd("levels.%d.blocks.%d." % (i, j), c, dx32, N, Hc, Wc, C, Gr, G)
                 lv["layers"][j] = None
                 # the weight gradients are queued and launched a few layers at a time (ops.WgradQueue: edge tiles for the 192- / 384-channel
                 # levels and the offset / mask heads, the contraction of the 131072- / 32768-token levels cut into pieces inside the launch);
