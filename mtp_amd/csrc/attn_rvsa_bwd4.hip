@@ -135,7 +135,7 @@ __device__ __forceinline__ void put_col_t_bits(char* img, int col, const uint4 (
 }
 
 
-constexpr int SMP_F = 10;
+constexpr int SMP_F = 18;      // per key: fx fy x0 y0 rx ry cs sn relx rely | tok[4] | w[4] (the neighbour records, one computation per key)
 
 // ===================================================================================================================
 // RVSA backward, 4 waves per (image, window, head): wave w owns query tile w in the query-major phase and key tile w in the
@@ -201,24 +201,42 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         uint4 kq[2][4], vq[2][4], da[2], oc[2];
         float wq[2][4];
         int qtok[2];
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int key = (wave + 4 * gi) * 8 + kl, kc = key < 48 ? key : 48;      // 8 groups = 64 key rows; keys >= 49 are zero rows
+        {   // ---- ONE sample computation per key (round 5): lane l < 16 of a wave owns key (wave + 4 (l >> 3)) * 8 + (l & 7) -- the 16 keys whose rows this
+            // wave gathers -- and publishes the record (position, the four neighbour tokens and weights) in `smp`; the other lanes repeat it idly (same
+            // instruction stream).  The wave reads its OWN records back (LDS operations of one wave execute in order: no block barrier), so the gather
+            // costs one sample + four neighbours per wave instruction stream instead of two + eight, and the coordinate-gradient phase recomputes nothing.
+            const int l16 = lane & 15;
+            const int key = (wave + 4 * (l16 >> 3)) * 8 + (l16 & 7), kc = key < 48 ? key : 48;
             Sample sm = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, kc / 7, kc % 7);   // (unconditional: no branch around its loads)
-            if (key >= 49) { sm.x0 = -100; sm.y0 = -100; sm.fx = 0.f; sm.fy = 0.f; }
-            if (ch == 0) {
-                smp[0 * 64 + key] = sm.fx; smp[1 * 64 + key] = sm.fy; smp[2 * 64 + key] = __int_as_float(sm.x0); smp[3 * 64 + key] = __int_as_float(sm.y0);
-                smp[4 * 64 + key] = sm.rx; smp[5 * 64 + key] = sm.ry; smp[6 * 64 + key] = sm.cs; smp[7 * 64 + key] = sm.sn;
-                smp[8 * 64 + key] = sm.relx; smp[9 * 64 + key] = sm.rely;
-            }
-            const float fx = sm.fx, fy = sm.fy;
-            const int x0 = sm.x0, y0 = sm.y0;
+            if (key >= 49) { sm.x0 = -100; sm.y0 = -100; sm.fx = 0.f; sm.fy = 0.f; }      // keys >= 49 are zero rows: every neighbour outside -> weight 0
+            float wv[4];
+            int tk[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float w;
-                const int tok = neighbour(g, x0, y0, fx, fy, k, w);      // (keys >= 49: x0 = -100 -> outside -> weight 0)
+                const int tok = neighbour(g, sm.x0, sm.y0, sm.fx, sm.fy, k, w);
+                tk[k] = tok;
+                wv[k] = tok >= 0 ? w : 0.f;
+            }
+            if (lane < 16) {
+                smp[0 * 64 + key] = sm.fx; smp[1 * 64 + key] = sm.fy; smp[2 * 64 + key] = __int_as_float(sm.x0); smp[3 * 64 + key] = __int_as_float(sm.y0);
+                smp[4 * 64 + key] = sm.rx; smp[5 * 64 + key] = sm.ry; smp[6 * 64 + key] = sm.cs; smp[7 * 64 + key] = sm.sn;
+                smp[8 * 64 + key] = sm.relx; smp[9 * 64 + key] = sm.rely;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    smp[(10 + k) * 64 + key] = __int_as_float(tk[k]);
+                    smp[(14 + k) * 64 + key] = wv[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int key = (wave + 4 * gi) * 8 + kl;      // 8 groups = 64 key rows
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int tok = __float_as_int(smp[(10 + k) * 64 + key]);
                 const int tc = tok >= 0 ? tok : 0;
-                wq[gi][k] = tok >= 0 ? w : 0.f;
+                wq[gi][k] = smp[(14 + k) * 64 + key];
                 const uint32_t roff = (uint32_t)tc * ld2 + ch16;      // 32-bit byte offsets off the (image, head) base: no 64-bit address arithmetic
                 kq[gi][k] = ldg16_at(base + C, roff);
                 vq[gi][k] = ldg16_at(base + 2 * C, roff);
@@ -490,16 +508,13 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
         bool live[2][4];
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-            const int key = (wave + 4 * gi) * 8 + kl, kc = key < 48 ? key : 48;      // keys 0 .. 63 (49 real)
-            const float fx = smp[0 * 64 + kc], fy = smp[1 * 64 + kc];
-            const int x0 = __float_as_int(smp[2 * 64 + kc]), y0 = __float_as_int(smp[3 * 64 + kc]);
+            const int key = (wave + 4 * gi) * 8 + kl;      // keys 0 .. 63 (49 real); the neighbour tokens come out of the gather's records
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float w;
-                const int tok = key < 49 ? neighbour(g, x0, y0, fx, fy, k, w) : -1;
+                const int tok = __float_as_int(smp[(10 + k) * 64 + key]);
                 const int tc = tok >= 0 ? tok : 0;
                 live[gi][k] = tok >= 0;
-                const uint32_t roff = (uint32_t)tc * ld2 + ch16;      // 32-bit byte offsets off the (image, head) base: no 64-bit address arithmetic
+                const uint32_t roff = (uint32_t)tc * ld2 + ch16;
                 kq[gi][k] = ldg16_at(base + C, roff);
                 vq[gi][k] = ldg16_at(base + 2 * C, roff);
             }

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
     __shared__ __attribute__((aligned(16))) char Vt[64 * TP];
     __shared__ float QR[26 * 64];
     __shared__ float tab[176];
+    __shared__ float rec[8 * 64];      // per key: the four neighbour tokens and weights of its bilinear sample
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, gq = lane >> 4;
     const int H = g.heads, nW = g.nh * g.nw;
     const int h = blockIdx.x % H, bw = blockIdx.x / H, b = bw / nW, win = bw % nW, wi = win / g.nw, wj = win % g.nw;
@@ -165,18 +166,40 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
         const int kl = lane >> 3, ch = lane & 7;
         uint4 kq[2][4], vq[2][4];
         float wq[2][4];
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int key = (wave + 4 * gi) * 8 + kl, kc = key < 48 ? key : 48;      // 8 groups = 64 key rows; keys >= 49 are zero rows
+        {   // ONE sample + four neighbours per key and wave instruction stream (round 5; it was two + eight: every lane its own two keys): lane l < 16 owns
+            // key (wave + 4 (l >> 3)) * 8 + (l & 7), writes the neighbour record to `rec`, and the wave reads its own records back -- LDS operations of one
+            // wave execute in order, so no barrier is involved (attn_rvsa_bwd4.hip does the same and keeps the records for its coordinate-gradient phase)
+            const int l16 = lane & 15;
+            const int key = (wave + 4 * (l16 >> 3)) * 8 + (l16 & 7), kc = key < 48 ? key : 48;
             const Sample sm = make_sample(g, samp + (int64_t)bw * 5 * H, h, wi, wj, kc / 7, kc % 7);
+            float wv[4];
+            int tk[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float w;
-                const int tok = key < 49 ? neighbour(g, sm.x0, sm.y0, sm.fx, sm.fy, k, w) : -1;
+                const int tok = key < 49 ? neighbour(g, sm.x0, sm.y0, sm.fx, sm.fy, k, w) : -1;      // keys >= 49 are zero rows
+                tk[k] = tok;
+                wv[k] = tok >= 0 ? w : 0.f;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    rec[k * 64 + key] = __int_as_float(tk[k]);
+                    rec[(4 + k) * 64 + key] = wv[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int key = (wave + 4 * gi) * 8 + kl;      // 8 groups = 64 key rows
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int tok = __float_as_int(rec[k * 64 + key]);
                 const int tc = tok >= 0 ? tok : 0;
-                wq[gi][k] = tok >= 0 ? w : 0.f;
-                kq[gi][k] = ldg16(base + C + (int64_t)tc * ld + 8 * ch);
-                vq[gi][k] = ldg16(base + 2 * C + (int64_t)tc * ld + 8 * ch);
+                wq[gi][k] = rec[(4 + k) * 64 + key];
+                const uint32_t roff = (uint32_t)tc * (uint32_t)(6 * C) + (uint32_t)(16 * ch);      // 32-bit byte offsets off the (image, head) base
+                kq[gi][k] = ldg16_at(base + C, roff);
+                vq[gi][k] = ldg16_at(base + 2 * C, roff);
             }
         }
         // QR = tables x Q^T of this wave's query tile, while the gather's loads are in flight
