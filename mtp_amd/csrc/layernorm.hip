@@ -610,9 +610,13 @@ extern "C" int mtp_reduce_rows_batched_f32(const float* const* parts, float* con
             if (e != hipSuccess) return (int)e;
         }
     const int64_t col_blocks = (C + 255) / 256;
-    int64_t splits = 1024 / col_blocks;     // as the single-buffer form (the atomics of a buffer are 1/n of the launch's)
+    // ~2048 workgroups for the WHOLE launch and at least 16 rows per thread (round 5).  Rounds 2-4 split every buffer as if it were alone (1024 / col_blocks
+    // pieces each): a burst of InternImage-XL layers (n = 32 buffers of 512 x 2304 partial rows) became 32 544 workgroups of five loads and one atomic each,
+    // 113 atomics per output element -- 77 us x 40 launches = 3.1 ms of its 57-ms step; ViT-L's bursts (n = 8, C = 2048) 8192
+    // workgroups of four rows.
+    int64_t splits = 2048 / (col_blocks * n);
+    if (splits > rows / 16) splits = rows / 16;
     if (splits < 1) splits = 1;
-    if (splits > rows) splits = rows;
     const int64_t rpb = (rows + splits - 1) / splits;
     splits = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(reduce_rows_batched_kernel, dim3((unsigned)col_blocks, (unsigned)splits, (unsigned)n), dim3(256), 0, s, t, ld, rows, C, rpb);
