@@ -12,8 +12,14 @@
 //     strips of a workgroup's XCD share their B panel in L2, so the miss traffic is that of the 256-row tiles.
 //   * the epilogue needs no LDS: two v_permlane16_swap_b32 turn the MFMA layout (lane = 4 consecutive columns of one row) into
 //     8 consecutive bf16 columns per lane (16-byte stores, 64 contiguous bytes per row and instruction); it is cut into
-//     8 (bf16 out) / 16 (f32 out) SLICES of a few dozen VALU instructions + one store, and slice s of strip i is issued in
-//     the read part of one odd phase of strip i + 1's K-tile s + 1 (s + 2 when the slice has a side input).
+//     8 (bf16 out) / 16 (f32 out) SLICES of a few dozen VALU instructions + one store, each issued in the read part of one odd
+//     phase of strip i + 1's first ten K-tiles (schedule: S8Epi::use_ktile), its side input loaded one K-tile earlier.
+// MEASURED (round 5, profiles/r05_ab_gemm_s8_strip*.txt): bit-identical to the other NT kernels on every epilogue, and 10-38 % SLOWER than the
+// 8-wave kernel on the ViT-L shapes -- a phase takes ~1100 cycles instead of ~600: the strip's read part carries 12 / 4 fragment reads and
+// three DMA pieces per wave (the 256-row tile: 8 / 4 and two), and the read part, not the matrix pipe, is what both kernels' phases wait
+// for (profiles/r05_ab_p8_loop_ablations.txt).  It WINS where the 256 x 256 tiles leave most CUs idle: problems of 40-128 tiles (ViT-B at
+// batch 32 with N = C, InternImage-XL's 768- / 1536-channel levels) run 8-19 % faster on twice as many, half as long work units, and
+// that is where mtp_gemm_nt dispatches it (gemm.hip: nt_s8_mode).
 //
 // Pipeline (same two-wave-group stagger, barriers and counted waits as gemm_p8.h; re-derived for 3 half tiles per K-tile):
 //   LDS ring = 3 K-tile buffers x { A (128 rows), B0, B1 (128 columns each: the 32-column sub-tile h of every wave column) },
