@@ -480,6 +480,11 @@ def main():
         if rank == 0:
             print(_error_line(args, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)), flush=True)
         raise SystemExit(2)
+    if rank != 0:
+        # stdout carries rank 0's ONE result line: whatever the other ranks (or the libraries under them -- RCCL prints a
+        # version banner through C stdio, flushed when the process exits) write to fd 1 goes to stderr instead
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if args.cpu_standin:
         return run_cpu_standin(args, world, rank)
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
@@ -503,7 +508,9 @@ def main():
     force_comm = os.environ.get("MTP_FORCE_COMM") == "1"     # debugging aid: run the RCCL path on a single GPU
     rccl_log = None
     if world > 1 or force_comm:
-        if "NCCL_DEBUG" not in os.environ:      # what RCCL chose (algorithm / protocol / channels) goes into `comm.rccl`: rank 0's INFO log, parsed after the run
+        # what RCCL chose (algorithm / protocol / channels) goes into `comm.rccl`: rank 0's INFO log, written to a file and parsed after the run.  The image
+        # exports NCCL_DEBUG=VERSION (round 5: that is why `rccl` was null in the first forced-comm lines); a level the user picked for a real log stays.
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION", "WARN") and os.environ.get("MTP_RCCL_LOG", "1") != "0":
             import tempfile
             rccl_log = os.path.join(tempfile.gettempdir(), "mtp_rccl_%d.%d.log" % (os.getpid(), rank))
             os.environ["NCCL_DEBUG"] = "INFO"

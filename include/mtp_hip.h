@@ -73,8 +73,8 @@ typedef struct {
                          * forbids it; bit15 / bit16 force / forbid its persistent-tile form; bits20-21 store policy of its epilogue
                          * (0 = by epilogue: nt, sc1 for the f32 residual form; 1 = nt, 2 = sc1 write-through, 3 = plain).  All variants
                          * of one problem give bit-identical results.  Bit 17 forces the strip kernel (round 5; see mtp_gemm_nt_tile), bit 18
-                         * forbids it.  (Bits 7, 11-14, 19 selected kernels that were removed in round 4 -- tools/ablation/ -- and are
-                         * ignored.) */
+                         * forbids it.  TN grouped: bit 19 = the plain phase instead of the read-ahead phase (round 5 A/B).  (Bits 7, 11-14
+                         * selected kernels that were removed in round 4 -- tools/ablation/ -- and are ignored.) */
     float* colsum;      /* TN only, optional: colsum[m] += sum_k A[k][m]  (f32, M entries, ACCUMULATES) -- the bias
                          * gradient db = sum_rows dY comes out of the dW = dY^T X GEMM that streams dY anyway  */
     int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them

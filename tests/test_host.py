@@ -223,7 +223,10 @@ def test_unsupported_configs_fail_loudly():
     with pytest.raises(NotImplementedError):
         mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=96, num_heads=2)      # head_dim != 64
     with pytest.raises(NotImplementedError):
-        mtp_amd.ViT_Win_RVSA_V3_WSZ7(init_values=0.1)
+        mtp_amd.ViT_Win_RVSA_V3_WSZ7(drop_rate=0.1)                  # dropout p > 0: neither MTP factory uses it
+    with pytest.raises(NotImplementedError):
+        mtp_amd.ViT_Win_RVSA_V3_WSZ7(patch_size=4)                   # the reference defines FPN tails for 16 and 8 only
+    mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=3, num_heads=2, interval=3, out_indices=[0, 1, 2, 2], init_values=0.1)   # accepted since round 5 (fixture f14)
 
 
 def test_import_sets_the_hardware_queue_count_unless_the_user_did():
