@@ -135,17 +135,35 @@ def parse_rccl_log(path):
     """what RCCL reported about itself in its NCCL_DEBUG=INFO log (rank 0): version, channel count, the algorithm / protocol names it mentions for the
     collectives of the run, the transports of its rings.  A tolerant line scan -- the log format is RCCL's, not ours; absent keys stay None."""
     import re
-    info = dict(version=None, channels=None, algorithms=[], protocols=[], transports=[], collective_lines=0, log_lines=0)
+    info = dict(version=None, channels=None, algorithms=[], protocols=[], transports=[], collective_lines=0, log_lines=0, tuning_lines=[])
     try:
         lines = open(path, errors="replace").read().splitlines()
     except OSError:
         return None
+    keep = os.environ.get("MTP_RCCL_LOG_COPY")      # keep the raw log next to the line (the temporary file goes with the box)
+    if keep:
+        try:
+            with open(keep, "w") as f:
+                f.write("\n".join(lines[:4000]) + "\n")
+        except OSError:
+            pass
     info["log_lines"] = len(lines)
     chans = set()
     for ln in lines:
-        m = re.search(r"(?:RCCL|NCCL) version ([\w.+-]+)", ln)
+        m = re.search(r"(?:RCCL|NCCL) version\s*:?\s*([\w.+:-]+)", ln)
         if m and not info["version"]:
             info["version"] = m.group(1)
+        m = re.search(r"Bytes -> Algo (\d+) proto (\d+)", ln)      # NCCL's TUNING line: the algorithm / protocol by number
+        if m:
+            a, pr = int(m.group(1)), int(m.group(2))
+            a = ("Tree", "Ring", "CollNetDirect", "CollNetChain", "NVLS", "NVLSTree", "PAT")[a] if a < 7 else str(a)
+            pr = ("LL", "LL128", "Simple")[pr] if pr < 3 else str(pr)
+            if a not in info["algorithms"]:
+                info["algorithms"].append(a)
+            if pr not in info["protocols"]:
+                info["protocols"].append(pr)
+            if len(info["tuning_lines"]) < 4:
+                info["tuning_lines"].append(ln[-200:])
         m = re.search(r"Channel (\d+)[/ :]", ln)
         if m:
             chans.add(int(m.group(1)))
@@ -162,13 +180,18 @@ def parse_rccl_log(path):
         for pr in ("LL128", "LL", "Simple"):
             if (re.search(r"(?:Proto|proto|protocol)\W+%s\b" % pr, ln) or re.search(r"\b(?:Ring|Tree|CollNet|NVLS|PAT)\b\W+%s\b" % pr, ln)) and pr not in info["protocols"]:
                 info["protocols"].append(pr)
-        for tr in ("P2P/IPC", "P2P/direct", "SHM", "NET/", "XGMI", "via P2P"):
-            if tr in ln and tr not in info["transports"]:
-                info["transports"].append(tr)
+        m = re.search(r" via (\S+)", ln)                          # "Channel 00 : 0[0] -> 1[1] via P2P/IPC": the transport of a ring / tree edge
+        if m and m.group(1) not in info["transports"]:
+            info["transports"].append(m.group(1))
+        m = re.search(r"\bnranks (\d+)", ln)
+        if m:
+            info["nranks"] = int(m.group(1))
         if "AllReduce" in ln or "ReduceScatter" in ln or "AllGather" in ln:
             info["collective_lines"] += 1
     if info["channels"] is None and chans:
         info["channels"] = max(chans) + 1
+    if info.get("nranks") == 1:
+        info["note"] = "one rank: RCCL copies instead of choosing an algorithm / protocol (no TUNING lines, no ring edges)"
     return info
 
 

@@ -119,10 +119,69 @@ __global__ __launch_bounds__(256) void transpose_kernel(const Tin* __restrict__ 
     }
 }
 
+// bf16 -> bf16 with S % 8 == 0 and C % 8 == 0 (round 5): a lane owns 8 consecutive elements (16 bytes) of two tile rows 32 apart, so every 128-byte line of the
+// tile is read / written by 8 lanes of ONE instruction.  (The generic kernel above gives a lane 16 elements as four 8-byte pieces 32 bytes apart: each line is
+// assembled from four partial accesses -- the same pattern cost weight_images_kernel a third of its time.)
+template <bool ROWS2COLS>
+__global__ __launch_bounds__(256) void transpose8_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int64_t S, int64_t C, int Wp, int L) {
+    __shared__ float tile[64][65];      // [channel][position]
+    const int64_t bt = blockIdx.z;
+    const int64_t s0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    const bf16_t* ib = in + bt * S * C;
+    bf16_t* ob = out + bt * S * C;
+    const int t = threadIdx.x, ra = t >> 3, cg = (t & 7) * 8;
+    float x[8];
+    if (ROWS2COLS) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t sp = s0 + ra + 32 * h;
+            if (sp < S && c0 + cg < C) {
+                load8(ib + pixel_to_row(sp, Wp, L) * C + c0 + cg, x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tile[cg + e][ra + 32 * h] = x[e];      // bank = cg + e + ra (+ 32 h): distinct over a wave
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t c = c0 + ra + 32 * h;
+            if (c < C && s0 + cg < S) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = tile[ra + 32 * h][cg + e];
+                store8(ob + c * S + s0 + cg, x);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t c = c0 + ra + 32 * h;
+            if (c < C && s0 + cg < S) {
+                load8(ib + c * S + s0 + cg, x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tile[ra + 32 * h][cg + e] = x[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t sp = s0 + ra + 32 * h;
+            if (sp < S && c0 + cg < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = tile[cg + e][ra + 32 * h];
+                store8(ob + pixel_to_row(sp, Wp, L) * C + c0 + cg, x);
+            }
+        }
+    }
+}
+
 template <bool ROWS2COLS>
 int launch_transpose(const void* in, int in_dt, void* out, int out_dt, int64_t batches, int64_t S, int64_t C, int Wp, int L, hipStream_t s) {
     if (C % 4) return MTP_ERR_ARG;
     dim3 grid((unsigned)((S + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)batches), block(256);
+    if (in_dt == MTP_BF16 && out_dt == MTP_BF16 && !(S & 7) && !(C & 7) && !(((uintptr_t)in | (uintptr_t)out) & 15)) {
+        hipLaunchKernelGGL((transpose8_bf16_kernel<ROWS2COLS>), grid, block, 0, s, (const bf16_t*)in, (bf16_t*)out, S, C, Wp, L);
+        return mtp_launch_status();
+    }
 #define MTP_TR(TI, TO) hipLaunchKernelGGL((transpose_kernel<TI, TO, ROWS2COLS>), grid, block, 0, s, (const TI*)in, (TO*)out, S, C, Wp, L)
     if (in_dt == MTP_F32 && out_dt == MTP_F32) MTP_TR(float, float);
     else if (in_dt == MTP_F32 && out_dt == MTP_BF16) MTP_TR(float, bf16_t);
@@ -639,7 +698,8 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const mtp_wimg_desc*
     const int t = threadIdx.x, a = t >> 2, g = (t & 3) * 16;
     const int64_t r = r0 + a;
     const bool f32o = d.f32_out != 0;
-    if ((d.C & 3) || (d.wt && (d.R & 3))) {   // odd-sized (tiny) matrices: element-wise
+    const int am = (f32o || sizeof(T) == 4) ? 3 : 7;     // 16-byte stores: 4 floats or 8 bf16 per lane
+    if ((d.C & am) || (d.wt && (d.R & am))) {   // odd-sized (tiny) matrices: element-wise
         for (int e = 0; e < 16; ++e) {
             const int64_t c = c0 + g + e;
             if (r < d.R && c < d.C) {
@@ -650,31 +710,50 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const mtp_wimg_desc*
         }
         return;
     }
-    float4 x[4];
+    // vector path (round 5): a lane owns 8 consecutive columns of two rows (32 apart), so a row of the tile is ONE 128-byte (bf16) line written by 8 lanes of one
+    // instruction -- and likewise a row of the transposed tile.  (Rounds 1-4: 16 columns per lane as four 8-byte bf16 stores 32 bytes apart: every line of
+    // both images was assembled from four partial writes -- 1.26 x the algorithmic bytes at the L2 boundary, 0.51 of the HBM peak.)
+    const int ra = t >> 3, cg = (t & 7) * 8;
+    float x[2][8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int64_t c = c0 + g + 4 * q;
-        const bool ok = r < d.R && c < d.C;
-        x[q] = ok ? load4(d.src + r * d.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < 2; ++h) {
+        const int64_t rr = r0 + ra + 32 * h, c = c0 + cg;
+        const bool ok = rr < d.R && c < d.C;         // (C % 4 == 0: columns c .. c + 3 are in range; c + 4 .. c + 7 checked separately)
+        const bool ok2 = ok && c + 4 < d.C;
+        const float4 v0 = ok ? load4(d.src + rr * d.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v1 = ok2 ? load4(d.src + rr * d.C + c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[h][0] = v0.x; x[h][1] = v0.y; x[h][2] = v0.z; x[h][3] = v0.w; x[h][4] = v1.x; x[h][5] = v1.y; x[h][6] = v1.z; x[h][7] = v1.w;
         if (ok && d.w) {
-            if (f32o) store4(reinterpret_cast<float*>(d.w) + r * d.C + c, x[q]);
-            else store4(reinterpret_cast<T*>(d.w) + r * d.C + c, x[q]);
+            if (ok2) {
+                if (f32o) store8(reinterpret_cast<float*>(d.w) + rr * d.C + c, x[h]);
+                else store8(reinterpret_cast<T*>(d.w) + rr * d.C + c, x[h]);
+            } else {
+                if (f32o) store4(reinterpret_cast<float*>(d.w) + rr * d.C + c, v0);
+                else store4(reinterpret_cast<T*>(d.w) + rr * d.C + c, v0);
+            }
         }
     }
     if (d.wt) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            tile[g + 4 * q + 0][a] = x[q].x; tile[g + 4 * q + 1][a] = x[q].y; tile[g + 4 * q + 2][a] = x[q].z; tile[g + 4 * q + 3][a] = x[q].w;
-        }
-        __syncthreads();
-        const int64_t c = c0 + a;   // source column = image row
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t rr = r0 + g + 4 * q;
+            for (int e = 0; e < 8; ++e) tile[cg + e][ra + 32 * h] = x[h][e];      // bank = cg + e + ra (+ 32 h): distinct over the 64 lanes
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cl = ra + 32 * h;                   // source column = image row
+            const int64_t c = c0 + cl, rr = r0 + cg;
             if (c < d.C && rr < d.R) {
-                const float4 v = make_float4(tile[a][g + 4 * q], tile[a][g + 4 * q + 1], tile[a][g + 4 * q + 2], tile[a][g + 4 * q + 3]);
-                if (f32o) store4(reinterpret_cast<float*>(d.wt) + c * d.R + rr, v);
-                else store4(reinterpret_cast<T*>(d.wt) + c * d.R + rr, v);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = tile[cl][cg + e];
+                if (rr + 4 < d.R) {
+                    if (f32o) store8(reinterpret_cast<float*>(d.wt) + c * d.R + rr, o);
+                    else store8(reinterpret_cast<T*>(d.wt) + c * d.R + rr, o);
+                } else {                                  // (R % 4 == 0)
+                    if (f32o) store4(reinterpret_cast<float*>(d.wt) + c * d.R + rr, make_float4(o[0], o[1], o[2], o[3]));
+                    else store4(reinterpret_cast<T*>(d.wt) + c * d.R + rr, make_float4(o[0], o[1], o[2], o[3]));
+                }
             }
         }
     }

@@ -611,9 +611,8 @@ extern "C" int mtp_reduce_rows_batched_f32(const float* const* parts, float* con
         }
     const int64_t col_blocks = (C + 255) / 256;
     // ~2048 workgroups for the WHOLE launch and at least 16 rows per thread (round 5).  Rounds 2-4 split every buffer as if it were alone (1024 / col_blocks
-    // pieces each): a burst of InternImage-XL layers (n = 32 buffers of 512 x 2304 partial rows) became 32 544 workgroups of five loads and one atomic each,
-    // 113 atomics per output element -- 77 us x 40 launches = 3.1 ms of its 57-ms step; ViT-L's bursts (n = 8, C = 2048) 8192
-    // workgroups of four rows.
+    // pieces each): ViT-L's bursts (n = 8 buffers of 512 x 2048 partial rows) became 8192 workgroups of four rows and one atomic each.  (The 77 us per launch
+    // the InternImage-XL traces show for this kernel are as-run durations next to the weight-gradient burst it is queued behind -- 10 us of work)
     int64_t splits = 2048 / (col_blocks * n);
     if (splits > rows / 16) splits = rows / 16;
     if (splits < 1) splits = 1;

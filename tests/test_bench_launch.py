@@ -125,6 +125,14 @@ def test_rccl_log_parser_and_report_order():
     os.unlink(f.name)
     assert info["version"].startswith("2.22") and info["channels"] == 16 and info["algorithms"] == ["Ring"] and info["protocols"] == ["Simple"]
     assert "P2P/IPC" in info["transports"] and info["collective_lines"] == 1
+    # the forms seen on the MI355X box (round 5): the banner's "RCCL version : x", and NCCL's TUNING line with the algorithm / protocol as numbers only
+    with tempfile.NamedTemporaryFile("w", suffix=".log", delete=False) as f:
+        f.write("RCCL version : 2.26.6-HEAD:64f48b6\nh:1:2 [0] NCCL INFO Channel 127/128 : 0\n"
+                "h:1:2 [0] NCCL INFO ReduceScatter: 26214400 Bytes -> Algo 1 proto 0 time 55.0\nh:1:2 [0] NCCL INFO AllReduce: 1024 Bytes -> Algo 0 proto 1 time 9.0\n")
+    info = b.parse_rccl_log(f.name)
+    os.unlink(f.name)
+    assert info["version"].startswith("2.26.6") and info["channels"] == 128 and info["algorithms"] == ["Ring", "Tree"] and info["protocols"] == ["LL", "LL128"]
+    assert len(info["tuning_lines"]) == 2
     assert b.parse_rccl_log("/nonexistent/file") is None
     src = open(os.path.join(ROOT, "bench.py")).read()
     main = src[src.index("def main():"):]

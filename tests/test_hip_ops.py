@@ -427,9 +427,15 @@ def test_weight_images_one_launch(ops, dtype):
                (dws[3], stack[:32], None, True), (dws[4], stack[32:], None, True), (dws[5], bias, None, True)]
     odd, odd_w, odd_t = rnd(6, 2, seed=7), e(6, 2), e(2, 6, dtype=dtype)          # tiny odd sizes: element-wise path
     entries += [(dev(odd), odd_w, None, True), (dev(odd), None, odd_t, False)]
+    # ragged tiles on the 16-byte path (round 5: 8 bf16 / 4 f32 per lane): rows and columns that are multiples of 8 but not of 64, and a 4-but-not-8 pair
+    extra = [rnd(200, 72, seed=8), rnd(136, 1032, seed=9), rnd(108, 196, seed=10)]
+    ximgs = [(e(*w.shape, dtype=dtype), e(w.shape[1], w.shape[0], dtype=dtype)) for w in extra]
+    entries += [(dev(w), a, at, False) for w, (a, at) in zip(extra, ximgs)]
     tab = ops.WeightImages(entries, dtype)
     tab.refresh()
     assert torch.equal(odd_w.cpu(), odd) and torch.equal(odd_t.cpu(), odd.t().contiguous().to(dtype))
+    for w, (a, at) in zip(extra, ximgs):
+        assert torch.equal(a.cpu(), w.to(dtype)) and torch.equal(at.cpu(), w.t().contiguous().to(dtype))
     for w, (a, at) in zip(ws[:3], imgs):
         if a is not None:
             assert torch.equal(a.cpu(), w.to(dtype))
@@ -572,6 +578,10 @@ def test_tokens_nchw_roundtrip(ops, dtype, L):
     x2 = rnd(3 * 5 * 4 ** L, 68)   # ragged tile edges, f32 -> f32
     f2 = ops.tokens_to_nchw(dev(x2), e(1, 68, 3 << L, 5 << L), 1, 3, 5, L)
     assert torch.equal(f2.cpu(), O.tokens_to_nchw(x2, 1, 3, 5, L))
+    x3 = rnd(2 * 4 * 6 * 4 ** L, 72, dtype=dtype)   # positions and channels multiples of 8 but not of 64: ragged tiles of the 16-byte bf16 kernel (round 5)
+    f3 = ops.tokens_to_nchw(dev(x3, dtype), e(2, 72, 4 << L, 6 << L, dtype=dtype), 2, 4, 6, L)
+    assert torch.equal(f3.float().cpu(), O.tokens_to_nchw(x3, 2, 4, 6, L))
+    assert torch.equal(ops.nchw_to_tokens(f3, e(x3.shape[0], 72, dtype=dtype), 2, 4, 6, L).float().cpu(), x3)
 
 
 @pytest.mark.parametrize("dtype", DT)
