@@ -214,6 +214,82 @@ __global__ __launch_bounds__(256) void convt_unpack_kernel(const float* __restri
     }
 }
 
+// The same two packings through a (64 ci) x (64 co) tile in LDS, two taps at a time (round 5): every global access is a whole line -- the float4 of the four taps
+// of (ci, co) on the parameter side (1 KiB per wave instruction), 8 lanes x 16 bytes per row of the images.  (The element-wise kernels above write 2-byte pieces
+// scattered over the images: 31 us for a 1024 x 1024 weight.)  Cin, Cout multiples of 8.
+template <typename T>
+__global__ __launch_bounds__(256) void convt_pack_tiled_kernel(const float* __restrict__ w, T* __restrict__ wg, T* __restrict__ wgT, int Cin, int Cout) {
+    __shared__ float tile[2][64][65];      // [tap of the pair][ci][co]
+    const int ci0 = blockIdx.y * 64, co0 = blockIdx.x * 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, ra = t >> 3, cg = (t & 7) * 8;
+    float4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int ci = ci0 + wave + 4 * k, co = co0 + lane;
+        v[k] = (ci < Cin && co < Cout) ? load4(w + ((int64_t)ci * Cout + co) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            tile[0][wave + 4 * k][lane] = half ? v[k].z : v[k].x;
+            tile[1][wave + 4 * k][lane] = half ? v[k].w : v[k].y;
+        }
+        __syncthreads();
+        float o[8];
+        if (wgT) {         // wgT[ci][q * Cout + co]: a line = (ci, q), 64 co
+            for (int l = ra; l < 128; l += 32) {
+                const int r = l >> 1, qq = l & 1, ci = ci0 + r;
+                if (ci < Cin && co0 + cg < Cout) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = tile[qq][r][cg + e];
+                    store8(wgT + (int64_t)ci * 4 * Cout + (int64_t)(2 * half + qq) * Cout + co0 + cg, o);
+                }
+            }
+        }
+        if (wg) {          // wg[q * Cout + co][ci]: a line = (q, co), 64 ci
+            for (int l = ra; l < 128; l += 32) {
+                const int qq = l >> 6, c = l & 63, co = co0 + c;
+                if (co < Cout && ci0 + cg < Cin) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = tile[qq][cg + e][c];
+                    store8(wg + ((int64_t)(2 * half + qq) * Cout + co) * Cin + ci0 + cg, o);
+                }
+            }
+        }
+    }
+}
+// dw[ci][co][q] = dwg[q * Cout + co][ci]
+__global__ __launch_bounds__(256) void convt_unpack_tiled_kernel(const float* __restrict__ dwg, float* __restrict__ dw, int Cin, int Cout) {
+    __shared__ float tile[2][64][65];      // [tap of the pair][ci][co]
+    const int ci0 = blockIdx.y * 64, co0 = blockIdx.x * 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, rb = t >> 4, c4 = (t & 15) * 4;
+    float g[16][4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        for (int l = rb; l < 128; l += 16) {       // a line = (q, co): 64 ci = 16 lanes x 16 bytes
+            const int qq = l >> 6, c = l & 63, co = co0 + c;
+            if (co < Cout && ci0 + c4 < Cin) {
+                const float4 x = load4(dwg + ((int64_t)(2 * half + qq) * Cout + co) * Cin + ci0 + c4);
+                tile[qq][c4 + 0][c] = x.x; tile[qq][c4 + 1][c] = x.y; tile[qq][c4 + 2][c] = x.z; tile[qq][c4 + 3][c] = x.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            g[k][2 * half] = tile[0][wave + 4 * k][lane];
+            g[k][2 * half + 1] = tile[1][wave + 4 * k][lane];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int ci = ci0 + wave + 4 * k, co = co0 + lane;
+        if (ci < Cin && co < Cout) store4(dw + ((int64_t)ci * Cout + co) * 4, make_float4(g[k][0], g[k][1], g[k][2], g[k][3]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ MaxPool2d(2,2) on tokens
 template <typename Tout>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, Tout* __restrict__ y, int B, int Hp, int Wp, int C) {
@@ -535,6 +611,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
 }
 
 // AdamW (torch.optim.AdamW semantics, MAIN:424-457) over a flat buffer; segments start at multiples of 4 elements.
+// (round 5: nontemporal loads / stores on all seven streams: 1660 -> 1603 us alone, no difference in the step -- profiles/r05_ab_late_adamw_nontemporal.txt; not kept)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    const int64_t* __restrict__ seg_start, const float* __restrict__ seg_wd, int nseg,
                                                    const float* __restrict__ hyper, const float* __restrict__ sqnorm, float max_norm, float grad_scale) {
@@ -771,6 +848,14 @@ extern "C" int mtp_weight_images(const mtp_wimg_desc* descs_dev, int n, int64_t 
 
 extern "C" int mtp_convt_pack(const float* w, void* wg, void* wgT, int dtype, int64_t Cin, int64_t Cout, mtp_stream_t stream) {
     if (!w || Cin <= 0 || Cout <= 0) return MTP_ERR_ARG;
+    if (!(Cin & 7) && !(Cout & 7) && Cin < (1 << 20) && Cout < (1 << 20) && (dtype == MTP_BF16 || dtype == MTP_F32)) {
+        const dim3 tg((unsigned)((Cout + 63) / 64), (unsigned)((Cin + 63) / 64));
+        if (dtype == MTP_BF16)
+            hipLaunchKernelGGL((convt_pack_tiled_kernel<bf16_t>), tg, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wg, (bf16_t*)wgT, (int)Cin, (int)Cout);
+        else
+            hipLaunchKernelGGL((convt_pack_tiled_kernel<float>), tg, dim3(256), 0, (hipStream_t)stream, w, (float*)wg, (float*)wgT, (int)Cin, (int)Cout);
+        return mtp_launch_status();
+    }
     dim3 grid(blocks_for(Cin * Cout * 4, 256, 4096)), block(256);
     if (dtype == MTP_BF16)
         hipLaunchKernelGGL((convt_pack_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, w, (bf16_t*)wg, (bf16_t*)wgT, Cin, Cout);
@@ -781,6 +866,10 @@ extern "C" int mtp_convt_pack(const float* w, void* wg, void* wgT, int dtype, in
 
 extern "C" int mtp_convt_unpack_grad(const float* dwg, float* dw, int64_t Cin, int64_t Cout, mtp_stream_t stream) {
     if (!dwg || !dw || Cin <= 0 || Cout <= 0) return MTP_ERR_ARG;
+    if (!(Cin & 7) && !(Cout & 7) && Cin < (1 << 20) && Cout < (1 << 20)) {
+        hipLaunchKernelGGL(convt_unpack_tiled_kernel, dim3((unsigned)((Cout + 63) / 64), (unsigned)((Cin + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dwg, dw, (int)Cin, (int)Cout);
+        return mtp_launch_status();
+    }
     hipLaunchKernelGGL(convt_unpack_kernel, dim3(blocks_for(Cin * Cout * 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, dwg, dw, Cin, Cout);
     return mtp_launch_status();
 }

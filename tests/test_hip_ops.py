@@ -588,16 +588,21 @@ def test_tokens_nchw_roundtrip(ops, dtype, L):
 def test_weight_packing(ops, dtype):
     w = rnd(384, 128)
     assert torch.equal(ops.transpose_cast(dev(w), e(128, 384, dtype=dtype)).cpu(), w.t().contiguous().to(dtype))
-    cw = rnd(64, 96, 2, 2, seed=3)
-    wg, wgT = e(4 * 96, 64, dtype=dtype), e(64, 4 * 96, dtype=dtype)
-    ops.convt_pack(dev(cw), wg, wgT)
-    ref = O.convT_gemm_weight(cw)
-    assert torch.equal(wg.cpu(), ref.to(dtype)) and torch.equal(wgT.cpu(), ref.t().contiguous().to(dtype))
-    dwg = rnd(4 * 96, 64, seed=4)
-    dw = ops.convt_unpack_grad(dev(dwg), e(64, 96, 2, 2))
-    wr = cw.clone().requires_grad_(True)
-    (O.convT_gemm_weight(wr) * dwg).sum().backward()
-    assert torch.equal(dw.cpu(), wr.grad)
+    # (64, 96), (136, 72), (256, 128): the tiled kernels (channels multiples of 8; ragged and whole 64 x 64 tiles); (10, 12): the element-wise ones
+    for Cin, Cout in ((64, 96), (136, 72), (256, 128), (10, 12)):
+        cw = rnd(Cin, Cout, 2, 2, seed=3)
+        wg, wgT = e(4 * Cout, Cin, dtype=dtype), e(Cin, 4 * Cout, dtype=dtype)
+        ops.convt_pack(dev(cw), wg, wgT)
+        ref = O.convT_gemm_weight(cw)
+        assert torch.equal(wg.cpu(), ref.to(dtype)) and torch.equal(wgT.cpu(), ref.t().contiguous().to(dtype)), (Cin, Cout)
+        only_t = e(Cin, 4 * Cout, dtype=dtype)
+        ops.convt_pack(dev(cw), None, only_t)
+        assert torch.equal(only_t.cpu(), ref.t().contiguous().to(dtype))
+        dwg = rnd(4 * Cout, Cin, seed=4)
+        dw = ops.convt_unpack_grad(dev(dwg), e(Cin, Cout, 2, 2))
+        wr = cw.clone().requires_grad_(True)
+        (O.convT_gemm_weight(wr) * dwg).sum().backward()
+        assert torch.equal(dw.cpu(), wr.grad), (Cin, Cout)
 
 
 @pytest.mark.parametrize("dtype", DT)
