@@ -31,7 +31,7 @@ FAMILIES = [
     ("v3_bwd_a", "v3_bwd_a_kernel", "full_v3_bwd_a", T * 3 * C * 2 + 2 * T * C * 2 + T * C * 2, "qkv + o + do + dq"),
     ("v3_bwd_b", "v3_bwd_b_kernel", "full_v3_bwd_b", T * 3 * C * 2 + T * C * 2 + 2 * T * C * 2, "qkv + do + dk|dv"),
     ("rvsa_sampling_fwd (x rows in: pooled grid + heads)", "rvsa_sampling_fwd_kernel", "rvsa_sampling_fwd", T * C * 2, "x bf16"),
-    ("transpose (token <-> NCHW layout changes of the FPN tail, per launch average)", "transpose_kernel", "transpose", None, "--"),
+    ("transpose (token <-> NCHW layout changes of the FPN tail, per launch average)", "transpose", "transpose", None, "--"),
 ]
 MFMA = [("gemm_nt (NT family: forward + data gradients)", "gemm_nt_p8_kernel", "gemm_nt_kernel"), ("gemm_tn_p8 (grouped weight gradients)", "gemm_tn_p8_kernel", "gemm_tn_kernel")]
 
