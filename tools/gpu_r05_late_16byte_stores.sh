@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (how profiles/r05_ab_late_16byte_stores.txt was taken): needs tools/_abl/libmtp_hip_prev.so = the library of commit b7f9c7c (git archive b7f9c7c mtp_amd/csrc include | tar -x -C /tmp/x && make -C /tmp/x/mtp_amd/csrc)
+if [ "$MTP_RUN_HISTORICAL" != "1" ]; then echo "tools/gpu_r05_late_16byte_stores.sh: historical record of a measurement -- see its header; set MTP_RUN_HISTORICAL=1 to run it anyway" >&2; exit 1; fi
 # round 5, late (2): 16-byte stores in weight_images_kernel and the bf16 transposes.  (1) their tests + the FPN / backbone tests that run them; (2) step A/B against the previous
 # library, interleaved; (3) one-stream kernel statistics: ViT-L (the two kernels' own times) and InternImage-XL (what reduce_rows_batched costs by itself); (4) forced-comm line with
 # RCCL's INFO log kept (comm.rccl)

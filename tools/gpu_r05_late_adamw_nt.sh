@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (how profiles/r05_ab_late_adamw_nontemporal.txt was taken): the MTP_ADAMW_NT switch existed only in the experiment's library (nontemporal loads / stores in adamw_kernel) and was removed
+if [ "$MTP_RUN_HISTORICAL" != "1" ]; then echo "tools/gpu_r05_late_adamw_nt.sh: historical record of a measurement -- see its header; set MTP_RUN_HISTORICAL=1 to run it anyway" >&2; exit 1; fi
 # round 5, late (3): AdamW with streaming (nontemporal) hints on its 28 B per parameter, same library, switch by environment; interleaved
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; O=$R/gpurun_out/r05_p; rm -rf $O; mkdir -p $O

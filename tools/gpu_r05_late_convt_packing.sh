@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (how profiles/r05_ab_late_convt_packing.txt was taken): needs tools/_abl/libmtp_hip_prev2.so = the library of commit b475aa6
+if [ "$MTP_RUN_HISTORICAL" != "1" ]; then echo "tools/gpu_r05_late_convt_packing.sh: historical record of a measurement -- see its header; set MTP_RUN_HISTORICAL=1 to run it anyway" >&2; exit 1; fi
 # round 5, late (4): tiled ConvTranspose2d weight packing / gradient unpacking.  Tests, then the step against the library of commit b475aa6, interleaved
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; O=$R/gpurun_out/r05_q; rm -rf $O; mkdir -p $O

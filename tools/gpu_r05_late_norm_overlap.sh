@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (how profiles/r05_ab_late_weight_images_norm_overlap.txt was taken): needs tools/ablation/grad_norm_overlap.patch.txt applied (MTP_NORM_OVERLAP) and tools/_abl/libmtp_hip_prev.so = the library of commit b7f9c7c
+if [ "$MTP_RUN_HISTORICAL" != "1" ]; then echo "tools/gpu_r05_late_norm_overlap.sh: historical record of a measurement -- see its header; set MTP_RUN_HISTORICAL=1 to run it anyway" >&2; exit 1; fi
 # round 5, late: (1) tests of the 16-byte weight-image stores and the overlapped gradient norm; (2) step A/B, interleaved: previous library + single-pass norm / new library +
 # single-pass norm / new library + norm in pieces; (3) InternImage-XL kernel statistics on ONE stream (what reduce_rows_batched costs by itself); (4) forced-comm line (comm.rccl)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
