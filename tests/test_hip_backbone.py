@@ -665,7 +665,7 @@ def test_bench_stand_in_heads_hand_the_backward_the_cotangents_of_their_loss(hea
     else:
         ref = sum(f.mean() for f in leaves)
     rg = torch.autograd.grad(ref, leaves)
-    assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * max(1.0, abs(float(ref.detach())))
     for g, r, f in zip(grads, rg, feats):
         assert g.shape == f.shape and g.is_contiguous() and rel_err(g.float().cpu(), r.cpu()) < 1e-5
     if heads != "mean":
