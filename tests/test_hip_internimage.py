@@ -43,7 +43,8 @@ def _l2(a, b):
 
 # ------------------------------------------------------------------------------------------------ operators
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,nchw", [(2, 20, 24, 3, 16, 2, True), (2, 13, 9, 16, 32, 2, False), (1, 8, 8, 8, 8, 1, False)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,nchw", [(2, 20, 24, 3, 16, 2, True), (2, 13, 9, 16, 32, 2, False), (1, 8, 8, 8, 8, 1, False),
+                                                         (2, 17, 15, 24, 40, 2, False), (1, 10, 6, 12, 8, 2, False)])     # (Cin % 8 == 0 in bf16: the 16-byte kernels of round 5; 12: the element-wise ones)
 def test_conv3x3_as_im2col_gemm_forward_and_gradients(dtype, N, H, W, Cin, Cout, stride, nchw):
     """Conv2d(k=3, s, p=1) = im2col3x3 + gemm_nt; weight gradient = gemm_tn + unpack; data gradient = gemm_nt + col2im3x3 --
     against torch's CPU conv2d and its autograd; NCHW f32 image source (stem) and channels-last sources"""
