@@ -194,6 +194,70 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
     store4(o, acc);
 }
 
+// bf16 input, 8 consecutive pixels of a row per lane (round 5; W % 8 == 0): the 3 x 10 input window is loaded once (30 eight-byte loads, all in flight) and the lane's 36 weights
+// as nine float4, then the ten columns are unpacked once each and accumulated into the outputs they touch -- 8.25 loads per output quad where dwconv3x3_kernel issues 45.
+// (Different summation order from the one-pixel kernel: column-major over the window instead of tap-major; both are exact to f32 rounding.)
+template <typename To, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv3x3_p8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, To* __restrict__ y,
+                                                          int H, int W, int C, int accumulate, int64_t total) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (uint32_t)total) return;
+    const uint32_t c4 = (uint32_t)C >> 2, W8 = (uint32_t)W >> 3;
+    const uint32_t grp = idx / c4;
+    const int c = 4 * (int)(idx - grp * c4);
+    const uint32_t row = grp / W8, n32 = row / (uint32_t)H;
+    const int wx0 = 8 * (int)(grp - row * W8), h = (int)(row - n32 * (uint32_t)H);
+    const int64_t n = n32;
+    float wf[36];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(w + (int64_t)c * 9 + 4 * j);      // (c % 4 == 0: 16-byte aligned)
+        wf[4 * j] = t.x; wf[4 * j + 1] = t.y; wf[4 * j + 2] = t.z; wf[4 * j + 3] = t.w;
+    }
+    uint2 raw[3][10];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int hh = h + r - 1;
+        const bool rok = hh >= 0 && hh < H;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int ww = wx0 + j - 1;
+            const bool ok = rok && ww >= 0 && ww < W;
+            const uint2 t = *reinterpret_cast<const uint2*>(x + ((n * H + (ok ? hh : h)) * W + (ok ? ww : wx0)) * C + c);      // unconditional load on a clamped address
+            raw[r][j] = ok ? t : make_uint2(0u, 0u);
+        }
+    }
+    float4 acc[8];
+    const float4 b0 = (bias && !FLIP) ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = b0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint2 t = raw[r][j];
+            const float v0 = bf16_bits_to_f32(t.x & 0xffffu), v1 = bf16_bits_to_f32(t.x >> 16), v2 = bf16_bits_to_f32(t.y & 0xffffu), v3 = bf16_bits_to_f32(t.y >> 16);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int p = j - kw;
+                if (p < 0 || p >= 8) continue;
+                const int tap = FLIP ? (2 - r) * 3 + (2 - kw) : r * 3 + kw;
+                acc[p].x += v0 * wf[tap]; acc[p].y += v1 * wf[9 + tap]; acc[p].z += v2 * wf[18 + tap]; acc[p].w += v3 * wf[27 + tap];
+            }
+        }
+    }
+    To* o = y + ((n * H + h) * W + wx0) * (int64_t)C + c;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        float4 a = acc[p];
+        if (accumulate) {
+            const float4 q = load4(o + (int64_t)p * C);
+            a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+        }
+        store4(o + (int64_t)p * C, a);
+    }
+}
+
 // weight / bias gradient partials: part[block][c * 9 + tap] = sum over the block's pixels of dy[pix][c] x[pix + tap][c],
 // part[block][9 C + c] = sum dy[pix][c].  Block = 256 threads = (64 channel quads) x (4 pixel lanes); reduced through LDS.
 template <typename T>
@@ -243,6 +307,76 @@ __global__ __launch_bounds__(256) void dwconv3x3_dw_kernel(const T* __restrict__
             const float s = (red[0][cq][i] + red[1][cq][i]) + (red[2][cq][i] + red[3][cq][i]);
             if (i < 36) out[(c + i / 9) * 9 + i % 9] = s;
             else out[9 * (int64_t)C + c + (i - 36)] = s;
+        }
+    }
+}
+
+// the same partials with P consecutive pixels of a row per step (round 5; bf16, W % P == 0, pix_per_block % P == 0): P gradient loads + the 3 x (P + 2) window -- 22 loads for
+// P = 4 pixels (the kernel above: 10 per pixel), every one in flight before the first multiply.  (P = 8 needs 256 registers: one wave per SIMD.)
+template <int P>
+__global__ __launch_bounds__(256) void dwconv3x3_dw_px_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ part,
+                                                             int H, int W, int C, int64_t pixels, int64_t pix_per_block) {
+    __shared__ float red[4][64][40];
+    const int cq = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = 4 * ((int)blockIdx.x * 64 + cq);
+    const bool cok = c < C;
+    const int cc = cok ? c : 0;
+    float acc[40];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) acc[i] = 0.f;
+    const int64_t p0 = (int64_t)blockIdx.y * pix_per_block;
+    int64_t p1 = p0 + pix_per_block;
+    p1 = p1 < pixels ? p1 : pixels;
+    for (int64_t pix = p0 + P * pl; pix < p1; pix += 4 * P) {      // (pix % P == 0 and W % P == 0: the P pixels lie in one row)
+        const int wx0 = (int)(pix % W), h = (int)((pix / W) % H);
+        uint2 gr[P], raw[3][P + 2];
+#pragma unroll
+        for (int q = 0; q < P; ++q) gr[q] = *reinterpret_cast<const uint2*>(dy + (pix + q) * C + cc);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hh = h + r - 1;
+            const bool rok = hh >= 0 && hh < H;
+#pragma unroll
+            for (int jj = 0; jj < P + 2; ++jj) {
+                const int ww = wx0 + jj - 1;
+                const bool ok = rok && ww >= 0 && ww < W;
+                const uint2 t = *reinterpret_cast<const uint2*>(x + (pix + (ok ? (int64_t)(r - 1) * W + (jj - 1) : 0)) * C + cc);
+                raw[r][jj] = ok ? t : make_uint2(0u, 0u);
+            }
+        }
+        float g[P][4];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            g[q][0] = bf16_bits_to_f32(gr[q].x & 0xffffu); g[q][1] = bf16_bits_to_f32(gr[q].x >> 16);
+            g[q][2] = bf16_bits_to_f32(gr[q].y & 0xffffu); g[q][3] = bf16_bits_to_f32(gr[q].y >> 16);
+            acc[36] += g[q][0]; acc[37] += g[q][1]; acc[38] += g[q][2]; acc[39] += g[q][3];
+        }
+#pragma unroll
+        for (int jj = 0; jj < P + 2; ++jj) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const uint2 t = raw[r][jj];
+                const float v0 = bf16_bits_to_f32(t.x & 0xffffu), v1 = bf16_bits_to_f32(t.x >> 16), v2 = bf16_bits_to_f32(t.y & 0xffffu), v3 = bf16_bits_to_f32(t.y >> 16);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int q = jj - kw;
+                    if (q < 0 || q >= P) continue;
+                    const int tap = r * 3 + kw;
+                    acc[tap] += g[q][0] * v0; acc[9 + tap] += g[q][1] * v1; acc[18 + tap] += g[q][2] * v2; acc[27 + tap] += g[q][3] * v3;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 40; ++i) red[pl][cq][i] = acc[i];
+    __syncthreads();
+    if (pl == 0 && cok) {
+        float* out = part + (int64_t)blockIdx.y * (10 * (int64_t)C);
+#pragma unroll
+        for (int i = 0; i < 40; ++i) {
+            const float sum = (red[0][cq][i] + red[1][cq][i]) + (red[2][cq][i] + red[3][cq][i]);
+            if (i < 36) out[(c + i / 9) * 9 + i % 9] = sum;
+            else out[9 * (int64_t)C + c + (i - 36)] = sum;
         }
     }
 }
@@ -445,6 +579,10 @@ extern "C" int mtp_dwconv3x3_fwd(const void* x, const float* w, const float* bia
     if (total >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;      // 32-bit index arithmetic in the kernel
     const dim3 grid(blocks_for(total)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16 && !(W & 7) && !(((uintptr_t)w | (uintptr_t)(bias ? bias : w)) & 15)) {
+        hipLaunchKernelGGL((dwconv3x3_p8_kernel<bf16_t, false>), dim3(blocks_for(total / 8)), block, 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, (int)H, (int)W, (int)C, 0, total / 8);
+        return mtp_launch_status();
+    }
     if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, bf16_t, false>), grid, block, 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, (int)H, (int)W, (int)C, 0, total);
     else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconv3x3_kernel<float, float, false>), grid, block, 0, s, (const float*)x, w, bias, (float*)y, (int)H, (int)W, (int)C, 0, total);
     else return MTP_ERR_UNSUPPORTED;
@@ -457,6 +595,10 @@ extern "C" int mtp_dwconv3x3_bwd_dx(const void* dy, int dtype, const float* w, f
     if (total >= ((int64_t)1 << 31)) return MTP_ERR_UNSUPPORTED;      // 32-bit index arithmetic in the kernel
     const dim3 grid(blocks_for(total)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16 && !(W & 7) && !((uintptr_t)w & 15)) {
+        hipLaunchKernelGGL((dwconv3x3_p8_kernel<float, true>), dim3(blocks_for(total / 8)), block, 0, s, (const bf16_t*)dy, w, (const float*)nullptr, dx, (int)H, (int)W, (int)C, accumulate, total / 8);
+        return mtp_launch_status();
+    }
     if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, float, true>), grid, block, 0, s, (const bf16_t*)dy, w, (const float*)nullptr, dx, (int)H, (int)W, (int)C, accumulate, total);
     else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconv3x3_kernel<float, float, true>), grid, block, 0, s, (const float*)dy, w, (const float*)nullptr, dx, (int)H, (int)W, (int)C, accumulate, total);
     else return MTP_ERR_UNSUPPORTED;
@@ -466,7 +608,7 @@ extern "C" int mtp_dwconv3x3_bwd_dx(const void* dy, int dtype, const float* w, f
 extern "C" int64_t mtp_dwconv3x3_bwd_dw_partial_rows(int64_t N, int64_t H, int64_t W) {
     const int64_t pixels = N * H * W;
     const int64_t nb = (pixels + 127) / 128;      // (round 4: up to 1024 workgroups; with 256 a level-0 launch had one 4-wave workgroup per CU and ran
-    return nb < 1024 ? nb : 1024;                 //  on the latency of its ten 8-byte loads per pixel)
+    return nb < 1024 ? nb : 1024;                 //  on the latency of its loads.  Round 5: 32 pixels per block measured -- no gain, four times the partial rows)
 }
 
 /* part: (mtp_dwconv3x3_bwd_dw_partial_rows, 10 C) f32 = per-block partials of [dweight (C, 9) | dbias (C)] */
@@ -476,6 +618,11 @@ extern "C" int mtp_dwconv3x3_bwd_dw(const void* dy, const void* x, int dtype, fl
     const int64_t ppb = (pixels + nb - 1) / nb;
     const dim3 grid((unsigned)((C / 4 + 63) / 64), (unsigned)nb), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16 && !(W & 3)) {      // blocks of whole 4-pixel groups (the last blocks may be empty: they write zero partials)
+        const int64_t ppb4 = (ppb + 3) / 4 * 4;
+        hipLaunchKernelGGL(dwconv3x3_dw_px_kernel<4>, grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)x, part, (int)H, (int)W, (int)C, pixels, ppb4);
+        return mtp_launch_status();
+    }
     if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconv3x3_dw_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)x, part, (int)H, (int)W, (int)C, pixels, ppb);
     else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconv3x3_dw_kernel<float>), grid, block, 0, s, (const float*)dy, (const float*)x, part, (int)H, (int)W, (int)C, pixels, ppb);
     else return MTP_ERR_UNSUPPORTED;
