@@ -358,6 +358,13 @@ const char* mtp_version(void);
  * main stream leaves idle (the reference has no counterpart: its weight gradients are ATen calls on the one autograd stream).  The caller owns the
  * handle and frees it with mtp_stream_destroy. */
 int mtp_stream_create_low_priority(mtp_stream_t* stream);
+/* A stream restricted to the CUs of a bit mask (`words` 32-bit words; gfx950, SPX: bit i = XCC i % 8, CU i / 8 of that XCC).  The two half-batch
+ * schedule runs each half of the batch on its own 128 CUs (16 of every XCC); the reference has no counterpart (one autograd stream,
+ * main_pretrain.py:508-518).  MTP_ERR_ARG for a mask that leaves an XCC without a CU.  Freed with mtp_stream_destroy. */
+int mtp_stream_create_cu_mask(const uint32_t* mask, int words, mtp_stream_t* stream);
+/* Diagnostic: one record {XCC id, HW_ID register (cu_id [11:8], sh_id [12], se_id [15:13])} per workgroup of a `blocks`-workgroup launch on
+ * `stream`, each workgroup resident for `spin_clocks` shader clocks; out = (blocks, 2) int32 in device memory. */
+int mtp_probe_placement(int32_t* out, int blocks, int64_t spin_clocks, mtp_stream_t stream);
 int mtp_stream_destroy(mtp_stream_t stream);
 
 /* ---- gradient all-reduce over RCCL (reference: DistributedDataParallel, main_pretrain.py:508-518) ------ */

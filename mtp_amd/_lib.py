@@ -118,6 +118,8 @@ SIGNATURES = {
     "mtp_adamw_flat": (i32, [p, p, p, p, i64, p, p, i32, p, p, f32, f32, p]),
     "mtp_version": (C.c_char_p, []),
     "mtp_stream_create_low_priority": (i32, [p]),
+    "mtp_stream_create_cu_mask": (i32, [p, i32, p]),
+    "mtp_probe_placement": (i32, [p, i32, i64, p]),
     "mtp_stream_destroy": (i32, [p]),
 }
 

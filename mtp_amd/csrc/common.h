@@ -203,6 +203,10 @@ static inline int mtp_optin_lds(const void* kern, int bytes, unsigned long long&
         if (!(cond)) return MTP_ERR_ARG; \
     } while (0)
 
+// CUs a stream may use: what mtp_stream_create_cu_mask registered for it (the two half-batch schedule), else every CU of the device.  The GEMM
+// dispatch sizes tiles, strips and persistent grids by it (a 128-CU stream runs M / 2 rows with the tile quantisation of M rows on 256 CUs).
+int mtp_stream_cus(hipStream_t stream);
+
 static inline int mtp_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -3,6 +3,8 @@
 // linear layers of the RVSA sampling heads, and the flat-buffer optimizer step.  All accesses are 8/16-byte vectors
 // on the contiguous dimension; transposes go through a padded LDS tile so both sides stay coalesced.
 #include "common.h"
+#include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -1300,7 +1302,87 @@ extern "C" int mtp_stream_create_low_priority(void** stream) {
     *stream = (void*)s;
     return 0;
 }
+// ---- per-stream CU budget: written when a masked stream is created / destroyed (under a mutex), read by every GEMM dispatch (lock-free scan of 16 slots)
+namespace {
+constexpr int kMaskSlots = 16;
+std::atomic<void*> g_mask_stream[kMaskSlots];
+std::atomic<int> g_mask_cus[kMaskSlots];
+std::mutex g_mask_mu;
+int device_cus() {
+    static std::atomic<int> ncu{0};
+    int n = ncu.load(std::memory_order_relaxed);
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        n = prop.multiProcessorCount;
+        ncu.store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+}  // namespace
+
+int mtp_stream_cus(hipStream_t stream) {
+    if (stream)
+        for (int i = 0; i < kMaskSlots; ++i)
+            if (g_mask_stream[i].load(std::memory_order_acquire) == (void*)stream) return g_mask_cus[i].load(std::memory_order_relaxed);
+    return device_cus();
+}
+
+// A stream whose kernels may only use the CUs named by a bit mask (hipExtStreamCreateWithCUMask): the two half-batch schedule (engine.py,
+// DESIGN section 5b) gives each half its own CUs, so that one half's HBM-bound kernels and epilogue bursts run beside the other half's K loops
+// instead of queueing behind them.  gfx950 in SPX mode: bit i of the mask = XCC (i % 8), CU (i / 8) of that XCC in the driver's
+// enumeration (checked on the hardware by mtp_probe_placement, profiles/r06_cu_mask_probe.txt).  A mask that leaves an XCC without any CU is rejected:
+// the dispatcher still hands that XCC every eighth workgroup.
+extern "C" int mtp_stream_create_cu_mask(const uint32_t* mask, int words, void** stream) {
+    if (!mask || !stream || words <= 0 || words > 32) return MTP_ERR_ARG;
+    for (int x = 0; x < 8; ++x) {
+        bool any = false;
+        for (int i = x; i < words * 32 && i < 256; i += 8) any |= (mask[i / 32] >> (i % 32)) & 1u;
+        if (!any) return MTP_ERR_ARG;
+    }
+    int cus = 0;
+    for (int i = 0; i < words * 32 && i < 256; ++i) cus += (mask[i / 32] >> (i % 32)) & 1u;
+    std::lock_guard<std::mutex> lock(g_mask_mu);
+    int slot = -1;
+    for (int i = 0; i < kMaskSlots && slot < 0; ++i)
+        if (!g_mask_stream[i].load(std::memory_order_relaxed)) slot = i;
+    if (slot < 0) return MTP_ERR_UNSUPPORTED;      // more masked streams alive than the table holds
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+    if (e != hipSuccess) return (int)e;
+    g_mask_cus[slot].store(cus, std::memory_order_relaxed);
+    g_mask_stream[slot].store((void*)s, std::memory_order_release);
+    *stream = (void*)s;
+    return 0;
+}
+
+namespace {
+// one record per workgroup: {XCC_ID, HW_ID}; every workgroup stays resident for `spin` clocks so that a launch of >= 2 workgroups per CU touches every
+// CU the stream may use
+__global__ void __launch_bounds__(256) probe_placement_kernel(int32_t* __restrict__ out, long long spin) {
+    const long long t0 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x + 0] = (int32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        out[2 * blockIdx.x + 1] = (int32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+    }
+    while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+// Where do the workgroups of a launch on `stream` run?  out: (blocks, 2) int32 = {XCC id, HW_ID register} per workgroup.
+extern "C" int mtp_probe_placement(int32_t* out, int blocks, int64_t spin_clocks, mtp_stream_t stream) {
+    if (!out || blocks <= 0 || spin_clocks < 0 || spin_clocks > (1ll << 28)) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(probe_placement_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, (long long)spin_clocks);
+    return mtp_launch_status();
+}
+
 extern "C" int mtp_stream_destroy(void* stream) {
     if (!stream) return MTP_ERR_ARG;
+    {
+        std::lock_guard<std::mutex> lock(g_mask_mu);
+        for (int i = 0; i < kMaskSlots; ++i)
+            if (g_mask_stream[i].load(std::memory_order_relaxed) == stream) g_mask_stream[i].store(nullptr, std::memory_order_release);
+    }
     return (int)hipStreamDestroy((hipStream_t)stream);
 }

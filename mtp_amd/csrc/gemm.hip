@@ -584,7 +584,7 @@ int fill_common(const mtp_gemm_args* a, KArgs& k) {
 // which NT kernel family runs a bf16 problem: 0 = the 128-wide kernels of this file, else gemm_p8.hip: 1 = tile height picked per
 // problem (256 or 224 rows), 2 = 224-row tiles, 3 = 256-row tiles.  variant bits 8-9 force 1 / 2 / 3 (when the problem fits), bit 10
 // forbids the kernel; bits 11-14 select an ablation build (tools/ab_gemm.py).
-int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k) {
+int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k, int cus) {
     if (a->in_dtype != MTP_BF16 || (a->variant & 1024) || !mtp_nt_p8_fits(k, a->out_dtype, a->epilogue)) return 0;
     const int forced = (a->variant >> 8) & 3;
     if (forced) return forced;
@@ -594,13 +594,14 @@ int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k) {
     // InternImage-XL's 768- / 1536-channel levels and of ViT-B at batch 32 (tools/ab_gemm_mid.py, round 3): 96 tiles +6 % (K = 768) /
     // +17 % (K = 3072), 75 tiles +3 % / +16 %, 48 tiles +5 % (K = 1536) / +14 % (K = 6144), but 64 tiles of which half are mostly edge
     // (N = 432, K = 768) -19 %: from 72 tiles on, or from 40 when the contraction is long.
-    const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    // (cus: the CUs of the stream, 256 unless it is CU-masked -- the thresholds are fractions of a round)
+    const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256) * 256 / cus;
     return (tiles >= 72 || (tiles >= 40 && a->K >= 1536)) ? 1 : 0;
 }
 
 // the strip kernel of gemm_s8.hip (two accumulator sets, the epilogue of a strip under the next strip's K loop): variant bit 17 forces
 // it (when the problem fits), bit 18 forbids it.
-int nt_s8_mode(const mtp_gemm_args* a, const KArgs& k) {
+int nt_s8_mode(const mtp_gemm_args* a, const KArgs& k, int cus) {
     if (a->in_dtype != MTP_BF16 || (a->variant & (1024 | (1 << 18))) || ((a->variant >> 8) & 3) || !mtp_nt_s8_fits(k, a->out_dtype, a->epilogue)) return 0;
     if (a->variant & (1 << 17)) return 1;
     // default: problems of less than half a round of 256 x 256 tiles on the 256 CUs -- the 768- / 1536-channel levels of InternImage-XL, ViT-B at
@@ -609,7 +610,7 @@ int nt_s8_mode(const mtp_gemm_args* a, const KArgs& k) {
     // 2048 x 1536 x 6144 83.3 -> 67.9 (twice as many work units, each half as long, the epilogue of all but the last hidden); from 225 tiles on the
     // 8-wave kernel wins (its loop moves 2/3 of the L2 -> LDS bytes per flop): 6272 x 2304 x 768 22.5 vs 29.0, every ViT-L shape 10-38 %.
     // Below 40 tiles (not measured with this kernel) the 128-wide kernels keep the problem: 4 x as many, smaller workgroups.
-    const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256) * 256 / cus;
     return tiles >= 40 && tiles <= 128;
 }
 
@@ -627,8 +628,9 @@ int launch_nt(const mtp_gemm_args* a, hipStream_t stream) {
     // 3 = 256 rows), bits 11-14 an ablation build, bits 15 / 16 force / forbid persistent tiles; falls through to the 128-wide kernels
     // when the problem does not fit it
     if constexpr (sizeof(T) == 2) {
-        if (nt_s8_mode(a, k)) return mtp_nt_s8_launch(k, a->out_dtype, EPI, ((((a->variant >> 1) & 3) == 1) ? 2 : 0), stream);
-        const int p8 = nt_p8_mode(a, k);
+        const int cus = mtp_stream_cus(stream);
+        if (nt_s8_mode(a, k, cus)) return mtp_nt_s8_launch(k, a->out_dtype, EPI, ((((a->variant >> 1) & 3) == 1) ? 2 : 0), stream);
+        const int p8 = nt_p8_mode(a, k, cus);
         if (p8) return mtp_nt_p8_launch(k, a->out_dtype, EPI, (p8 == 2 ? 1 : p8 == 3 ? 4 : 0) | ((((a->variant >> 1) & 3) == 1) ? 2 : 0) | (((a->variant >> 15) & 3) << 8) | (((a->variant >> 20) & 3) << 13), stream);
     }
     const int tiles_m = (k.M + BM - 1) / BM;
@@ -776,8 +778,9 @@ extern "C" int mtp_gemm_nt_tile(const mtp_gemm_args* a) {
     if (a->in_dtype != MTP_BF16) return 128;
     KArgs k;
     if (fill_common<bf16_t>(a, k)) return MTP_ERR_ARG;
-    if (nt_s8_mode(a, k)) return 64;
-    return nt_p8_mode(a, k) ? 256 : 128;
+    const int cus = mtp_stream_cus(nullptr);
+    if (nt_s8_mode(a, k, cus)) return 64;
+    return nt_p8_mode(a, k, cus) ? 256 : 128;
 }
 
 extern "C" int mtp_sum_partials_batch(const float* const* parts, float* const* outs, const int64_t* numel, const int* splits, int count, mtp_stream_t stream) {

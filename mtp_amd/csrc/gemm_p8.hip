@@ -251,30 +251,20 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
-int p8_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        ncu = prop.multiProcessorCount;
-    }
-    return ncu;
-}
-
 template <typename Tout, int EPI, int MI1, int XP, int PS = 0, int SP = 0>
 int launch_p8_kernel(const KArgs& a, int ntiles, hipStream_t stream) {
     constexpr int LDS = P8_LDS + ((PS || SP) ? 8 * 4096 : 0);
     static unsigned long long optin = 0;   // 128 / 160 KiB of dynamic LDS needs the opt-in once per kernel and device
     if (const int e = mtp_optin_lds((const void*)gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>, LDS, optin)) return e;
-    const int grid = PS ? (ntiles < p8_cus() ? ntiles : p8_cus()) : ntiles;
+    const int cus = mtp_stream_cus(stream);
+    const int grid = PS ? (ntiles < cus ? ntiles : cus) : ntiles;
     hipLaunchKernelGGL((gemm_nt_p8_kernel<Tout, EPI, MI1, XP, PS, SP>), dim3(grid), dim3(P8_THREADS), LDS, stream, a);
     return mtp_launch_status();
 }
 
 // rows per tile: whole rounds of one workgroup per CU cost (rows per tile) each -- take the cheaper of 256 and 224
-int p8_pick_bm(int64_t M, int64_t N) {
-    const int64_t cus = p8_cus(), tn = (N + P8_BN - 1) / P8_BN;
+int p8_pick_bm(int64_t M, int64_t N, int64_t cus) {
+    const int64_t tn = (N + P8_BN - 1) / P8_BN;
     const int64_t t256 = ((M + 255) / 256) * tn, t224 = ((M + 223) / 224) * tn;
     const int64_t c256 = ((t256 + cus - 1) / cus) * 256, c224 = ((t224 + cus - 1) / cus) * 224;
     return c224 < c256 ? 224 : 256;
@@ -282,7 +272,7 @@ int p8_pick_bm(int64_t M, int64_t N) {
 
 template <typename Tout, int EPI>
 int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
-    const int bm = (flags & 1) ? 224 : (flags & 4) ? 256 : p8_pick_bm(k.M, k.N);
+    const int bm = (flags & 1) ? 224 : (flags & 4) ? 256 : p8_pick_bm(k.M, k.N, mtp_stream_cus(stream));
     const int tiles_m = (k.M + bm - 1) / bm, tiles_n = (k.N + P8_BN - 1) / P8_BN;
     KArgs a = k;
     a.tiles_n = tiles_n;
@@ -293,7 +283,7 @@ int launch_p8(const KArgs& k, int flags, hipStream_t stream) {
     // persistent tiles: default for problems of more than one round of 224-row tiles (measured, tools/ab_gemm.py: +3...4 % at N = 3072 /
     // 4096, K = 1024 and on the FPN GEMM, nothing to gain on one-round problems; the 256-row instantiations spill 2-17 VGPRs with the
     // second tile loop and stay opt-in).  flags bit 8 forces it, bit 9 forbids it (A/B).
-    const bool persist = (flags & 256) || (!(flags & 512) && bm == 224 && ntiles > p8_cus());
+    const bool persist = (flags & 256) || (!(flags & 512) && bm == 224 && ntiles > mtp_stream_cus(stream));
     // store policy of the epilogue (224-row tiles; flags bits 13-14: 0 = by epilogue, 1 = nt, 2 = sc1 write-through, 3 = plain).  Measured with
     // rotating output buffers (tools/ab_gemm.py, MTP_AB_ROTATE=8: in the training step every GEMM writes fresh memory) and in the step
     // itself (profiles/r03_ab_store_policy.txt): nt wins for the bf16 outputs (+2...4 %), sc1 for the f32 residual epilogue (+1...5 %:

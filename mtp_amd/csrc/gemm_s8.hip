@@ -537,17 +537,6 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     e.template flush_from<0, POL>(p);
 }
 
-int s8_cus() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        ncu = prop.multiProcessorCount;
-    }
-    return ncu;
-}
-
 template <typename Tout, int EPI, bool HASB, int POL>
 int launch_s8_kernel(const KArgs& k, int flags, hipStream_t stream) {
     static unsigned long long optin = 0;   // 144 KiB of dynamic LDS needs the opt-in once per kernel and device
@@ -557,7 +546,8 @@ int launch_s8_kernel(const KArgs& k, int flags, hipStream_t stream) {
     a.k_tiles = k.K / 64;
     a.order = (flags >> 1) & 1;
     const int nstrips = ((k.M + S8_BM - 1) / S8_BM) * a.tiles_n;
-    const int grid = nstrips < s8_cus() ? nstrips : s8_cus();
+    const int cus = mtp_stream_cus(stream);
+    const int grid = nstrips < cus ? nstrips : cus;
     hipLaunchKernelGGL((gemm_nt_s8_kernel<Tout, EPI, HASB, POL>), dim3(grid), dim3(S8_THREADS), S8_LDS, stream, a);
     return mtp_launch_status();
 }

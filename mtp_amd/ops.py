@@ -170,6 +170,37 @@ def low_priority_stream(device):
     return st
 
 
+_mask_streams = {}
+
+
+def cu_mask_words(kind, part, parts=2, cus_per_xcc=32, xccs=8):
+    """the CU bit mask (list of 32-bit words) of partition `part` of `parts`: bit i = XCC i % xccs, CU j = i // xccs of that XCC (gfx950, SPX mode).
+    kind "interleaved": CU j belongs to partition j % parts (whole shader engines); "blocked": j * parts // cus_per_xcc (a slice of every engine).
+    Every partition holds cus_per_xcc / parts CUs of EVERY XCC: the dispatcher hands each XCC every eighth workgroup whatever the mask says."""
+    words = [0] * (cus_per_xcc * xccs // 32)
+    for i in range(cus_per_xcc * xccs):
+        j = i // xccs
+        mine = (j % parts == part) if kind == "interleaved" else (j * parts // cus_per_xcc == part)
+        if mine:
+            words[i // 32] |= 1 << (i % 32)
+    return words
+
+
+def cu_mask_stream(device, words):
+    """a stream restricted to the CUs of `words` (mtp_stream_create_cu_mask), wrapped for torch; one per (device, mask), kept for the process"""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, tuple(words))
+    st = _mask_streams.get(key)
+    if st is None:
+        h = C.c_void_p()
+        arr = (C.c_uint32 * len(words))(*words)
+        with torch.cuda.device(idx):
+            check(lib().mtp_stream_create_cu_mask(arr, len(words), C.byref(h)), "mtp_stream_create_cu_mask")
+        st = _mask_streams[key] = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
+    return st
+
+
 class WgradQueue:
     """Deferred weight gradients dW = dY^T X (+ bias gradient = column sums of dY): the weight gradients of a transformer block
     depend only on tensors the backward pass has anyway, so they are collected and launched together -- ONE

@@ -1009,6 +1009,43 @@ def test_adamw_flat_and_sqnorm(ops):
     assert rel_err(dp.cpu(), torch.cat([r.detach() for r in ref_p])) < 1e-5
 
 
+def test_cu_mask_stream_entry_points(ops):
+    """mtp_stream_create_cu_mask / mtp_probe_placement (round 6): a launch on the masked stream touches exactly the CUs of the mask (16 of every XCC for a
+    half), the GEMM dispatch sized by the stream's CU count gives the same bits as on the whole chip, masks that leave an XCC empty are refused."""
+    import ctypes as C
+    from mtp_amd import _lib
+    lib = _lib.load()
+    for kind in ("interleaved", "blocked"):
+        seen = []
+        for part in range(2):
+            st = ops.cu_mask_stream("cuda", ops.cu_mask_words(kind, part))
+            rec = torch.full((2048, 2), -1, device="cuda", dtype=torch.int32)
+            torch.cuda.synchronize()
+            assert lib.mtp_probe_placement(C.c_void_p(rec.data_ptr()), 2048, 40000, C.c_void_p(st.cuda_stream)) == 0
+            st.synchronize()
+            r = rec.cpu()
+            xcc, hw = r[:, 0] & 15, r[:, 1]
+            slots = set((int(x) << 12) | ((int(h) >> 8) & 0xff) for x, h in zip(xcc, hw))     # (XCC, se | sh | cu)
+            assert len(slots) == 128, "%s half %d ran on %d CUs" % (kind, part, len(slots))
+            assert all(int((xcc == x).sum()) == 256 for x in range(8))        # every XCC still gets one workgroup in eight
+            seen.append(slots)
+        assert not (seen[0] & seen[1])
+    # the same GEMM on the whole chip and on a 128-CU stream (other tile height / kernel family by CU count): bit-identical
+    a = torch.randn(6272, 1024, device="cuda").bfloat16()
+    w = torch.randn(1024, 1024, device="cuda").bfloat16()
+    y0 = ops.gemm_nt(a, w, torch.empty(6272, 1024, device="cuda", dtype=torch.bfloat16))
+    st = ops.cu_mask_stream("cuda", ops.cu_mask_words("interleaved", 0))
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        y1 = ops.gemm_nt(a, w, torch.empty(6272, 1024, device="cuda", dtype=torch.bfloat16))
+    st.synchronize()
+    assert torch.equal(y0, y1)
+    h = C.c_void_p()
+    bad = (C.c_uint32 * 8)(*([0x7f7f7f7f] * 8))      # XCC 7 without any CU
+    assert lib.mtp_stream_create_cu_mask(bad, 8, C.byref(h)) == -1
+    assert lib.mtp_stream_create_cu_mask(None, 8, C.byref(h)) == -1
+
+
 def test_low_priority_stream_entry_points(ops):
     """mtp_stream_create_low_priority / mtp_stream_destroy (round 4): the handle is a real HIP stream -- kernels launched on it through the C ABI run and
     are ordered by events against the compute stream -- and ops.low_priority_stream wraps one per device for torch (the weight-gradient side stream)."""

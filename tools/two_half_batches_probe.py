@@ -1,6 +1,7 @@
-"""Probe (round 5): the forward of ONE batch of 64 against the forwards of its two halves on two streams.  With two independent launch queues the workgroups of the two halves' GEMMs
-interleave on the CUs as they free up, so one half's epilogue bursts and HBM-bound kernels meet the other half's K loops (profiles/r05_epilogue_probe.txt).  Inference mode only
-(engine.forward keeps no state between calls besides the read-only weight images).   python tools/two_half_batches_probe.py [rounds]"""
+"""Probe: the forward of ONE batch of 64 against the forwards of its two halves on two streams -- plain streams (round 5: the hardware interleaves the
+workgroups of the two halves on all CUs) and CU-masked streams (round 6, VERDICT r05 #1: each half owns 128 CUs, 16 of every XCC, so M/2 rows on half the CUs keep the
+whole-batch tile quantisation and one half's HBM-bound kernels meet the other half's K loops).  Inference mode only (engine.forward keeps no state between calls
+besides the read-only weight images).   python tools/two_half_batches_probe.py [rounds] [--cu-mask]"""
 import os
 import sys
 import time
@@ -9,10 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import mtp_amd
+from mtp_amd import ops
 
 
 def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rounds = int(args[0]) if args else 5
+    masked = "--cu-mask" in sys.argv
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     net = mtp_amd.vit_l_rvsa(type("A", (), dict(image_size=224, use_ckpt=False))()).to(dev)
@@ -26,13 +30,16 @@ def main():
     def whole():
         eng.forward(img, training=False, need_grad=False)
 
-    def split(parts):
+    def split(parts, sts, stagger_blocks=0):
         cur = torch.cuda.current_stream()
-        for p, s in zip(parts, streams):
+        for s in sts[:len(parts)]:
             s.wait_stream(cur)
+        for k, (p, s) in enumerate(zip(parts, sts)):
             with torch.cuda.stream(s):
+                if k and stagger_blocks:
+                    torch.cuda._sleep(int(stagger_blocks))      # delay the second half by about this many clocks
                 eng.forward(p, training=False, need_grad=False)
-        for p, s in zip(parts, streams):
+        for p, s in zip(parts, sts):
             cur.wait_stream(s)
 
     def sequential(parts):
@@ -47,15 +54,35 @@ def main():
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
-    res = {k: [] for k in ("whole", "2 halves, 2 streams", "2 halves, 1 stream", "4 quarters, 4 streams")}
+
+    cases = {"whole": whole, "2 halves, 2 streams": lambda: split(halves, streams), "2 halves, 1 stream": lambda: sequential(halves)}
+    if masked:
+        for kind in ("interleaved", "blocked"):
+            ms = [ops.cu_mask_stream(dev, ops.cu_mask_words(kind, k)) for k in range(2)]
+            cases["2 halves, 2 CU-masked streams (%s)" % kind] = (lambda ms=ms: split(halves, ms))
+            cases["2 halves, 2 CU-masked streams (%s), second half 200 us late" % kind] = (lambda ms=ms: split(halves, ms, 400000))
+        ms = [ops.cu_mask_stream(dev, ops.cu_mask_words("interleaved", k)) for k in range(2)]
+        with torch.cuda.stream(ms[0]):
+            pass
+        cases["half a batch alone on a 128-CU stream"] = (lambda ms=ms: split(halves[:1], ms[:1]))
+        cases["half a batch alone on the whole chip"] = (lambda: sequential(halves[:1]))
+        q = [ops.cu_mask_stream(dev, ops.cu_mask_words("interleaved", k, parts=4)) for k in range(4)]
+        cases["4 quarters, 4 CU-masked streams (64 CUs each)"] = (lambda q=q: split(quarters, q))
+    else:
+        cases["4 quarters, 4 streams"] = lambda: split(quarters, streams)
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    if only:      # for rocprofv3 --kernel-trace --stats: a few passes of the named cases only
+        for k, fn in cases.items():
+            if k in only:
+                print(k, "%.3f ms" % t(fn, 5))
+        return
+    res = {k: [] for k in cases}
     for _ in range(rounds):
-        res["whole"].append(t(whole))
-        res["2 halves, 2 streams"].append(t(lambda: split(halves)))
-        res["2 halves, 1 stream"].append(t(lambda: sequential(halves)))
-        res["4 quarters, 4 streams"].append(t(lambda: split(quarters)))
+        for k, fn in cases.items():
+            res[k].append(t(fn))
     print("# ViT-L + RVSA forward (inference mode), 64 images, ms per pass: min over %d interleaved rounds of 10 passes" % rounds)
     for k, v in res.items():
-        print("%-24s %.3f ms  (%s)" % (k, min(v), " ".join("%.2f" % x for x in v)))
+        print("%-78s %.3f ms  (%s)" % (k, min(v), " ".join("%.2f" % x for x in v)))
 
 
 if __name__ == "__main__":
