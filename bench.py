@@ -10,8 +10,9 @@ for the three task decoders (they live in un-vendored mmseg/mmdet/mmrotate; SURV
     python bench.py --gpus 8 ...          # no launcher environment: starts its own 8 ranks (torch.distributed.run on 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant GEMM kernel family, HIP-event timed inside the timed region) and, at
-N=1, `cpu_baseline` (the oracle -- a CPU port of the reference path -- timed on the host cores on a bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant GEMM kernel family, HIP-event timed on extra steps run right behind the timed
+region, so that `value` times the step alone) and, at N=1, `cpu_baseline` (the oracle -- a CPU port of the reference path -- timed on the
+host cores on bounded samples: BASELINE configs[0] on all threads and on one, the headline model's fwd+bwd on all threads).
 """
 import argparse
 import json
@@ -100,35 +101,68 @@ class GemmTimer:
         return ["%-60s %5d launches %9.1f us avg %8.3f ms total %7.1f TF/s" % (str(k), v[2], v[1] / v[2] * 1e6, v[1] * 1e3, v[0] / v[1] / 1e12) for k, v in rows]
 
 
-def cpu_baseline(model, seconds_budget=25.0):
-    """The oracle (CPU port of the reference path, pinned to the reference's golden vectors) timed on the host cores:
-    ViT fwd+bwd, fp32, small batch -- a bounded sample of the same workload.  Baseline, not target."""
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(model, seconds_budget=38.0):
+    """The oracle (CPU port of the reference path, pinned to the reference's golden vectors) timed on the host cores, the legs BASELINE.md section 5 names,
+    each a bounded sample: ViT-B forward at batch 2 (BASELINE configs[0]) on all host threads and on ONE thread, and the headline model's fwd+bwd at a
+    small batch on all threads.  Top-level value / cores / sample = the fwd+bwd leg (the metric's own workload); `samples` holds every leg with its
+    configuration, thread count and the CPU model.  Baseline, not target."""
+    import statistics
     import recipe
     from oracle import vit_rvsa_oracle as O
-    cfg = dict(vit_l=(1024, 24, 16, 6, [7, 11, 15, 23]), vit_b=(768, 12, 12, 3, [3, 5, 7, 11]))[model]
+    cfgs = dict(vit_l=(1024, 24, 16, 6, [7, 11, 15, 23]), vit_b=(768, 12, 12, 3, [3, 5, 7, 11]))
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
-    B = 4
-    p = {k: v.requires_grad_(True) for k, v in recipe.make_params(recipe.state_shapes(cfg[0], cfg[1], cfg[2], cfg[3])).items()}
-    img = recipe.make_input(B, 224, 224)
+    many = min(cores, 64)
+    cpu = _cpu_model()
+    t_start = time.time()
 
-    def one():
-        feats = O.backbone_forward(img, p, cfg[1], cfg[2], cfg[3], cfg[4])
-        sum(f.mean() for f in feats).backward()
-        for v in p.values():
-            v.grad = None
-    t0 = time.time()
-    one()
-    warm = time.time() - t0
-    n, t0 = 0, time.time()
-    while n < 1 or (time.time() - t0 + warm) < seconds_budget and n < 5:
-        one()
-        n += 1
-    dt = (time.time() - t0) / n
-    return dict(value=B / dt, unit="images/sec", cores=threads, kind="port",
-                sample="oracle (torch CPU fp32 restatement of the reference path) %s fwd+bwd, batch %d, %d timed iters after 1 warm-up, %d of %d host threads"
-                       % (model, B, n, threads, cores))
+    def leg(name, threads, B, backward, budget, max_iters, warm_iters):
+        cfg = cfgs[name]
+        torch.set_num_threads(threads)
+        p = {k: v.requires_grad_(backward) for k, v in recipe.make_params(recipe.state_shapes(cfg[0], cfg[1], cfg[2], cfg[3])).items()}
+        img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(2023))
+
+        def one():
+            if backward:
+                feats = O.backbone_forward(img, p, cfg[1], cfg[2], cfg[3], cfg[4])
+                sum(f.mean() for f in feats).backward()
+                for v in p.values():
+                    v.grad = None
+            else:
+                with torch.no_grad():
+                    O.backbone_forward(img, p, cfg[1], cfg[2], cfg[3], cfg[4])
+        t0 = time.time()
+        for _ in range(warm_iters):
+            one()
+        warm = time.time() - t0
+        ts = []
+        while len(ts) < 1 or (sum(ts) + warm < budget and len(ts) < max_iters):
+            t1 = time.time()
+            one()
+            ts.append(time.time() - t1)
+        dt = statistics.median(ts)
+        return dict(config="%s %s, batch %d, 224x224, fp32" % ({"vit_b": "ViT-B + RVSA", "vit_l": "ViT-L + RVSA"}[name], "fwd+bwd" if backward else "forward", B),
+                    value=round(B / dt, 3), unit="images/sec", seconds_per_iter=round(dt, 4), threads=threads, host_threads=cores, cpu_model=cpu,
+                    iters=len(ts), warmup_iters=warm_iters, statistic="median")
+    samples = [leg("vit_b", many, 2, False, 4.0, 5, 2),          # BASELINE configs[0]: "ViT-B/16 backbone forward only, batch=2 ... CPU PyTorch reference"
+               leg("vit_b", 1, 2, False, 10.0, 3, 1),            # the same on one thread
+               leg(model, many, 4, True, max(8.0, seconds_budget - (time.time() - t_start) - 1.0), 5, 1)]
+    torch.set_num_threads(many)
+    head = samples[-1]
+    return dict(value=head["value"], unit="images/sec", cores=head["threads"], kind="port", cpu_model=cpu,
+                sample="oracle (torch CPU fp32 restatement of the reference path) %s, median of %d timed iters after %d warm-up, %d of %d host threads; "
+                       "`samples` adds BASELINE configs[0] (ViT-B forward, batch 2) on all threads and on one" % (head["config"], head["iters"], head["warmup_iters"], head["threads"], cores),
+                samples=samples, seconds_spent=round(time.time() - t_start, 1))
 
 
 def parse_rccl_log(path):
@@ -467,10 +501,10 @@ def main():
     ap.add_argument("--use-ckpt", action="store_true", help="activation checkpointing (`use_ckpt='True'`, VIT:799-800): every block's forward is recomputed in the "
                     "backward -- the recipe MTP pretrains with at 448^2 (Readme.md:233-240).  The recomputation is NOT counted in the step's flops")
     ap.add_argument("--gemm-shapes", action="store_true", help="print the per-shape table of the instrumented GEMM launches to stderr")
-    ap.add_argument("--timer-every", type=int, default=10,
-                    help="the per-launch HIP events behind `roofline` are recorded on every N-th timed step (step 0, N, 2N, ...): two events per "
-                         "GEMM launch cost ~1.3 ms per instrumented step (measured: 39.97 vs 38.63 ms), so instrumenting every step would make "
-                         "`value` a measurement of the instrumentation (20 steps, same box: every 4th 36.66 ms, every 10th 36.45, none 36.29); 1 = every step")
+    ap.add_argument("--timer-every", type=int, default=0,
+                    help="0 (default since round 6): no step of the timed region carries per-launch HIP events -- `value` times the step alone; the events behind "
+                         "`roofline` (one stream) and `roofline.concurrent` (as the step runs) are recorded on extra steps right AFTER the timed region.  N > 0: "
+                         "additionally instrument every N-th timed step the old way (two events per GEMM launch cost ~1.3 ms per instrumented step)")
     ap.add_argument("--host-input", action="store_true", help="additionally time the step fed from HOST uint8 batches (pinned staging, side-stream H2D, "
                                                               "fused preprocess): reported as `host_input`, never as `value`")
     ap.add_argument("--heads", default="mean", choices=["mean", "standin3", "standin_seg"],
@@ -537,7 +571,7 @@ def main():
             import tempfile
             rccl_log = os.path.join(tempfile.gettempdir(), "mtp_rccl_%d.%d.log" % (os.getpid(), rank))
             os.environ["NCCL_DEBUG"] = "INFO"
-            os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,COLL,GRAPH,TUNING"
+            os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"      # (no COLL: one formatted line per collective would land inside the timed region)
             os.environ["NCCL_DEBUG_FILE"] = rccl_log
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -604,7 +638,7 @@ def main():
     side_default = getattr(eng_cls, "wgrad_side_stream", False)
     conc_steps = 0
     for i in range(args.steps):
-        timer.on = (not args.no_gemm_timer) and i % max(1, args.timer_every) == 0
+        timer.on = (not args.no_gemm_timer) and args.timer_every > 0 and i % args.timer_every == 0
         if timer.on:
             timer.use(1 if side_default else 0)
             if side_default:
@@ -616,16 +650,25 @@ def main():
     dt = time.perf_counter() - t0
     clocks = sampler.stop() if sampler is not None else None
     timer.on = False
-    if side_default and not args.no_gemm_timer:
-        n_inst = max(2, args.steps // max(1, args.timer_every))
-        eng_cls.wgrad_side_stream = False
+    if not args.no_gemm_timer:
+        # the instrumented steps, right behind the timed region (same weights, same buffers, same clocks): first as the timed steps ran (`concurrent`,
+        # engines with a weight-gradient side stream only), then with every launch on the one compute stream (`roofline` proper)
+        n_inst = max(2, min(4, args.steps // 5))
+        if side_default:
+            timer.on = True
+            timer.use(1)
+            for _ in range(n_inst):
+                trainer.step(img, loss_and_grads)
+            sync()
+            conc_steps += n_inst
+            eng_cls.wgrad_side_stream = False
         try:
             timer.on = True
             timer.use(0)
             for _ in range(n_inst):
                 trainer.step(img, loss_and_grads)
             sync()
-            timed_steps = n_inst
+            timed_steps += n_inst
         finally:
             eng_cls.wgrad_side_stream = side_default
             timer.on = False
@@ -662,8 +705,20 @@ def main():
         ms_nocomm = float(tnc.item()) / args.steps * 1e3
         busf = 2.0 * (world - 1) / world if world > 1 else 1.0
         rccl = parse_rccl_log(rccl_log) if (rank == 0 and rccl_log) else None
-        comm = dict(ranks=dist.get_world_size(), backend=dist.get_backend(), collectives_per_step=ncoll, bytes_per_step=int(nbytes), exposed_ms=round(ms - ms_nocomm, 3), rccl=rccl,
-                    wire_bytes_per_step=int(wire), exchange=red.describe(),
+        if rccl_log:
+            try:
+                os.unlink(rccl_log)
+            except OSError:
+                pass
+        ex = red.describe()
+        seen = ex["communicator"].get("nranks") if isinstance(ex.get("communicator"), dict) else (rccl or {}).get("nranks")
+        if world > 1 and seen != world:
+            # the exchange did not run over the communicator the line would claim: no result line
+            if rank == 0:
+                print(_error_line(args, "--gpus %d but the RCCL communicator of the gradient exchange reports %r ranks" % (world, seen)), flush=True)
+            raise SystemExit(4)
+        comm = dict(ranks=dist.get_world_size(), rccl_nranks=seen, backend=dist.get_backend(), collectives_per_step=ncoll, bytes_per_step=int(nbytes), exposed_ms=round(ms - ms_nocomm, 3), rccl=rccl,
+                    wire_bytes_per_step=int(wire), exchange=ex,
                     allreduce_ms_per_step=round(secs * 1e3, 3), bus_GBps=round(wire * busf / max(secs, 1e-9) / 1e9, 1),
                     xgmi_peak_GBps=7 * 153, ms_per_step_without_comm=round(ms_nocomm, 3), exposed_comm_ms=round(ms - ms_nocomm, 3),
                     note="all-reduce time = HIP events on the side stream around each collective (its own duration, overlapped with the "
@@ -734,8 +789,10 @@ def main():
                         flops_per_launch=round(d["flops"] / d["launches"]),
                         avg_launch_us=round(d["seconds"] / d["launches"] * 1e6, 1), launches_per_step=d["launches"] // max(1, timed_steps),
                         instrumented_steps=timed_steps,
-                        instrumented_where=("steps run right after the timed region with every launch on ONE stream (a launch's events then time that kernel alone); "
-                                            "`concurrent` = events of steps inside the timed region, run as all timed steps are") if side_default else "inside the timed region",
+                        instrumented_where=("extra steps run right after the timed region (none of the timed steps carries events: `value` is the step alone)"
+                                            + ("; every launch on ONE stream, so a launch's events time that kernel alone -- `concurrent` = the same events on steps run as "
+                                               "the timed steps are (weight-gradient bursts on the side stream)" if side_default else "")
+                                            + ("; plus every %d-th timed step (--timer-every)" % args.timer_every if args.timer_every > 0 else "")),
                         families={k: dict(tflops=round(v["flops"] / v["seconds"] / 1e12, 1), ms_per_step=round(v["seconds"] / max(1, timed_steps) * 1e3, 2))
                                   for k, v in fams.items()})
             if conc_steps:

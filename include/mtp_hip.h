@@ -384,6 +384,9 @@ int mtp_comm_allreduce_bucket_dt(void* comm, void* bucket, int64_t count, int dt
  * has no such mode). */
 int mtp_comm_reduce_scatter_bucket(void* comm, void* bucket, int64_t count_per_rank, int rank, int dtype, mtp_stream_t stream);
 int mtp_comm_allgather_bucket(void* comm, void* bucket, int64_t count_per_rank, int rank, int dtype, mtp_stream_t stream);
+/* info4 = {ranks in the communicator, this rank, its device ordinal, RCCL's version code}; -1 where RCCL has no answer.  (The reference reads the
+ * same from torch.distributed, main_pretrain.py:132-140.) */
+int mtp_comm_info(void* comm, int* info4);
 int mtp_comm_destroy(void* comm);
 
 #ifdef __cplusplus

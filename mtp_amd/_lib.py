@@ -95,6 +95,7 @@ SIGNATURES = {
     "mtp_comm_allreduce_bucket_dt": (i32, [p, p, i64, i32, p]),
     "mtp_comm_reduce_scatter_bucket": (i32, [p, p, i64, i32, i32, p]),
     "mtp_comm_allgather_bucket": (i32, [p, p, i64, i32, i32, p]),
+    "mtp_comm_info": (i32, [p, p]),
     "mtp_comm_destroy": (i32, [p]),
     "mtp_full_attn_fwd": (i32, [p, p, p, i32, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_full_attn_bwd_workspace_floats": (i64, [i64, i64, i64, i64]),
@@ -139,7 +140,10 @@ def load():
         raise MtpHipError("libmtp_hip.so not found at %s -- build it first (__graft_entry__.build() or make -C mtp_amd/csrc); "
                           "mtp_amd has no CPU/PyTorch fallback" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    ab = bool(os.environ.get("MTP_HIP_LIB"))
     for name, (res, args) in SIGNATURES.items():
+        if ab and not hasattr(lib, name):
+            continue              # an A/B build of an older tree (tools/_abl): entry points added since are simply absent
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

@@ -1,9 +1,9 @@
 """RCCL communicator through the C ABI (include/mtp_hip.h: mtp_comm_unique_id / mtp_comm_init / mtp_comm_allreduce_bucket[_dt] /
 mtp_comm_reduce_scatter_bucket / mtp_comm_allgather_bucket / mtp_comm_destroy) -- the native form of the gradient all-reduce the reference gets from DistributedDataParallel
 (main_pretrain.py:508-518).  torch.distributed is used once, to hand rank 0's 128-byte id to the other ranks; the collectives
-themselves are ncclAllReduce calls on the caller's stream.  mtp_amd.parallel.GradReducer uses it when MTP_NATIVE_COMM=1 (the default
-stays torch.distributed's all_reduce on the same side stream: same RCCL underneath, and the variant the multi-GPU runs of this
-repository have been exercised with)."""
+themselves are ncclAllReduce / ncclReduceScatter / ncclAllGather calls on the caller's stream.  Since round 6 this is what
+mtp_amd.parallel.GradReducer exchanges gradients with on the GPU (MTP_NATIVE_COMM=0 goes back to torch.distributed's collectives on the same
+side stream: same RCCL underneath); torch.distributed stays the bootstrap (rendezvous, the id broadcast, barriers)."""
 import ctypes as C
 
 import torch
@@ -53,6 +53,14 @@ class RcclComm:
         _lib.check(_lib.load().mtp_comm_allgather_bucket(self._h, buf.data_ptr(), buf.numel() // self.world, self.rank, self._dt(buf),
                                                          torch.cuda.current_stream().cuda_stream), "mtp_comm_allgather_bucket")
         return buf
+
+    def info(self):
+        """what RCCL says about this communicator: ranks, this rank, device ordinal, library version (mtp_comm_info)"""
+        a = (C.c_int * 4)()
+        _lib.check(_lib.load().mtp_comm_info(self._h, a), "mtp_comm_info")
+        v = a[3]
+        ver = None if v < 0 else ("%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v >= 10000 else "%d.%d.%d" % (v // 1000, (v // 100) % 10, v % 100))
+        return dict(nranks=a[0], rank=a[1], device=a[2], version_code=v, version=ver)
 
     def close(self):
         if self._h:

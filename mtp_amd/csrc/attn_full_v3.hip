@@ -438,19 +438,53 @@ __global__ __launch_bounds__(64 * NW) void v3_bwd_a_kernel(const bf16_t* __restr
             }
         }
     }
-    // per-wave partial sums -> drel_part[bh][RH + RW rows][64] (zeroed by the launcher)
-    float* dp = drel_part + (int64_t)bh * (g.RH + g.RW) * HD;
+    // table partials of the NW waves -> ONE image per (image, head): tree reduction through LDS (the Q / K / V images are dead by now; the exchange buffer holds
+    // register images -- 16 float4 per lane, lane-contiguous 16-byte accesses, no bank conflicts), then plain stores by wave 0.  Round 5 had every wave add its
+    // partials to global memory with f32 atomics: 8 x 14 MB of read-modify-write per launch where 14 MB of stores are owed (profiles/r05_hbm_fractions.txt: 1.74 x the
+    // algorithmic bytes), plus the clearing pass in front of it.
+    __syncthreads();
+    float4* xb = reinterpret_cast<float4*>(sm);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            float4* slot = xb + (wave - half) * 1024 + lane;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+                for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int r = 16 * rt + 4 * gq + rr;
-                    if (r < (t ? g.RW : g.RH)) atomicAdd(dp + ((t ? g.RH : 0) + r) * HD + 16 * dt + fr, tacc[t][rt][dt][rr] * scale);
-                }
+                    for (int dt = 0; dt < 4; ++dt)
+                        slot[((t * 2 + rt) * 4 + dt) * 64] = make_float4(tacc[t][rt][dt][0], tacc[t][rt][dt][1], tacc[t][rt][dt][2], tacc[t][rt][dt][3]);
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float4* slot = xb + wave * 1024 + lane;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const float4 v = slot[((t * 2 + rt) * 4 + dt) * 64];
+                        tacc[t][rt][dt][0] += v.x; tacc[t][rt][dt][1] += v.y; tacc[t][rt][dt][2] += v.z; tacc[t][rt][dt][3] += v.w;
+                    }
+        }
+        if (half > 1) __syncthreads();
+    }
+    if (wave == 0) {
+        float* dp = drel_part + (int64_t)bh * (g.RH + g.RW) * HD;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = 16 * rt + 4 * gq + rr;
+                        if (r < (t ? g.RW : g.RH)) dp[((t ? g.RH : 0) + r) * HD + 16 * dt + fr] = tacc[t][rt][dt][rr] * scale;
+                    }
+    }
 }
 
 // ===================================================================================================================
@@ -635,10 +669,10 @@ int mtp_full_v3_bwd_launch(const void* qkv, const void* o, const void* dout, con
                            float* drel_part, int64_t B, int64_t Hp, int64_t Wp, int64_t heads, float scale, hipStream_t s) {
     V3Geom g;
     if (!v3_geom(Hp, Wp, heads, g)) return MTP_ERR_UNSUPPORTED;
-    hipError_t e = hipMemsetAsync(drel_part, 0, sizeof(float) * (size_t)(B * heads) * (size_t)(g.RH + g.RW) * HD, s);
-    if (e != hipSuccess) return (int)e;
+    // (drel_part needs no clearing: v3_bwd_a_kernel stores every row of every (image, head) image once)
     constexpr int NW = 8;
-    const size_t lds_a = 3 * (size_t)g.NPR * 128 + 8192 + (size_t)NW * 1280 * 4;
+    const size_t lds_a = 3 * (size_t)g.NPR * 128 + 8192 + (size_t)NW * 1280 * 4;      // >= 64 KiB for every grid: the table-partial exchange buffer (NW / 2 x 16 KiB) fits
+    static_assert(NW == 8, "the exchange buffer of v3_bwd_a_kernel's table reduction is sized for eight waves");
     const size_t lds_b = 3 * (size_t)g.NPR * 128 + 8192 + 2 * (size_t)g.NPR * 4 + (size_t)NW * 768 * 4;
     const dim3 grid((unsigned)(B * heads)), block(64 * NW);
     if (Hp == 14) {

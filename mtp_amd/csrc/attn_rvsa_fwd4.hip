@@ -189,6 +189,11 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
                 }
             }
         }
+        // (the records cross lanes: a wavefront-scope release + wave barrier keeps the compiler from moving the read-back above the writes; the hardware
+        //  executes one wave's LDS operations in order, so this costs no instruction -- ADVICE r05)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             const int key = (wave + 4 * gi) * 8 + kl;      // 8 groups = 64 key rows

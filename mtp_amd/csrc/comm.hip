@@ -18,6 +18,10 @@ struct Rccl {
     ncclResult_t (*reduce_scatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*comm_count)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*comm_user_rank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*comm_device)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*get_version)(int*) = nullptr;
     bool ok = false;
 };
 
@@ -35,6 +39,10 @@ Rccl& rccl() {
         x.reduce_scatter = reinterpret_cast<decltype(x.reduce_scatter)>(dlsym(x.lib, "ncclReduceScatter"));
         x.all_gather = reinterpret_cast<decltype(x.all_gather)>(dlsym(x.lib, "ncclAllGather"));
         x.comm_destroy = reinterpret_cast<decltype(x.comm_destroy)>(dlsym(x.lib, "ncclCommDestroy"));
+        x.comm_count = reinterpret_cast<decltype(x.comm_count)>(dlsym(x.lib, "ncclCommCount"));
+        x.comm_user_rank = reinterpret_cast<decltype(x.comm_user_rank)>(dlsym(x.lib, "ncclCommUserRank"));
+        x.comm_device = reinterpret_cast<decltype(x.comm_device)>(dlsym(x.lib, "ncclCommCuDevice"));
+        x.get_version = reinterpret_cast<decltype(x.get_version)>(dlsym(x.lib, "ncclGetVersion"));
         x.ok = x.get_unique_id && x.comm_init_rank && x.all_reduce && x.reduce_scatter && x.all_gather && x.comm_destroy;
         return x;
     }();
@@ -102,6 +110,20 @@ extern "C" int mtp_comm_allgather_bucket(void* comm, void* bucket, int64_t count
     if (!rccl().ok) return MTP_ERR_UNSUPPORTED;
     const char* shard = reinterpret_cast<const char*>(bucket) + (size_t)rank * (size_t)count_per_rank * eb;
     return rc(rccl().all_gather(shard, bucket, (size_t)count_per_rank, t, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+// What the communicator says about itself: info[0] = ranks in it (ncclCommCount), [1] = this rank (ncclCommUserRank), [2] = its device (ncclCommCuDevice),
+// [3] = the library's version code (ncclGetVersion) -- bench.py refuses to print an N-GPU line unless info[0] == N.  Entries RCCL cannot answer stay -1.
+extern "C" int mtp_comm_info(void* comm, int* info4) {
+    if (!comm || !info4) return MTP_ERR_ARG;
+    if (!rccl().ok) return MTP_ERR_UNSUPPORTED;
+    for (int i = 0; i < 4; ++i) info4[i] = -1;
+    const Rccl& r = rccl();
+    if (r.comm_count) { const int e = rc(r.comm_count((ncclComm_t)comm, &info4[0])); if (e) return e; }
+    if (r.comm_user_rank) { const int e = rc(r.comm_user_rank((ncclComm_t)comm, &info4[1])); if (e) return e; }
+    if (r.comm_device) { const int e = rc(r.comm_device((ncclComm_t)comm, &info4[2])); if (e) return e; }
+    if (r.get_version) { const int e = rc(r.get_version(&info4[3])); if (e) return e; }
+    return 0;
 }
 
 extern "C" int mtp_comm_destroy(void* comm) {

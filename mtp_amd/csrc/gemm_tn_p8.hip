@@ -296,9 +296,10 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
     g.plain = (args[0].variant >> 1) & 1;
     // read-ahead phases (gemm_p8.h: the next phase's transpose reads issued under the current phase's MFMAs; round 5: +5-11 %); variant bit 19 = the
     // plain phases of rounds 2-4 (A/B, bit-identical)
-    void (*kern)(TnGroup) = ((args[0].variant >> 19) & 1) ? gemm_tn_p8_kernel<0, 0> : gemm_tn_p8_kernel<0, 1>;
-    static unsigned long long optin = 0;     // 128 KiB of dynamic LDS: opt-in once per kernel and device
-    if (const int e = mtp_optin_lds((const void*)kern, P8_LDS, optin)) return e;
+    const int plain_phase = (args[0].variant >> 19) & 1;
+    void (*kern)(TnGroup) = plain_phase ? gemm_tn_p8_kernel<0, 0> : gemm_tn_p8_kernel<0, 1>;
+    static unsigned long long optin[2] = {0, 0};     // 128 KiB of dynamic LDS: opt-in once per kernel INSTANTIATION and device
+    if (const int e = mtp_optin_lds((const void*)kern, P8_LDS, optin[plain_phase])) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(P8_THREADS), P8_LDS, (hipStream_t)stream, g);
     int rc = mtp_launch_status();
     // the split problems' images -> C

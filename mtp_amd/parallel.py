@@ -196,10 +196,11 @@ class GradReducer:
         # MTP_FORCE_COMM=1: issue the collectives even at world size 1 (exercises the RCCL + side-stream path on a 1-GPU box)
         self.active = self.world > 1 or (os.environ.get("MTP_FORCE_COMM") == "1" and dist.is_available() and dist.is_initialized())
         self.stream = torch.cuda.Stream() if self.cuda and self.active else None
-        # MTP_NATIVE_COMM=1: the collectives go through the C ABI (mtp_comm_* -> ncclAllReduce / ncclReduceScatter / ncclAllGather)
-        # instead of torch.distributed
+        # The collectives go through the C ABI (mtp_comm_* -> ncclAllReduce / ncclReduceScatter / ncclAllGather on the side stream): the exchange entry
+        # points include/mtp_hip.h advertises are the ones every GPU run exercises (round 6; torch.distributed is the bootstrap: rendezvous, the
+        # 128-byte id, barriers).  MTP_NATIVE_COMM=0: torch.distributed's collectives instead (same RCCL underneath).
         self.native = None
-        if self.stream is not None and os.environ.get("MTP_NATIVE_COMM") == "1":
+        if self.stream is not None and os.environ.get("MTP_NATIVE_COMM", "1") != "0":
             from .comm import RcclComm
             self.native = RcclComm(group)
         self.works = []
@@ -321,6 +322,11 @@ class GradReducer:
     def describe(self):
         """what bench.py prints about the exchange (library, algorithm knobs in effect)"""
         d = dict(mode=self.mode, wire_dtype="bf16" if self.bf16 else "f32", native_c_abi=self.native is not None, bucket_bytes=self.bucket_bytes)
+        if self.native is not None:
+            try:
+                d["communicator"] = self.native.info()       # ranks / rank / device / version as RCCL reports them for THIS communicator
+            except Exception as e:
+                d["communicator"] = "unreadable: %s" % e
         for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE", "NCCL_DEBUG"):
             if k in os.environ:
                 d[k] = os.environ[k]

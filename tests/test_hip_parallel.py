@@ -50,9 +50,17 @@ def _worker(rank, world, port, q, native=False, mode="allreduce", bf16=False):
         gref = ref.flat.grad.clone()
         # ---- the data-parallel step: this rank's shard, replicas seeded differently on purpose (the trainer broadcasts rank 0's)
         os.environ["MTP_FORCE_COMM"] = "1"
-        os.environ["MTP_NATIVE_COMM"] = "1" if native else "0"
+        if native is None:       # the default: the C-ABI communicator (round 6)
+            os.environ.pop("MTP_NATIVE_COMM", None)
+            native = True
+        else:
+            os.environ["MTP_NATIVE_COMM"] = "1" if native else "0"
         tr = DataParallelTrainer(_net(0 if rank == 0 else 123).to(dev), total_steps=10, bucket_bytes=1 << 20, comm_mode=mode, comm_bf16=bf16)
         assert tr.reducer.active and tr.reducer.stream is not None and (tr.reducer.native is not None) == native
+        if native:      # what RCCL itself says about the communicator behind mtp_comm_* (mtp_comm_info)
+            info = tr.reducer.native.info()
+            assert info["nranks"] == world and info["rank"] == rank and info["device"] == rank and info["version_code"] > 0, info
+            assert tr.reducer.describe()["communicator"]["nranks"] == world
         assert tr.reducer.mode == mode and tr.reducer.bf16 == bf16
         shard = imgs[2 * rank:2 * rank + 2].to(dev)
         tr.step(shard, _loss)
@@ -86,6 +94,12 @@ def test_forced_comm_single_rank_rccl_side_stream():
     gradients must equal the run without communication (up to the f32-atomic summation order of the RVSA scatter, ~1e-7: two
     runs of the SAME configuration differ by as much) and the updated parameters likewise"""
     (rank, err, dparam, ncoll, all_bytes), = _run(1)
+    assert err < 1e-5 and dparam < 1e-6 and ncoll >= 2 and all_bytes
+
+
+def test_c_abi_communicator_is_the_default_exchange():
+    """no MTP_NATIVE_COMM in the environment: GradReducer exchanges through mtp_comm_* (the entry points the header advertises), torch.distributed only boots"""
+    (rank, err, dparam, ncoll, all_bytes), = _run(1, native=None)
     assert err < 1e-5 and dparam < 1e-6 and ncoll >= 2 and all_bytes
 
 
