@@ -58,6 +58,15 @@ class InternEngine:
             st = self._wstream = torch.cuda.Stream(device=self.dev)
         return st
 
+    def warm_streams(self, device):
+        """create and use the weight-gradient side stream now (BackboneEngine.warm_streams: hardware queues go to streams in the order of their first use)"""
+        self.dev = torch.device(device)
+        st = self._wgrad_stream()
+        if st is not None:
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=self.dev).add_(1.0)
+            st.synchronize()
+
     # ------------------------------------------------------------------ parameters -> GEMM-side images
     def params(self):
         return dict(self.m.named_parameters())

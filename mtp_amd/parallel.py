@@ -202,6 +202,10 @@ class GradReducer:
         self.native = None
         if self.stream is not None and os.environ.get("MTP_NATIVE_COMM", "1") != "0":
             from .comm import RcclComm
+            # (the exchange stream takes its hardware queue at first use: use it BEFORE RCCL creates the communicator's own streams -- BackboneEngine.warm_streams)
+            with torch.cuda.stream(self.stream):
+                torch.zeros(1, device=flat.grad.device).add_(1.0)
+            self.stream.synchronize()
             self.native = RcclComm(group)
         self.works = []
         self.pending_casts = []   # bf16 mode: (scratch bucket, f32 slice) pairs whose cast back waits for the collective
@@ -474,6 +478,8 @@ class DataParallelTrainer:
         self.engine = module._engine()
         self.flat = FlatParams(module, unused=module._unused_params)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.flat.data.is_cuda and hasattr(self.engine, "warm_streams"):
+            self.engine.warm_streams(self.flat.data.device)      # before the reducer creates its RCCL communicator
         self.reducer = GradReducer(self.flat, bucket_bytes, mode=comm_mode, bf16=comm_bf16)
         self.opt = FlatAdamW(self.flat, lr=lr, weight_decay=weight_decay, max_norm=max_norm, total_steps=total_steps, world_size=self.world)
         self.feature_dtype = feature_dtype

@@ -597,6 +597,59 @@ def test_large_inputs_bf16_flash_attention_path_vs_oracle(size):
         assert v < (0.6 if "sampling" in n else 0.15), (n, v)
 
 
+def test_vit_b_config2_whole_at_batch_32():
+    """BASELINE configs[1] as a whole: ViT-B + RVSA, batch 32, 224^2, bf16 mode, forward + backward through the trainer's path of
+    bench.py -- every map finite, the GEMM kernels the bench line runs on (6272 token rows: strip kernel for N = 768, 8-phase kernel for N = 2304 / 3072),
+    and -- the images of a batch being independent -- the features and the input gradient of images 3 and 20 against the fp32 oracle run on those two images."""
+    from mtp_amd import ops
+
+    class A:
+        image_size = 224
+        use_ckpt = "False"
+        precision = "bf16"
+    net = mtp_amd.vit_b_rvsa(A)
+    net.feature_dtype = torch.float32
+    params = recipe.make_params(recipe.state_shapes(768, 12, 12, 3))
+    net.load_state_dict(params, strict=False)
+    net = net.cuda().eval()         # (eval: no drop path, so that the oracle sees the same function)
+    img = recipe.make_input(32, 224, 224, seed=5)
+    x = img.cuda().requires_grad_(True)
+    feats = net.forward_features(x)
+    assert [tuple(f.shape) for f in feats] == [(32, 768, 56, 56), (32, 768, 28, 28), (32, 768, 14, 14), (32, 768, 7, 7)]
+    assert all(bool(torch.isfinite(f).all()) for f in feats)
+    ws = [recipe.loss_weights((2,) + tuple(f.shape[1:]), 900 + i) for i, f in enumerate(feats)]        # cotangents of the two checked images; zero elsewhere
+    pick = [3, 20]
+    cot = []
+    for f, w in zip(feats, ws):
+        c = torch.zeros_like(f)
+        c[pick] = w.cuda()
+        cot.append(c)
+    torch.autograd.backward(feats, cot)
+    assert bool(torch.isfinite(x.grad).all())
+    P = dict(net.named_parameters())
+    assert all(bool(torch.isfinite(q.grad).all()) for n, q in P.items() if q.grad is not None) and P["norm.weight"].grad is None
+    assert float(x.grad[[0, 1, 2, 4, 31]].abs().max()) == 0.0       # images that received no cotangent get no gradient: nothing leaks across the batch
+    # the kernels of the bench line (tools: profiles/r05_vitb_b32_gemm_shapes.txt): tile width by problem
+    T = 32 * 196
+    a = torch.empty(T, 768, device="cuda", dtype=torch.bfloat16)
+    for N, K, want in ((768, 768, 64), (2304, 768, 256), (3072, 768, 256), (768, 3072, 64)):
+        ak = a if K == 768 else torch.empty(T, K, device="cuda", dtype=torch.bfloat16)
+        got = ops.gemm_nt_tile(ak, torch.empty(N, K, device="cuda", dtype=torch.bfloat16), torch.empty(T, N, device="cuda", dtype=torch.bfloat16))
+        assert got == want, (N, K, got, want)
+    # the two images through the oracle (fp32, CPU)
+    p = {k: v.clone().requires_grad_(False) for k, v in params.items()}
+    xr = img[pick].clone().requires_grad_(True)
+    ref = O.backbone_forward(xr, p, 12, 12, 3, [3, 5, 7, 11])
+    sum((f * w).sum() for f, w in zip(ref, ws)).backward()
+    for i, (f, r) in enumerate(zip(feats, ref)):
+        v = _l2(f[pick].detach().float().cpu().numpy(), r.detach().numpy())
+        record_parity("vit_b_batch32_bf16_vs_fp32_oracle_l2", "f%d" % i, v)
+        assert v < 2e-2, (i, v)
+    v = _l2(x.grad[pick].cpu().numpy(), xr.grad.numpy())
+    record_parity("vit_b_batch32_bf16_vs_fp32_oracle_l2", "dimg", v)
+    assert v < 0.15, v
+
+
 def test_window_partition_reverse_on_device_bit_exact(golden):
     """VIT:113-140 (dead code in the reference's forward, kept in the module surface): the same view / permute on device tensors,
     bit for bit against fixture f1, and partition -> reverse is the identity on a bf16 activation-sized tensor"""

@@ -36,6 +36,29 @@ FAMILIES = [
 MFMA = [("gemm_nt (NT family: forward + data gradients)", "gemm_nt_p8_kernel", "gemm_nt_kernel"), ("gemm_tn_p8 (grouped weight gradients)", "gemm_tn_p8_kernel", "gemm_tn_kernel")]
 
 
+def gemm_algorithmic_bytes_per_step():
+    """every operand and result of every GEMM launch of one step once (bf16 activations 2 B, f32 residual stream / weight gradients 4 B, bf16 weight images):
+    returns (NT bytes, NT launches, TN bytes) per step.  VERDICT r05 #5a: the traffic table printed '--' for the GEMM families."""
+    a, w = T * C * 2, C * C * 2                                   # one (T, C) bf16 activation, one (C, C) bf16 weight image
+    x = T * C * 4                                                 # one (T, C) f32 residual-stream tensor
+    blk_nt = [a + 3 * w + 3 * a,                                  # qkv:      ln1 | W | qkv
+              a + w + x + x,                                      # proj:     o | W | residual in | x1 out (f32)
+              a + 4 * w + 4 * a + 4 * a,                          # fc1:      ln2 | W | h | gelu' image u
+              4 * a + 4 * w + x + x,                              # fc2:      h | W | residual in | x2 out
+              a + 4 * w + 4 * a + 4 * a,                          # dgrad fc2: dx2 | W^T | u | du
+              4 * a + 4 * w + a,                                  # dgrad fc1: du | W^T | dln2
+              a + w + a,                                          # dgrad proj
+              3 * a + 3 * w + a]                                  # dgrad qkv
+    fpn_nt = [a + 4 * w + 4 * a, 4 * a + 4 * w + 16 * a, a + 4 * w + 4 * a,            # fpn1.0, fpn1.3, fpn2.0 forward (ConvT as GEMM, bf16 out)
+              16 * a + 4 * w + 4 * a, 4 * a + 4 * w + x, 4 * a + 4 * w + x,            # their data gradients (the two that reach the residual stream: f32 out)
+              T * 768 * 2 + 768 * C * 2 + x]                                           # patch embedding forward
+    nt = 24 * sum(blk_nt) + sum(fpn_nt)
+    dw = C * C * 4
+    blk_tn = [a + 4 * a + 4 * dw, 4 * a + a + 4 * dw, a + a + dw, 3 * a + a + 3 * dw]  # fc2, fc1, proj, qkv weight gradients: dY | X | dW (f32)
+    fpn_tn = [16 * a + 4 * a + 4 * dw, 4 * a + a + 4 * dw, 4 * a + a + 4 * dw, a + T * 768 * 2 + 768 * C * 4]
+    return nt, 24 * 8 + 7, 24 * sum(blk_tn) + sum(fpn_tn)
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     jpath = None
@@ -71,12 +94,22 @@ def main():
         print("%-46s %8d %9.1f %10.1f %10s %8s %7.2f %6.2f   %s" % (label.split(" (")[0], n, us, algo / 1e6, "%.1f" % (ctr / 1e6) if ctr else "--",
                                                                  "%.2f" % (ctr / algo) if ctr else "--", tbps, tbps / (PEAK / 1e12), what))
         out["kernels"][label.split(" (")[0]] = dict(launches=n, us_per_launch=round(us, 1), algorithmic_bytes=int(algo), counter_bytes=ctr, TBps=round(tbps, 2), frac=round(tbps / (PEAK / 1e12), 3))
-    print("# MFMA-bound families, for the traffic column only (their roofline is the matrix pipe: bench.py `roofline`)")
-    for label, needle, key in MFMA:
+    print("# MFMA-bound families, for the traffic column only (their roofline is the matrix pipe: bench.py `roofline`).  algo MB = the step's GEMM operands and results once,")
+    print("# divided by the launches of the family in the PMC pass (the grouped TN launch count depends on the burst size: per-step totals are in the json)")
+    nt_b, nt_n, tn_b = gemm_algorithmic_bytes_per_step()
+    for (label, needle, key), per_step in zip(MFMA, (nt_b, tn_b)):
         n, tot = agg(needle)
         if n:
-            ctr = pmc.get(key, {}).get("hbm_bytes_per_launch")
-            print("%-46s %8d %9.1f %10s %10s" % (label.split(" (")[0], n, tot / n / 1e3, "--", "%.1f" % (ctr / 1e6) if ctr else "--"))
+            e = pmc.get(key, {})
+            ctr, nl = e.get("hbm_bytes_per_launch"), e.get("launches")
+            per_launch = per_step / (nl / 2.0) if nl else None          # the PMC passes hold two steps (--steps 1 --warmup 1)
+            print("%-46s %8d %9.1f %10s %10s %8s" % (label.split(" (")[0], n, tot / n / 1e3, "%.1f" % (per_launch / 1e6) if per_launch else "--",
+                                                      "%.1f" % (ctr / 1e6) if ctr else "--", "%.2f" % (ctr / per_launch) if ctr and per_launch else "--"))
+            out["kernels"][label.split(" (")[0] + " [mfma-bound]"] = dict(launches=n, us_per_launch=round(tot / n / 1e3, 1), algorithmic_bytes=int(per_launch) if per_launch else None,
+                                                                        algorithmic_bytes_per_step=int(per_step), counter_bytes=ctr, TBps=None, frac=None)
+    print("# NT ratio: one XCD's 32 CUs hold 32 tiles, whose operand panels (0.5 MiB each at K = 1024) exceed its 4-MiB L2 for any tile order, so each of the 8 L2s fetches")
+    print("# the panels of its own tile range: the re-fetches are L2 misses served by the 256-MiB Infinity Cache (the operands of a launch total 32 MB), counted by FETCH_SIZE;")
+    print("# the HBM side of a launch stays at its algorithmic bytes (DESIGN.md section 4, 'XCD-aware tile order').")
     if jpath:
         json.dump(out, open(jpath, "w"), indent=1)
 
