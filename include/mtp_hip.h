@@ -188,9 +188,15 @@ typedef struct {
     int64_t R, C;
     int64_t tile0;
     int32_t f32_out; /* images of this entry are f32 whatever act_dtype says */
-    int32_t pad_;
+    float wd;        /* weight decay of this parameter (mtp_adamw_weight_images only; mtp_weight_images ignores it) */
 } mtp_wimg_desc;
 int mtp_weight_images(const mtp_wimg_desc* descs_dev, int n, int64_t total_tiles, int act_dtype, mtp_stream_t stream);
+/* The optimizer step and the images in ONE pass (round 6): torch.optim.AdamW semantics + clip_grad_norm_ scaling exactly as mtp_adamw_flat (main_pretrain.py:424-457,
+ * 783-788), applied tile by tile to the parameters the descriptors name -- `src` points INTO the flat parameter buffer that starts at p_base; the gradient and the two
+ * moments of a parameter sit at the same offset of g_base / m_base / v_base -- and the updated tile is written to the parameter and to its images w / wt (either may be
+ * NULL: parameters that no GEMM reads).  Descriptors must cover every parameter that is to be updated exactly once. */
+int mtp_adamw_weight_images(const mtp_wimg_desc* descs_dev, int n, int64_t total_tiles, int act_dtype, float* p_base, const float* g_base, float* m_base, float* v_base,
+                            const float* hyper, const float* sqnorm, float max_norm, float grad_scale, mtp_stream_t stream);
 /* ConvTranspose2d weight (Cin, Cout, 2, 2) f32 -> GEMM weight wg (4*Cout, Cin) and its transpose wgT (Cin, 4*Cout) */
 int mtp_convt_pack(const float* w, void* wg, void* wgT, int dtype, int64_t Cin, int64_t Cout, mtp_stream_t stream);
 /* dwg (4*Cout, Cin) f32 -> dw (Cin, Cout, 2, 2) f32 */

@@ -48,4 +48,4 @@ from .backbone import (InternImage, internimage_xl, RVSA_MTP, RVSA_MTP_branches,
                        window_partition, window_reverse)
 from .registry import BACKBONES, MODELS, build_backbone  # noqa: F401
 
-__version__ = "0.5.0"      # = mtp_version() of libmtp_hip.so ("mtp_hip 0.5 (gfx950)"): the round of the build
+__version__ = "0.6.0"      # = mtp_version() of libmtp_hip.so ("mtp_hip 0.6 (gfx950)"): the round of the build

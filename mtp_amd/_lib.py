@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
 
 class WimgDesc(C.Structure):
     """mtp_wimg_desc"""
-    _fields_ = [("src", p), ("w", p), ("wt", p), ("R", i64), ("C", i64), ("tile0", i64), ("f32_out", C.c_int32), ("pad_", C.c_int32)]
+    _fields_ = [("src", p), ("w", p), ("wt", p), ("R", i64), ("C", i64), ("tile0", i64), ("f32_out", C.c_int32), ("wd", C.c_float)]
 
 
 class Dcnv3Geom(C.Structure):
@@ -117,6 +117,7 @@ SIGNATURES = {
     "mtp_zero_segments_f32": (i32, [p, p, p, i32, p]),
     "mtp_sqnorm_f32": (i32, [p, p, i64, p]),
     "mtp_adamw_flat": (i32, [p, p, p, p, i64, p, p, i32, p, p, f32, f32, p]),
+    "mtp_adamw_weight_images": (i32, [p, i32, i64, i32, p, p, p, p, p, p, f32, f32, p]),
     "mtp_version": (C.c_char_p, []),
     "mtp_stream_create_low_priority": (i32, [p]),
     "mtp_stream_create_cu_mask": (i32, [p, i32, p]),

@@ -838,6 +838,148 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const mtp_wimg_desc*
     }
 }
 
+// ---- AdamW of the whole flat buffer AND every GEMM-side weight image in one launch (round 6): the update of a 64 x 64 tile of a parameter matrix is followed, from
+// the same registers, by the tile's bf16 row-major image and (through LDS) its transpose.  The separate pass (weight_images_kernel) read every f32 master once more:
+// 4 of its 8 bytes per GEMM weight, 1.2 GB per ViT-L step.  Descriptors as for mtp_weight_images, one per parameter of the flat buffers (1-D parameters as rows of 64
+// with no images), `src` = the parameter inside the flat data buffer, `wd` = its weight decay; g / m / v live at the same offset of their flat buffers.
+__device__ __forceinline__ void adamw_elem(float& P, float G, float& M, float& V, float gs, float decay, float b1, float b2, float step, float rbc2, float eps) {
+    const float ge = G * gs;
+    P *= decay;
+    M = b1 * M + (1.0f - b1) * ge;
+    V = b2 * V + (1.0f - b2) * ge * ge;
+    P -= step * M / (sqrtf(V) * rbc2 + eps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_images_kernel(const mtp_wimg_desc* __restrict__ descs, int n, const float* __restrict__ p_base, const float* __restrict__ g_base,
+                                                          float* __restrict__ m_base, float* __restrict__ v_base, const float* __restrict__ hyper,
+                                                          const float* __restrict__ sqnorm, float max_norm, float grad_scale) {
+    __shared__ float tile[64][65];
+    const int64_t tl = blockIdx.x;
+    int lo = 0, hi = n - 1;   // last descriptor with tile0 <= tl (uniform over the workgroup: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile0 <= tl) lo = mid; else hi = mid - 1;
+    }
+    const mtp_wimg_desc d = descs[lo];
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2 = hyper[5];
+    float gs = grad_scale;
+    if (sqnorm) {
+        const float total = sqrtf(*sqnorm) * grad_scale;
+        const float coef = max_norm / (total + 1e-6f);
+        gs *= coef < 1.0f ? coef : 1.0f;
+    }
+    const float rbc2 = rsqrtf(bc2), step = lr / bc1, decay = 1.0f - lr * d.wd;
+    float* __restrict__ P = const_cast<float*>(d.src);
+    const int64_t off = d.src - p_base;
+    const float* __restrict__ G = g_base + off;
+    float* __restrict__ M = m_base + off;
+    float* __restrict__ V = v_base + off;
+    const int64_t local = tl - d.tile0, tc = (d.C + 63) / 64;
+    const int64_t r0 = (local / tc) * 64, c0 = (local % tc) * 64;
+    const int t = threadIdx.x;
+    const bool f32o = d.f32_out != 0;
+    const int am = (f32o || sizeof(T) == 4) ? 3 : 7;     // 16-byte image stores: 4 floats or 8 bf16 per lane
+    if ((d.C & 3) || ((d.w || d.wt) && (d.C & am)) || (d.wt && (d.R & am))) {   // odd-sized (tiny) matrices: element-wise
+        const int a = t >> 2, g = (t & 3) * 16;
+        const int64_t r = r0 + a;
+        for (int e = 0; e < 16; ++e) {
+            const int64_t c = c0 + g + e;
+            if (r < d.R && c < d.C) {
+                const int64_t i = r * d.C + c;
+                float pv = P[i], mv = M[i], vv = V[i];
+                adamw_elem(pv, G[i], mv, vv, gs, decay, b1, b2, step, rbc2, eps);
+                P[i] = pv; M[i] = mv; V[i] = vv;
+                if (d.w) { if (f32o) reinterpret_cast<float*>(d.w)[i] = pv; else Elem<T>::store(reinterpret_cast<T*>(d.w) + i, pv); }
+                if (d.wt) { if (f32o) reinterpret_cast<float*>(d.wt)[c * d.R + r] = pv; else Elem<T>::store(reinterpret_cast<T*>(d.wt) + c * d.R + r, pv); }
+            }
+        }
+        return;
+    }
+    // a lane owns 8 consecutive columns of two rows (32 apart): whole 128-byte lines of both bf16 images per store instruction (weight_images_kernel)
+    const int ra = t >> 3, cg = (t & 7) * 8;
+    float x[2][8];
+    float4 pv[2][2], gv[2][2], mv[2][2], vv[2][2];
+    bool okv[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {      // all 16 loads of the lane in flight before the first use
+        const int64_t rr = r0 + ra + 32 * h, c = c0 + cg;
+        okv[h][0] = rr < d.R && c < d.C;         // (C % 4 == 0: columns c .. c + 3 are in range; c + 4 .. c + 7 checked separately)
+        okv[h][1] = okv[h][0] && c + 4 < d.C;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t i = okv[h][q] ? rr * d.C + c + 4 * q : 0;
+            pv[h][q] = load4(P + i); gv[h][q] = load4(G + i); mv[h][q] = load4(M + i); vv[h][q] = load4(V + i);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t rr = r0 + ra + 32 * h, c = c0 + cg;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float Pq[4] = {pv[h][q].x, pv[h][q].y, pv[h][q].z, pv[h][q].w}, Mq[4] = {mv[h][q].x, mv[h][q].y, mv[h][q].z, mv[h][q].w};
+            float Vq[4] = {vv[h][q].x, vv[h][q].y, vv[h][q].z, vv[h][q].w};
+            const float Gq[4] = {gv[h][q].x, gv[h][q].y, gv[h][q].z, gv[h][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) adamw_elem(Pq[e], Gq[e], Mq[e], Vq[e], gs, decay, b1, b2, step, rbc2, eps);
+            if (okv[h][q]) {
+                const int64_t i = rr * d.C + c + 4 * q;
+                store4(P + i, make_float4(Pq[0], Pq[1], Pq[2], Pq[3]));
+                store4(M + i, make_float4(Mq[0], Mq[1], Mq[2], Mq[3]));
+                store4(V + i, make_float4(Vq[0], Vq[1], Vq[2], Vq[3]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[h][4 * q + e] = okv[h][q] ? Pq[e] : 0.f;
+        }
+        if (okv[h][0] && d.w) {
+            if (okv[h][1]) {
+                if (f32o) store8(reinterpret_cast<float*>(d.w) + rr * d.C + c, x[h]);
+                else store8(reinterpret_cast<T*>(d.w) + rr * d.C + c, x[h]);
+            } else {
+                if (f32o) store4(reinterpret_cast<float*>(d.w) + rr * d.C + c, make_float4(x[h][0], x[h][1], x[h][2], x[h][3]));
+                else store4(reinterpret_cast<T*>(d.w) + rr * d.C + c, make_float4(x[h][0], x[h][1], x[h][2], x[h][3]));
+            }
+        }
+    }
+    if (d.wt) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[cg + e][ra + 32 * h] = x[h][e];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cl = ra + 32 * h;                   // source column = image row
+            const int64_t c = c0 + cl, rr = r0 + cg;
+            if (c < d.C && rr < d.R) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = tile[cl][cg + e];
+                if (rr + 4 < d.R) {
+                    if (f32o) store8(reinterpret_cast<float*>(d.wt) + c * d.R + rr, o);
+                    else store8(reinterpret_cast<T*>(d.wt) + c * d.R + rr, o);
+                } else {                                  // (R % 4 == 0)
+                    if (f32o) store4(reinterpret_cast<float*>(d.wt) + c * d.R + rr, make_float4(o[0], o[1], o[2], o[3]));
+                    else store4(reinterpret_cast<T*>(d.wt) + c * d.R + rr, make_float4(o[0], o[1], o[2], o[3]));
+                }
+            }
+        }
+    }
+}
+
+extern "C" int mtp_adamw_weight_images(const mtp_wimg_desc* descs_dev, int n, int64_t total_tiles, int act_dtype, float* p_base, const float* g_base, float* m_base,
+                                       float* v_base, const float* hyper, const float* sqnorm, float max_norm, float grad_scale, mtp_stream_t stream) {
+    if (!descs_dev || n <= 0 || total_tiles <= 0 || total_tiles > INT32_MAX || !p_base || !g_base || !m_base || !v_base || !hyper) return MTP_ERR_ARG;
+    if (act_dtype == MTP_BF16)
+        hipLaunchKernelGGL((adamw_images_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, descs_dev, n, p_base, g_base, m_base, v_base, hyper,
+                           sqnorm, max_norm, grad_scale);
+    else if (act_dtype == MTP_F32)
+        hipLaunchKernelGGL((adamw_images_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, descs_dev, n, p_base, g_base, m_base, v_base, hyper,
+                           sqnorm, max_norm, grad_scale);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
 extern "C" int mtp_weight_images(const mtp_wimg_desc* descs_dev, int n, int64_t total_tiles, int act_dtype, mtp_stream_t stream) {
     if (!descs_dev || n <= 0 || total_tiles <= 0 || total_tiles > INT32_MAX) return MTP_ERR_ARG;
     if (act_dtype == MTP_BF16)
@@ -1286,7 +1428,9 @@ extern "C" int mtp_scale_rows_cast(const float* src, void* dst, int dst_dtype, c
 // 0.4: round 4 -- mtp_gemm_args as of round 3 (workspace / workspace_bytes trailing fields; now ignored: the stream-K form is gone),
 // mtp_gemm_tn_grouped honours split_k / aux.  Bump whenever a struct in include/mtp_hip.h changes size or a field changes meaning.
 // 0.5: round 5 -- no struct changed; mtp_gemm_args.variant gained bits 17 / 18 (strip kernel) and 19 (grouped TN: plain phases), mtp_gemm_nt_tile may answer 64.
-extern "C" const char* mtp_version(void) { return "mtp_hip 0.5 (gfx950)"; }
+// 0.6: round 6 -- mtp_wimg_desc.pad_ became `float wd` (same size; read only by mtp_adamw_weight_images); new entry points mtp_adamw_weight_images, mtp_stream_create_cu_mask,
+// mtp_probe_placement, mtp_comm_info.
+extern "C" const char* mtp_version(void) { return "mtp_hip 0.6 (gfx950)"; }
 
 // A stream of the LOWEST priority the device offers (non-blocking), for work that is off the critical path and should only take the CUs
 // the main stream leaves idle: the grouped weight-gradient launches next to under-filled data-gradient GEMMs (engine_intern.py).

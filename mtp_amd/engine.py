@@ -73,7 +73,9 @@ class BackboneEngine:
                 torch.mul(P[pre + "mlp.fc2.weight"].detach(), g2[:, None], out=b.w2_s)
                 torch.mul(P[pre + "attn.proj.bias"].detach(), g1, out=b.bproj)
                 torch.mul(P[pre + "mlp.fc2.bias"].detach(), g2, out=b.b2)
-        self._wimg.refresh()
+        if not getattr(self, "_images_fresh", False):      # (set by DataParallelTrainer when the optimizer launch wrote the images itself)
+            self._wimg.refresh()
+        self._images_fresh = False
         for name, (wg, wgT) in self._fpn.items():
             ops.convt_pack(P[name + ".weight"].detach().contiguous(), wg, wgT)
         self._key = key

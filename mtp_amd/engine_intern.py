@@ -80,8 +80,9 @@ class InternEngine:
         if ptrs != self._ptrs:
             self._build(P)
             self._ptrs = ptrs
-        if self._wimg is not None:
+        if self._wimg is not None and not getattr(self, "_images_fresh", False):      # (set by DataParallelTrainer when the optimizer launch wrote the images itself)
             self._wimg.refresh()
+        self._images_fresh = False
         for L in self._padded:
             ops.pack_rows_padded(P[L.name].detach(), L.w, L.wt)
         for k in range(0, len(self._padded), 12):      # the padded layers' biases: R floats each, 12 per launch

@@ -509,11 +509,70 @@ class WeightImages:
             tile0 += ((R + 63) // 64) * ((Cc + 63) // 64)
             self.keep.append((src, w, wt))
         self.n, self.total_tiles, self.act = n, tile0, _DT[act_dtype]
+        self.entries, self.act_dtype = list(entries), act_dtype
         dev = entries[0][0].device
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
 
     def refresh(self):
         check(lib().mtp_weight_images(self.table.data_ptr(), self.n, self.total_tiles, self.act, _s()), "mtp_weight_images")
+
+
+class AdamWImages:
+    """Descriptor table for mtp_adamw_weight_images: ONE launch updates every parameter of the flat buffers (AdamW + gradient clipping, as adamw_flat) and writes the
+    GEMM-side images of the parameters that have them from the same registers -- the separate image pass read each f32 master once more.
+    flat: mtp_amd.parallel.FlatParams; wimg: the engine's WeightImages (its sources must be the flat parameters themselves); wd_of(name) -> weight decay.
+    None is returned by build() when an image source is not a whole flat parameter (layer scale: the images are made from scaled temporaries)."""
+
+    @staticmethod
+    def build(flat, wimg, wd_of):
+        by_ptr = {}
+        for src, w, wt, f32_out in (wimg.entries if wimg is not None else []):
+            by_ptr[src.data_ptr()] = (src, w, wt, f32_out)
+        base = flat.data.data_ptr()
+        rows = []
+        used = 0
+        for n in flat.names:
+            if flat.groups[n] is None:
+                continue
+            off = flat.offsets[n]
+            numel = 1
+            for d in flat.shapes[n]:
+                numel *= d
+            ent = by_ptr.get(base + 4 * off)
+            if ent is not None:
+                src, w, wt, f32_out = ent
+                if src.numel() != numel:
+                    return None
+                R, Cc = src.shape
+                used += 1
+            else:
+                w = wt = None
+                f32_out = False
+                padded = (numel + 63) // 64 * 64          # FlatParams pads every parameter to 64 elements: the tail is zero and stays zero
+                R, Cc = padded // 64, 64
+            rows.append((base + 4 * off, w, wt, R, Cc, f32_out, float(wd_of(n))))
+        if used != len(by_ptr):
+            return None               # an image whose source is not a flat parameter
+        self = AdamWImages()
+        arr = (_lib.WimgDesc * len(rows))()
+        tile0 = 0
+        self.keep = []
+        for i, (ptr, w, wt, R, Cc, f32_out, wd) in enumerate(rows):
+            d = arr[i]
+            d.src, d.w, d.wt = ptr, _p(w), _p(wt)
+            d.R, d.C, d.tile0, d.f32_out, d.wd = R, Cc, tile0, int(bool(f32_out)), wd
+            tile0 += ((R + 63) // 64) * ((Cc + 63) // 64)
+            self.keep.append((w, wt))
+        self.n, self.total_tiles = len(rows), tile0
+        self.act = _DT[wimg.act_dtype] if wimg is not None else MTP_BF16
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(flat.data.device)
+        self.flat = flat
+        return self
+
+    def step(self, m, v, hyper, sqn, max_norm, grad_scale):
+        f = self.flat
+        check(lib().mtp_adamw_weight_images(self.table.data_ptr(), self.n, self.total_tiles, self.act, _f32(f.data), _f32(f.grad), _f32(m), _f32(v), _f32(hyper),
+                                            _f32(sqn), max_norm, grad_scale, _s()), "mtp_adamw_weight_images")
 
 
 def convt_pack(w, wg, wgT):

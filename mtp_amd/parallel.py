@@ -452,7 +452,20 @@ class FlatAdamW:
             self.last_epoch += 1
             self.sched_pending = False
 
+    def fuse_images(self, wimg):
+        """from now on step() also writes the engine's GEMM-side weight images (ops.AdamWImages: one launch for the update and the images); returns whether the
+        engine's images qualify (every image source is a whole parameter of the flat buffer).  MTP_FUSED_ADAMW=0 keeps the two passes (A/B)."""
+        from . import ops
+        self._fused, self._fused_for = None, wimg
+        if wimg is None or not self.flat.data.is_cuda or os.environ.get("MTP_FUSED_ADAMW", "1") == "0":
+            return False
+        no_decay = ("pos_embed", "cls_token")
+        wd = lambda n: 0.0 if (len(self.flat.shapes[n]) == 1 or n.endswith(".bias") or n in no_decay) else self.weight_decay      # (= FlatParams.weight_decay_segments)
+        self._fused = ops.AdamWImages.build(self.flat, wimg, wd)
+        return self._fused is not None
+
     def step(self):
+        """returns True when the step also refreshed the engine's weight images (fuse_images)"""
         from . import ops
         self.scheduler_step()
         self.t += 1
@@ -465,8 +478,12 @@ class FlatAdamW:
             self.sqn.zero_()
             ops.sqnorm(f.grad[:n], self.sqn)
             sq = self.sqn
-        ops.adamw_flat(f.data[:n], f.grad[:n], self.m[:n], self.v[:n], self.seg_start, self.seg_wd, self.hyper, sq, float(self.max_norm or 0.0), gs)
         self.sched_pending = True     # scheduler.step() of MAIN:832 happens after the save point: see __init__
+        if getattr(self, "_fused", None) is not None:
+            self._fused.step(self.m, self.v, self.hyper, sq, float(self.max_norm or 0.0), gs)
+            return True
+        ops.adamw_flat(f.data[:n], f.grad[:n], self.m[:n], self.v[:n], self.seg_start, self.seg_wd, self.hyper, sq, float(self.max_norm or 0.0), gs)
+        return False
 
 
 class DataParallelTrainer:
@@ -502,6 +519,7 @@ class DataParallelTrainer:
             self.opt.total_steps = int(cnt[2]) or None
             self.opt.sched_pending = bool(int(cnt[3]))
         self.engine._key = None
+        self.engine._images_fresh = False
 
     # ---- encoder checkpoint in the reference's dict format (MAIN:823-829 save, MAIN:483-499 resume) -------------------------
     def checkpoint(self, epoch=0, iteration=None, losses=()):
@@ -543,6 +561,7 @@ class DataParallelTrainer:
         if "scheduler" in ckpt:
             self.opt.load_scheduler_state_dict(ckpt["scheduler"])
         self.engine._key = None
+        self.engine._images_fresh = False
         self.sync_replicas(optimizer_state=True)
         losses = ckpt.get("loss_pretrain", [])
         return ckpt.get("epoch", 0), ckpt.get("iteration", self.opt.t), (losses.tolist() if hasattr(losses, "tolist") else list(losses))
@@ -556,6 +575,10 @@ class DataParallelTrainer:
         # (split_last: with collectives in flight, block 0's weight gradients go out on their own so that only ~50 MB stay exposed)
         self.engine.backward(ctx, dfeats, self.flat.G, on_block_done=self.reducer.on_block_done, split_last=self.reducer.active)
         self.reducer.finish()
-        self.opt.step()
-        self.engine._key = None   # parameters changed under torch's version counters: rebuild the GEMM weight images next forward
+        wimg = getattr(self.engine, "_wimg", None)
+        if getattr(self.opt, "_fused_for", 0) is not wimg:       # (first step, or the engine rebuilt its image buffers)
+            self.opt.fuse_images(wimg if not getattr(self.engine, "_ls", None) else None)
+        fresh = self.opt.step()
+        self.engine._key = None   # parameters changed under torch's version counters: rebuild the GEMM weight images next forward ...
+        self.engine._images_fresh = bool(fresh)       # ... unless the optimizer kernel has just written them (the packed ConvT / convolution weights still follow)
         return loss

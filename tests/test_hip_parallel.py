@@ -132,3 +132,55 @@ def test_two_ranks_match_single_process_whole_batch(native, mode):
     res = _run(2, native=native, mode=mode)
     for rank, err, dparam, ncoll, all_bytes in res:
         assert err < 2e-2 and ncoll >= 2 and all_bytes
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_fused_adamw_writes_the_weight_images_it_would_otherwise_need_a_second_pass_for(precision, monkeypatch):
+    """mtp_adamw_weight_images (round 6): ONE launch = AdamW + clipping over the whole flat buffer AND the GEMM-side weight images.  Against the two-pass form
+    (mtp_adamw_flat, then mtp_weight_images at the next forward): parameters, both moments and every image bit-identical after three steps, and the images the
+    fused launch left behind equal to what a refresh from the updated masters writes."""
+    import mtp_amd
+    from mtp_amd.parallel import DataParallelTrainer
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run(fused):
+        monkeypatch.setenv("MTP_FUSED_ADAMW", "1" if fused else "0")
+        torch.manual_seed(5)
+        net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=224, embed_dim=128, depth=4, num_heads=2, interval=2, qkv_bias=True, use_abs_pos_emb=True,
+                                           out_indices=[0, 1, 2, 3], drop_path_rate=0.0, precision=precision)
+        with torch.no_grad():
+            for n, q in net.named_parameters():
+                if "rel_pos" in n:
+                    q.normal_(0, 0.02)
+        tr = DataParallelTrainer(net.cuda().train(), lr=1e-3, total_steps=10)
+        for _ in range(3):
+            tr.step(img, _loss)
+        torch.cuda.synchronize()
+        assert (tr.opt._fused is not None) == fused
+        eng = tr.engine
+        left = [(None if w is None else w.clone(), None if wt is None else wt.clone()) for _, w, wt, _ in eng._wimg.entries]      # as the last step left them
+        if not fused:
+            eng._wimg.refresh()
+            left = [(None if w is None else w.clone(), None if wt is None else wt.clone()) for _, w, wt, _ in eng._wimg.entries]
+        else:
+            assert eng._images_fresh
+            eng._wimg.refresh()          # what the image pass makes of the updated masters
+            for (w0, t0), (_, w, wt, _) in zip(left, eng._wimg.entries):
+                assert (w0 is None or torch.equal(w0, w)) and (t0 is None or torch.equal(t0, wt))
+            # the same update by both kernels from the same state: bit-identical parameters and moments
+            from mtp_amd import ops
+            f, o = tr.flat, tr.opt
+            state = (f.data.clone(), o.m.clone(), o.v.clone(), left)
+            n = f.reduced
+            pc, mc, vc = f.data.clone(), o.m.clone(), o.v.clone()
+            ops.adamw_flat(pc[:n], f.grad[:n], mc[:n], vc[:n], o.seg_start, o.seg_wd, o.hyper, o.sqn, 5.0, 1.0)
+            o._fused.step(o.m, o.v, o.hyper, o.sqn, 5.0, 1.0)
+            torch.cuda.synchronize()
+            assert torch.equal(pc[:n], f.data[:n]) and torch.equal(mc[:n], o.m[:n]) and torch.equal(vc[:n], o.v[:n])
+            assert torch.equal(pc[n:], f.data[n:])          # parameters outside the reduced range (norm.*) are not touched
+            return state
+        return tr.flat.data.clone(), tr.opt.m.clone(), tr.opt.v.clone(), left
+    a, b = run(False), run(True)
+    # (two runs of the same configuration differ in the last bits: f32-atomic summation order in a few gradient by-products)
+    for x, y in zip(a[:3], b[:3]):
+        assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())

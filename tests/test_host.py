@@ -260,7 +260,7 @@ def test_hw_queue_note_is_given_once_and_only_when_the_setting_cannot_work(monke
     monkeypatch.setattr(mtp_amd, "_HWQ_BEFORE_IMPORT", None)
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
     assert "before `import mtp_amd`" in mtp_amd.hw_queue_note()
-    assert mtp_amd.__version__.startswith("0.5")
+    assert mtp_amd.__version__.startswith("0.6")
 
 
 def test_patch_size_8_and_layer_scale_state_dict_matches_the_reference(golden):
