@@ -1129,16 +1129,26 @@ __global__ __launch_bounds__(256) void rvsa_sampling_fwd_kernel(const T* __restr
     __syncthreads();
     // gridDim.y workgroups share a window: each pools it (the second reads come out of L2) and produces its share of the N outputs
     const int nper = ((N + (int)gridDim.y - 1) / (int)gridDim.y + 3) / 4 * 4, nlo = (int)blockIdx.y * nper, nhi = (nlo + nper) < N ? (nlo + nper) : N;
-    for (int n0 = nlo + 4 * wave; n0 < nhi; n0 += 16) {      // 4 output columns per pass: 4 x (C / 256) weight loads in flight per lane
+    for (int n0 = nlo + 4 * wave; n0 < nhi; n0 += 16) {      // 4 output columns per pass
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = lane * 4; k < C; k += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(pl + k);
+        // 4 k-steps x 4 outputs = 16 weight loads of 16 B in flight per lane before the first use (round 6: written as one k-step per iteration the loop bound is a
+        // run-time value, hipcc kept the iterations apart and a pass was C / 256 dependent L2 round trips -- most of the kernel's 21.6 us at C = 1024)
+        for (int k0 = lane * 4; k0 < C; k0 += 1024) {
+            float4 ww[4][4], a[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + q < N ? n0 + q : N - 1;
-                const float4 ww = load4(w + (int64_t)n * C + k);
-                acc[q] += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = k0 + 256 * kk, kc = k < C ? k : 0;
+                a[kk] = k < C ? *reinterpret_cast<const float4*>(pl + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + q < N ? n0 + q : N - 1;
+                    ww[kk][q] = load4(w + (int64_t)n * C + kc);
+                }
             }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += a[kk].x * ww[kk][q].x + a[kk].y * ww[kk][q].y + a[kk].z * ww[kk][q].z + a[kk].w * ww[kk][q].w;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1246,7 +1256,10 @@ extern "C" int mtp_rvsa_sampling_fwd(const void* x, int dtype, const float* w, c
     if (!x || !w || !avg || !pooled || !samp || B <= 0 || Hp <= 0 || Wp <= 0 || C <= 0 || (C % 4) || C > 8192 || N <= 0) return MTP_ERR_ARG;
     int pt, pl, nh, nw;
     rvsa_geom(Hp, Wp, pt, pl, nh, nw);
-    constexpr int ysplit = 2;   // workgroups per window: measured 24.1 / 18.1 / 19.3 us at 1 / 2 / 4
+    // workgroups per window (each pools the window again -- L2 reads -- and makes its share of the N outputs): round 2 measured 24.1 / 18.1 / 19.3 us at 1 / 2 / 4;
+    // round 6, with the weight loads of a pass in flight together: 16.8 / 16.3 / 21.1 / 26.2 us at 1 / 2 / 3 / 5 (17.5 before) -- the repeated pooling, not the
+    // product, is what more workgroups per window cost
+    constexpr int ysplit = 2;
     const dim3 grid((unsigned)(B * nh * nw), (unsigned)(N >= 16 * ysplit ? ysplit : 1)), block(256);
     const size_t lds = sizeof(float) * (size_t)C;
     if (dtype == MTP_BF16)

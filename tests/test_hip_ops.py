@@ -715,6 +715,20 @@ def test_full_attention_flash_large_grids(ops, Hp, Wp, B):
     assert vals["o"] < 3e-3 and max(vals["dq"], vals["dk"], vals["dv"]) < 6e-3, vals
 
 
+@pytest.mark.parametrize("C,heads", [(1024, 16), (768, 12), (1280, 3)])
+def test_rvsa_sampling_fwd_at_model_widths(ops, C, heads):
+    """the fused sampling-head forward at ViT-L / ViT-B widths: 5 * heads outputs split over ceil(N / 16) workgroups per window, a pass's weight loads in flight
+    together (round 6), C not a multiple of 1024 (the masked tail of the 4-step k loop)"""
+    B, Hp, Wp = 3, 14, 14
+    x = rnd(B * Hp * Wp, C, dtype=torch.bfloat16)
+    w, b = rnd(5 * heads, C, seed=1, scale=0.1), rnd(5 * heads, seed=2)
+    R = B * 4
+    avg, pooled, y = e(R, C), e(R, C), e(R, 5 * heads)
+    ops.rvsa_sampling_fwd(dev(x, torch.bfloat16), dev(w), dev(b), avg, pooled, y, B, Hp, Wp)
+    ar, pr = O.rvsa_pool_fwd(x, B, Hp, Wp)
+    assert rel_err(avg.cpu(), ar) < 1e-5 and rel_err(pooled.cpu(), pr) < 1e-5 and rel_err(y.cpu(), pr @ w.t() + b) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Hp,Wp", [(14, 14), (16, 12)])
 def test_rvsa_pool_and_small_linear(ops, dtype, Hp, Wp):

@@ -61,6 +61,18 @@ def main():
         dyb = r(T, 4 * C)
         t = timeit(lambda: ops.colsum(dyb, torch.empty(4 * C, device=dev)))
         print("colsum T x 4C bf16: %.1f us %.0f GB/s" % (t * 1e6, T * 4 * C * 2 / t / 1e9))
+    if "samp" in which:
+        # the RVSA sampling heads of one block: window pooling + LeakyReLU + the stacked (5 * heads, C) linear layer; rotating inputs (in the step ln1 is fresh every block)
+        xs = [r(T, C) for _ in range(6)]
+        wS, bS = torch.randn(5 * H, C, device=dev) * 0.02, torch.zeros(5 * H, device=dev)
+        avg, pooled, samp = torch.empty(256, C, device=dev), torch.empty(256, C, device=dev), torch.empty(256, 5 * H, device=dev)
+        it = [0]
+
+        def f():
+            it[0] += 1
+            ops.rvsa_sampling_fwd(xs[it[0] % 6], wS, bS, avg, pooled, samp, 64, 14, 14)
+        t = timeit(f, iters=60)
+        print("rvsa_sampling_fwd: %.1f us  (MTP_SAMPLING_YSPLIT=%s)" % (t * 1e6, __import__("os").environ.get("MTP_SAMPLING_YSPLIT", "default")))
     if "attn" in which:
         qkv = r(T, 3 * C)
         o, lse = torch.empty(T, C, device=dev, dtype=bf), torch.empty(64 * H * 196, device=dev)
