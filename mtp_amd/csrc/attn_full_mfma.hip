@@ -275,7 +275,7 @@ __device__ __forceinline__ uint4 kt_frag_tr(const char* Ks, int key0, int dt, in
 
 // NW waves per workgroup: 8 (two per SIMD, the second hides the first one's LDS / exp latency) when the per-wave tiles fit next to
 // the K / V images, else 4.  K^T fragments for dQ^T = K^T.dS^T come out of the row-major K image with the hardware transpose read
-// (ds_read_b64_tr_b16; layout probed in tools/tr_probe.hip) -- the separate K^T image of round 1 (29 KiB) is gone.
+// (ds_read_b64_tr_b16; layout probed in tools/probes/tr_probe.hip) -- the separate K^T image of round 1 (29 KiB) is gone.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void full_bwd_a_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, bf16_t* __restrict__ dqkv,

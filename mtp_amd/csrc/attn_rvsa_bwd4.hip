@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd4_mfma_kernel(const bf16_t* __
     }
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
     if (lane == 0) {   // per-wave partials, summed in a fixed order: LDS atomics here made dsamp differ by an ulp from run to run,
-                       // and downstream bf16 roundings turned that into 1e-4 gradient differences (tools/race_finder.py)
+                       // and downstream bf16 roundings turned that into 1e-4 gradient differences (tools/probes/race_finder.py)
         vsum[8 * wave + 0] = v0; vsum[8 * wave + 1] = v1; vsum[8 * wave + 2] = v2; vsum[8 * wave + 3] = v3; vsum[8 * wave + 4] = v4;
     }
     __syncthreads();

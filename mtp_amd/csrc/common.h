@@ -135,7 +135,7 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
 }
 
-// ---- lane exchanges without the LDS crossbar (round 5; probed in round 4: tools/dpp_probe.hip, profiles/r04_dpp_probe.txt) --------------------
+// ---- lane exchanges without the LDS crossbar (round 5; probed in round 4: tools/probes/dpp_probe.hip, profiles/r04_dpp_probe.txt) --------------------
 // hipcc turns every __shfl_xor into ds_bpermute_b32: an LDS instruction and an LDS round trip on the dependent chain (312 clocks per dependent 16-lane
 // butterfly against 88 with DPP).  The partners lane ^ 1 / 2 / 4 / 8 sit inside a 16-lane row and are reachable with DPP modifiers (xor 1, 2, 3 =
 // quad_perm; xor 7 = row_half_mirror; xor 15 = row_mirror; xor 4 = 7 o 3, xor 8 = 15 o 7); lane ^ 16 and lane ^ 32 cross rows: v_permlane16_swap /

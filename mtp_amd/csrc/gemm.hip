@@ -445,7 +445,7 @@ __global__ __launch_bounds__(NT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 // each) plus the fragment reads than the SIMDs spend on MFMAs.  Here both operand tiles go HBM -> LDS as they lie in memory
 // ([64 t rows][128 x] bf16 = 256-B rows, global_load_lds x16B, no VGPR/ds_write traffic) and the MFMA fragments come out of
 // ds_read_b64_tr_b16: a 16-lane group hands in the addresses of a [4 t][16 x] block (lane i: row i>>2, columns 4(i&3)..+3)
-// and lane i gets column i, rows 0..3 -- measured on gfx950 with tools/tr_probe.hip.  Two reads = the 8 consecutive k of
+// and lane i gets column i, rows 0..3 -- measured on gfx950 with tools/probes/tr_probe.hip.  Two reads = the 8 consecutive k of
 // one MFMA operand.  Swizzle: 32-B slot pair ^= f(t), f = (t&3) | (t>>3 & 1)<<2, so that the 8 rows a 32-lane group touches
 // ({0..3, 8..11} + const) fall on 8 different bank octets; applied on the per-lane SOURCE address of the DMA.
 typedef short tr_v4s __attribute__((ext_vector_type(4)));
@@ -591,7 +591,7 @@ int nt_p8_mode(const mtp_gemm_args* a, const KArgs& k, int cus) {
     // default: the pipelined kernel once its 256-wide tiles occupy a good part of the 256 CUs (one workgroup per CU); below that the
     // 128-wide kernels with 4 workgroups per CU spread a small problem better.  Measured on the ViT-L shapes (tools/ab_gemm.py):
     // +15 % (N = 3072 / 4096, K = 1024) ... +25 % (N = 1024, K = 3072 / 4096), +23 % on the FPN GEMM; on the mid-size shapes of
-    // InternImage-XL's 768- / 1536-channel levels and of ViT-B at batch 32 (tools/ab_gemm_mid.py, round 3): 96 tiles +6 % (K = 768) /
+    // InternImage-XL's 768- / 1536-channel levels and of ViT-B at batch 32 (tools/probes/ab_gemm_mid.py, round 3): 96 tiles +6 % (K = 768) /
     // +17 % (K = 3072), 75 tiles +3 % / +16 %, 48 tiles +5 % (K = 1536) / +14 % (K = 6144), but 64 tiles of which half are mostly edge
     // (N = 432, K = 768) -19 %: from 72 tiles on, or from 40 when the contraction is long.
     // (cus: the CUs of the stream, 256 unless it is CU-masked -- the thresholds are fractions of a round)

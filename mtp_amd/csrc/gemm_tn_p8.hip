@@ -12,7 +12,7 @@
 //
 // Operands are token-major as they lie in memory ([t][feature], feature contiguous): both go HBM -> LDS untransposed by LDS-DMA
 // and the MFMA fragments (8 consecutive t per lane) come out of the gfx950 transpose read ds_read_b64_tr_b16 -- the layout of
-// gemm_tn_tr_kernel (gemm.hip; probed with tools/tr_probe.hip): half tile = [64 t][128 features] (256-B rows), 32-B slot pair
+// gemm_tn_tr_kernel (gemm.hip; probed with tools/probes/tr_probe.hip): half tile = [64 t][128 features] (256-B rows), 32-B slot pair
 // (16 features) ^= f(t), f = (t & 3) | ((t >> 3) & 1) << 2, applied on the per-lane DMA SOURCE address.  A-half h holds the
 // feature columns "sub-tile h" of the two wave rows, B-half j the columns "sub-tile j" of the four wave columns, as in the NT
 // kernel, so the phase schedule is shared -- but here a half tile is 128 CONSECUTIVE columns and a wave's sub-tiles are strips

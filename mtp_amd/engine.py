@@ -165,7 +165,7 @@ class BackboneEngine:
     def warm_streams(self, device):
         """create AND use the weight-gradient side stream now: the HIP runtime hands a stream its hardware queue at first use, in the order of first uses.  A library
         that creates streams of its own in between (RCCL at communicator creation) otherwise pushes the side stream onto the compute stream's queue -- measured in
-        round 6: 34.6 -> 47 ms per step when the C-ABI communicator was created before the first backward (tools/native_comm_probe.py)."""
+        round 6: 34.6 -> 47 ms per step when the C-ABI communicator was created before the first backward (tools/probes/native_comm_probe.py)."""
         self.dev = torch.device(device)
         st = self._wgrad_stream()
         if st is not None:

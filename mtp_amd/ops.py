@@ -89,7 +89,7 @@ def gemm_nt_tile(a, w, out, epi=EPI_BIAS, bias=None, bias_mod=0, res=None, res_m
 
 def pick_split_k(M, N, K):
     """enough (tile, split) work items for >= 2 resident workgroups on each of the 256 CUs"""
-    # measured on MI355X (tools/ab_tn.py): ~512 work items (2 per CU) is the sweet spot; odd splits are consistently slower
+    # measured on MI355X (tools/probes/ab_tn.py): ~512 work items (2 per CU) is the sweet spot; odd splits are consistently slower
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     split = max(1, min(16, round(512 / tiles)))
     if split > 1 and split % 2:

@@ -1,6 +1,6 @@
 """fc1-shaped NT GEMM (12544 x 4096 x 1024) with each epilogue: how much of the in-model slowdown is the epilogue itself?"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mtp_amd import ops
 from tools.bench_ops import timeit, r

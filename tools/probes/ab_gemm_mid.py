@@ -1,11 +1,11 @@
 """A/B of the NT kernel families on mid-size problems (InternImage-XL levels 2 / 3: 48-128 tiles of 256 x 256 for 256 CUs): the 128-wide kernels of
 gemm.hip (variant 1024 = never the 8-phase kernel) against the 8-phase kernel forced (256 = tile height picked, 512 = 224 rows, 768 = 256 rows).
-usage: python tools/ab_gemm_mid.py [rounds]"""
+usage: python tools/probes/ab_gemm_mid.py [rounds]"""
 import os
 import statistics
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from mtp_amd import ops

@@ -1,11 +1,11 @@
 """Does the AdamW pass (HBM-bound, 8.9 GB) hide under a forward-like chain of NT GEMMs when it runs on a second stream?
 One process: (a) the GEMM chain alone, (b) AdamW alone, (c) both started together -- wall time of each (HIP events on a third stream would
-not see both; host timers around a device synchronize).  usage: python tools/ab_overlap_adamw.py"""
+not see both; host timers around a device synchronize).  usage: python tools/probes/ab_overlap_adamw.py"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from mtp_amd import ops

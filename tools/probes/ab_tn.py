@@ -2,7 +2,7 @@
 variant 0 = transpose-read kernel, automatic tile order; 6 = same kernel, N-fastest order forced; 4 = M-fastest forced;
 16 = register-transposing kernel."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mtp_amd import ops
 from tools.bench_ops import timeit, r

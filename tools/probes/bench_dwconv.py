@@ -1,8 +1,8 @@
-"""depth-wise 3x3 convolution kernels at InternImage-XL's level shapes (N = 8, 512^2 input): forward, data gradient, weight-gradient partials.  python tools/bench_dwconv.py"""
+"""depth-wise 3x3 convolution kernels at InternImage-XL's level shapes (N = 8, 512^2 input): forward, data gradient, weight-gradient partials.  python tools/probes/bench_dwconv.py"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from mtp_amd import ops

@@ -1,5 +1,5 @@
 // Which CUs does a stream created with hipExtStreamCreateWithCUMask use on gfx950 (SPX mode: one device = 8 XCCs x 32 CUs)?
-// Build: hipcc --offload-arch=gfx950 -O2 tools/cu_mask_probe.hip -o gpurun_out/cu_mask_probe ; run under `timeout 60`.
+// Build: hipcc --offload-arch=gfx950 -O2 tools/probes/cu_mask_probe.hip -o gpurun_out/cu_mask_probe ; run under `timeout 60`.
 // For every mask: workgroups per XCC and the number of distinct (XCC, SE, SH, CU) slots touched by a 2048-workgroup launch whose workgroups
 // stay resident ~20 us each; then a bandwidth / MFMA pair on two masked streams (do two halves of the chip run independently?).
 #include <hip/hip_runtime.h>

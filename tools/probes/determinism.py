@@ -1,9 +1,9 @@
 """Run-to-run determinism screen: the same step N times, max relative difference of every gradient against run 0.  f32 atomics
-(RVSA scatter, colsum) reorder sums: ~1e-7.  Anything near 1e-4 is a race.  usage: python tools/determinism.py [runs]"""
+(RVSA scatter, colsum) reorder sums: ~1e-7.  Anything near 1e-4 is a race.  usage: python tools/probes/determinism.py [runs]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import mtp_amd

@@ -1,6 +1,6 @@
 """Op-level run-to-run screen of the RVSA backward: same inputs N times, every output against run 0 (max abs diff / max abs)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mtp_amd import ops
 from tools.bench_ops import r

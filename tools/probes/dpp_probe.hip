@@ -4,7 +4,7 @@
 //   xor 7 = row_half_mirror (0x141), xor 15 = row_mirror (0x140); xor 4 = xor 7 o xor 3, xor 8 = xor 15 o xor 7.
 // Checks the mapping lane by lane, the 16-lane butterfly sum against the __shfl_xor form (bit-identical for the mirror order the sums take),
 // and times a dependent chain of butterflies both ways (clock64 around the loop of one wave per workgroup x 4 waves).
-// Build + run on an MI355X:  hipcc -O2 --offload-arch=gfx950 tools/dpp_probe.hip -o tools/_abl/dpp_probe && tools/_abl/dpp_probe
+// Build + run on an MI355X:  hipcc -O2 --offload-arch=gfx950 tools/probes/dpp_probe.hip -o tools/_abl/dpp_probe && tools/_abl/dpp_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -1,10 +1,10 @@
 """Is the NT kernel's epilogue burst bound per CU or by the chip?  Time T(K) of the 8-phase kernel at fixed (M, N) for several K and fit T = a + b K: `a` is everything that is not
 the K loop (prologue + epilogue).  Same N, three M: 224 / 112 / 56 tiles of 224 x 256 -- one tile per CU each, on all / half / a quarter of the CUs.  If `a` shrinks with fewer
-active CUs the burst is limited by the shared write path (HBM / fabric), not by a CU's own store issue.   python tools/epilogue_probe.py"""
+active CUs the burst is limited by the shared write path (HBM / fabric), not by a CU's own store issue.   python tools/probes/epilogue_probe.py"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from mtp_amd import ops

@@ -1,6 +1,6 @@
 """Fit t = a * GFLOP + b * MB + c to the NT-GEMM dispatches of a rocprofv3 kernel trace.
 
-    python tools/gemm_time_model.py profiles/r01_gemm_nt_trace.csv
+    python tools/probes/gemm_time_model.py profiles/r01_gemm_nt_trace.csv
 
 Input: rows (kernel, workgroups, duration_us) of every gemm_nt dispatch of `bench.py --steps 4 --warmup 2` (ViT-L, B = 64,
 224^2, bf16), extracted from the kernel trace.  The trace does not carry M, N, K: each (kernel template, grid) group is split

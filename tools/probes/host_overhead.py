@@ -1,6 +1,6 @@
 """host enqueue time vs GPU time of one training step (is the step launch-bound?)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mtp_amd
 from mtp_amd.parallel import DataParallelTrainer

@@ -1,4 +1,4 @@
-"""static instruction mix of one kernel in a `hipcc -S` listing: python tools/isa_mix.py file.s kernel_substring"""
+"""static instruction mix of one kernel in a `hipcc -S` listing: python tools/probes/isa_mix.py file.s kernel_substring"""
 import collections
 import re
 import sys

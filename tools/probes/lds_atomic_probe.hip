@@ -1,6 +1,6 @@
 // Probe: cost of LDS float atomics (ds_add_f32, no return) on gfx950 next to plain ds_write / ds_read, for the access patterns a
 // tile-accumulating DCNv3 backward would produce.  Build + run on an MI355X:
-//   hipcc -O2 -munsafe-fp-atomics --offload-arch=gfx950 tools/lds_atomic_probe.hip -o tools/_abl/lds_atomic_probe && tools/_abl/lds_atomic_probe
+//   hipcc -O2 -munsafe-fp-atomics --offload-arch=gfx950 tools/probes/lds_atomic_probe.hip -o tools/_abl/lds_atomic_probe && tools/_abl/lds_atomic_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int MODE>

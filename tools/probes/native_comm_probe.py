@@ -1,7 +1,7 @@
 """Why does the step slow down when the gradient exchange goes through the C-ABI RCCL communicator (world size 1, MTP_FORCE_COMM=1)?
-host enqueue vs total time of the step, thread count; exchange on / off.   MTP_NATIVE_COMM=0|1 python tools/native_comm_probe.py"""
+host enqueue vs total time of the step, thread count; exchange on / off.   MTP_NATIVE_COMM=0|1 python tools/probes/native_comm_probe.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1", MTP_FORCE_COMM="1")
 import torch

@@ -1,12 +1,12 @@
 """Which op is not run-to-run deterministic?  Wraps every function of mtp_amd.ops: after each call (device synchronised) a
 checksum of every tensor argument (sum and sum of squares in f64) is logged.  The same step is run N times; the first log
 entry that differs from run 0 names the op whose OUTPUT changed while all earlier entries (its inputs) were identical.
-usage: python tools/race_finder.py [runs]"""
+usage: python tools/probes/race_finder.py [runs]"""
 import os
 import sys
 import types
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import mtp_amd

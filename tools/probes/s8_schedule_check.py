@@ -4,7 +4,7 @@ one-barrier stagger of the two wave groups, for a stream of NT K-tiles.  Same me
 Model: group 0 runs the read part R_g of phase g in interval 2g and its MFMAs in 2g+1, group 1 one interval later; an interval ends at
 a barrier.  A wave's loads complete in issue order; `s_waitcnt vmcnt(N)` in R_g guarantees every load except the N youngest.  Adversary:
 a load is taken to land as LATE as the waits allow when it is read (RAW) and as EARLY as its issue when it overwrites (WAR).
-usage: python tools/s8_schedule_check.py [k_tiles_total]"""
+usage: python tools/probes/s8_schedule_check.py [k_tiles_total]"""
 import sys
 
 NT = int(sys.argv[1]) if len(sys.argv) > 1 else 40      # K-tiles of the flattened stream

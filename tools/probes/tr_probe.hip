@@ -1,5 +1,5 @@
 // Probe of the gfx950 LDS transpose read (ds_read_b64_tr_b16): which lane gets which element.  Build + run on an MI355X:
-//   hipcc -O2 --offload-arch=gfx950 tools/tr_probe.hip -o tools/_abl/tr_probe && tools/_abl/tr_probe
+//   hipcc -O2 --offload-arch=gfx950 tools/probes/tr_probe.hip -o tools/_abl/tr_probe && tools/_abl/tr_probe
 // Result (pattern 0): in each 16-lane group, lane i supplies the address of row i>>2, columns 4(i&3)..+3 of a [4][16] b16 block and
 // receives column i, rows 0..3 -- the layout gemm_tn_tr_kernel (mtp_amd/csrc/gemm.hip) is built on.
 #include <hip/hip_runtime.h>

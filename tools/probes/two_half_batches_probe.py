@@ -1,12 +1,12 @@
 """Probe: the forward of ONE batch of 64 against the forwards of its two halves on two streams -- plain streams (round 5: the hardware interleaves the
 workgroups of the two halves on all CUs) and CU-masked streams (round 6, VERDICT r05 #1: each half owns 128 CUs, 16 of every XCC, so M/2 rows on half the CUs keep the
 whole-batch tile quantisation and one half's HBM-bound kernels meet the other half's K loops).  Inference mode only (engine.forward keeps no state between calls
-besides the read-only weight images).   python tools/two_half_batches_probe.py [rounds] [--cu-mask]"""
+besides the read-only weight images).   python tools/probes/two_half_batches_probe.py [rounds] [--cu-mask]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import mtp_amd
