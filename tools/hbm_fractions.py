@@ -25,6 +25,7 @@ FAMILIES = [
     ("rvsa_scatter_gemm (dK_sel / dV_sel rows in, dk / dv token rows out)", "rvsa_scatter_gemm_kernel", "rvsa_scatter_gemm", 2 * NWIN * H * 49 * 64 * 2 + 2 * T * C * 2, "dKs|dVs + dk|dv"),
     ("rvsa_fwd4 (qkv rows in, o + lse out)", "rvsa_fwd4_mfma_kernel", "rvsa_fwd4", T * 3 * C * 2 + T * C * 2 + NWIN * H * 49 * 4, "qkv + o + lse"),
     ("adamw (p, g, m, v in; p, m, v out: 28 B per parameter)", "adamw_kernel", "adamw", 28 * PARAMS, "28 B x parameters"),
+    ("adamw_images (round 6: AdamW + both bf16 images of every GEMM weight in one launch)", "adamw_images_kernel", "adamw", 28 * PARAMS + 4 * 303_000_000, "28 B x parameters + 4 B x GEMM weights"),
     ("weight_images (f32 masters in, bf16 W and W^T images out)", "weight_images_kernel", "weight_images", 303_000_000 * (4 + 2 + 2), "GEMM weights x (4 + 2 + 2) B"),
     ("sqnorm (gradient norm: one read of the flat gradient)", "sqnorm_kernel", "sqnorm", 4 * PARAMS, "4 B x parameters"),
     ("v3_fwd (full attention, <= 16 x 16 grids: qkv in, o + lse out)", "v3_fwd_kernel", "full_v3_fwd", T * 3 * C * 2 + T * C * 2 + B * H * 196 * 4, "qkv + o + lse"),
