@@ -80,7 +80,9 @@ typedef struct {
     int defer_sum;      /* TN with a split-K workspace: 1 = leave the partial tiles in `aux`; the caller reduces them
                          * later with mtp_sum_partials_batch (one launch for the weight gradients of a whole block) */
     int pad_;
-    void* workspace;    /* reserved (rounds 3: scratch of the stream-K form of the pipelined NT kernel, removed in round 4); ignored.   */
+    void* workspace;    /* mtp_gemm_tn_grouped (round 6): optional device float (workspace_bytes >= 4) that receives += sum(C^2) of this
+                         * problem -- the clipping step's gradient norm as a by-product; MTP_ERR_UNSUPPORTED with split_k > 1.  Ignored by
+                         * every other entry (round 3: scratch of the stream-K NT form, removed in round 4).                          */
     int64_t workspace_bytes;
 } mtp_gemm_args;
 
@@ -313,6 +315,9 @@ int mtp_rvsa_attn_bwd(const void* qkv, const float* samp, const void* o, const v
  * one workgroup per entry: split long runs) */
 int mtp_zero_segments_f32(float* base, const int64_t* start, const int64_t* count, int n, mtp_stream_t stream);
 int mtp_sqnorm_f32(const float* g, float* out, int64_t n, mtp_stream_t stream);
+/* out += sum of squares over n runs base[start[i] .. start[i] + count[i]) (device tables, as mtp_zero_segments_f32): the share of the gradient norm that is not a
+ * by-product of mtp_gemm_tn_grouped (mtp_gemm_args.workspace) */
+int mtp_sqnorm_segments_f32(const float* base, const int64_t* start, const int64_t* count, int n, float* out, mtp_stream_t stream);
 /* AdamW over a flat f32 buffer; per-segment weight decay via sorted seg_start[nseg] (element offsets) and seg_wd[nseg];
  * hyper (device, f32[6]) = {lr, beta1, beta2, eps, bias_corr1, bias_corr2}; clip_coef = min(1, max_norm / (sqrt(*sqnorm)+1e-6)) if sqnorm */
 int mtp_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_start, const float* seg_wd, int nseg,

@@ -116,6 +116,7 @@ SIGNATURES = {
     "mtp_rvsa_attn_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, p, p, p, i64, i64, i64, i64, i64, f32, p]),
     "mtp_zero_segments_f32": (i32, [p, p, p, i32, p]),
     "mtp_sqnorm_f32": (i32, [p, p, i64, p]),
+    "mtp_sqnorm_segments_f32": (i32, [p, p, p, i32, p, p]),
     "mtp_adamw_flat": (i32, [p, p, p, p, i64, p, p, i32, p, p, f32, f32, p]),
     "mtp_adamw_weight_images": (i32, [p, i32, i64, i32, p, p, p, p, p, p, f32, f32, p]),
     "mtp_version": (C.c_char_p, []),

@@ -1400,6 +1400,38 @@ extern "C" int mtp_zero_segments_f32(float* base, const int64_t* start, const in
     return mtp_launch_status();
 }
 
+// out += sum of squares over n runs base[start[i] .. start[i] + count[i]) (runs of at most 64 K floats, as mtp_zero_segments_f32): the part of the gradient norm that
+// is not a by-product of the weight-gradient launches (biases, LayerNorm, tables, sampling heads, split problems) -- ~3 % of the buffer
+__global__ __launch_bounds__(256) void sqnorm_segments_kernel(const float* __restrict__ base, const int64_t* __restrict__ start, const int64_t* __restrict__ count, int n,
+                                                              float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int sgm = blockIdx.x; sgm < n; sgm += gridDim.x) {
+        const float* p = base + start[sgm];
+        const int64_t c = count[sgm];
+        if (((start[sgm] | c) & 3) == 0) {      // 16-byte loads (the flat buffers pad every parameter to 64 elements: always, for their tables)
+            for (int64_t i = 4 * threadIdx.x; i < c; i += 1024) {
+                const float4 v = load4(p + i);
+                s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < c; i += 256) {
+                const float v = p[i];
+                s += v * v;
+            }
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int mtp_sqnorm_segments_f32(const float* base, const int64_t* start, const int64_t* count, int n, float* out, mtp_stream_t stream) {
+    if (!base || !start || !count || n <= 0 || !out) return MTP_ERR_ARG;
+    hipLaunchKernelGGL(sqnorm_segments_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, (hipStream_t)stream, base, start, count, n, out);
+    return mtp_launch_status();
+}
+
 extern "C" int mtp_sqnorm_f32(const float* g, float* out, int64_t n, mtp_stream_t stream) {
     if (!g || !out || n <= 0) return MTP_ERR_ARG;
     hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, g, out, n);

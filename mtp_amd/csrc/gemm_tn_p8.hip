@@ -31,6 +31,7 @@ struct TnProb {
     const char* B;      // X  (Kc, N) bf16, ldb
     float* C;           // dW (M, N) f32, ldc
     float* colsum;      // += column sums of A (M entries) or nullptr
+    float* sqn;         // += sum of the squares of this problem's output (unsplit problems; the gradient norm of the clipping step) or nullptr
     int M, N, K;
     int lda, ldb, ldc;
     int tile0, tiles_m, tiles_n;
@@ -248,6 +249,32 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         __syncthreads();
     }
 
+    if (q.sqn) {
+        // squared-norm by-product (round 6): the sum of dW^2 over this tile straight out of the accumulators -- the clipping step then needs no pass over the 97 % of
+        // the gradient buffer these launches write.  acc[nf][4 h + mfl][e] = tile row 64 wr + 128 h + 16 mfl + fr, tile column 32 wc + 128 (c >> 5) + (c & 31) with
+        // c = 16 nf + 4 g + e (the mapping of epilogue_lds<.., 128, 128>); edge tiles mask what lies beyond (M, N)
+        const int fr = lane & 15, gq = lane >> 4;
+        const bool full = m0 + P8_BM <= q.M && n0 + P8_BN <= q.N;
+        float ss = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int hm = 0; hm < 8; ++hm)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[nf][hm][e];
+                    if (full) {
+                        ss += v * v;
+                    } else {
+                        const int row = m0 + wr * 64 + (hm >> 2) * 128 + (hm & 3) * 16 + fr;
+                        const int cc = nf * 16 + gq * 4 + e, col = n0 + wc * 32 + (cc >> 5) * 128 + (cc & 31);
+                        ss += (row < q.M && col < q.N) ? v * v : 0.f;
+                    }
+                }
+        ss = wave_sum(ss);
+        if (lane == 0) atomicAdd(q.sqn, ss);
+    }
+
     KArgs o = {};
     o.C = reinterpret_cast<char*>(q.C + (int64_t)piece * q.M * q.ldc);
     o.M = q.M; o.N = q.N; o.ldc = q.ldc;
@@ -283,6 +310,10 @@ extern "C" int mtp_gemm_tn_grouped(const mtp_gemm_args* args, int count, mtp_str
         }
         TnProb& q = g.p[i];
         q.A = (const char*)a.A; q.B = (const char*)a.B; q.C = splits > 1 ? (float*)a.aux : (float*)a.C; q.colsum = a.colsum;
+        // `workspace` (>= 4 bytes) = a device float that receives += sum(C^2): only for problems whose tiles hold the whole contraction
+        if (a.workspace && splits > 1) return MTP_ERR_UNSUPPORTED;
+        if (a.workspace && (a.workspace_bytes < 4 || ((uintptr_t)a.workspace & 3))) return MTP_ERR_ARG;
+        q.sqn = (float*)a.workspace;
         q.M = (int)a.M; q.N = (int)a.N; q.K = (int)a.K;
         q.lda = (int)a.lda; q.ldb = (int)a.ldb; q.ldc = (int)a.ldc;
         q.tiles_m = (int)((a.M + P8_BM - 1) / P8_BM); q.tiles_n = (int)((a.N + P8_BN - 1) / P8_BN);

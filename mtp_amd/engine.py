@@ -283,7 +283,8 @@ class BackboneEngine:
         # (weight gradients: queued, launched together with those of the neighbouring blocks -- ops.WgradQueue)
         wq = self._wq
         ls = pre + "gamma_1" in G
-        wq.add(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], G[pre + "mlp.fc2.bias"], after=(lambda: self._layer_scale_grads(pre, "mlp.fc2", "gamma_2", G)) if ls else None)
+        wq.add(dx2_act, s["h"], G[pre + "mlp.fc2.weight"], G[pre + "mlp.fc2.bias"], after=(lambda: self._layer_scale_grads(pre, "mlp.fc2", "gamma_2", G)) if ls else None,
+               norm_ok=not ls)
         du = ops.gemm_nt(dx2_act, b.w2T, self._e(T, 4 * C), epi=ops.EPI_MUL, aux=s["u"])
         wq.add(du, s["ln2"], G[pre + "mlp.fc1.weight"], G[pre + "mlp.fc1.bias"])
         dln2 = ops.gemm_nt(du, b.w1T, self._e(T, C))
@@ -292,7 +293,8 @@ class BackboneEngine:
         self._ln_bwd(dln2, s["x1"], s["mean2"], s["rstd2"], P[pre + "norm2.weight"], dx1, G[pre + "norm2.weight"], G[pre + "norm2.bias"],
                           dres=dx2, dx_copy=dx1_act, copy_scale=dps[0], rows_per_sample=N)
         # ---- attention branch
-        wq.add(dx1_act, s["o"], G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], after=(lambda: self._layer_scale_grads(pre, "attn.proj", "gamma_1", G)) if ls else None)
+        wq.add(dx1_act, s["o"], G[pre + "attn.proj.weight"], G[pre + "attn.proj.bias"], after=(lambda: self._layer_scale_grads(pre, "attn.proj", "gamma_1", G)) if ls else None,
+               norm_ok=not ls)
         do = ops.gemm_nt(dx1_act, b.wprojT, self._e(T, C))
         dqkv = self._e(T, 3 * C)
         if b.window:
@@ -448,7 +450,7 @@ class BackboneEngine:
         """weight gradient of a 2x2 / stride-2 ConvTranspose2d as the GEMM dy (rows, 4 C_out)^T x (rows, C_in), queued with the blocks'
         weight gradients; the (4 C_out, C_in) image is re-laid into the parameter's (C_in, C_out, 2, 2) right after the launch"""
         dwg = self._e(dy.shape[1], x.shape[1], dtype=F32)
-        self._wq.add(dy, x, dwg, after=lambda: ops.convt_unpack_grad(dwg, gw))
+        self._wq.add(dy, x, dwg, after=lambda: ops.convt_unpack_grad(dwg, gw), norm_of=gw)      # (the re-laid copy holds the same values: same norm)
 
     def _fpn_bwd(self, dfeats, fctx, B, Hp, Wp, G):
         """returns [dtap0..dtap3] (f32 (T,C) each, or None when the feature received no gradient)."""
@@ -502,7 +504,7 @@ class BackboneEngine:
         return out
 
     # ------------------------------------------------------------------ whole backward
-    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None, split_last=False):
+    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None, split_last=False, sqn=None):
         """dfeats: 4 NCHW cotangents (or None).  G: name -> f32 gradient buffer (overwritten; parameters that receive no
         gradient -- `norm.*`, blocks after the last tap -- are left untouched).  on_block_done(i) is called once the gradients
         of block i AND of every block after it (and, for i == -1, of patch-embed / pos-embed) are complete on the current stream:
@@ -510,7 +512,9 @@ class BackboneEngine:
         the burst -- or after every block when nothing is queued (f32 parity mode, shapes the grouped kernel does not take: the
         weight gradients were launched immediately) -- the hook mtp_amd.parallel uses to launch RCCL collectives of contiguous
         gradient slices on a side stream.  split_last: launch what is queued after block 1 as well, so that the last report before
-        the embeddings covers block 0 only (data-parallel runs: that last slice is the part of the exchange nothing overlaps)."""
+        the embeddings covers block 0 only (data-parallel runs: that last slice is the part of the exchange nothing overlaps).
+        sqn (1-element f32 device tensor, zeroed by the caller): the grouped weight-gradient launches add the squared norm of what they write to it
+        (ops.WgradQueue); afterwards self.norm_covered lists those gradient tensors -- the clipping step then sums only the rest (FlatAdamW.step)."""
         B, Cin, H, W, Hp, Wp = ctx["geom"]
         C, N, T = self.C, Hp * Wp, B * Hp * Wp
         P = self.P
@@ -520,6 +524,8 @@ class BackboneEngine:
         # weight gradients (FPN deconvolutions, the blocks' Linears, patch embed) are queued and launched in bursts (ops.WgradQueue)
         self._wq = wq = ops.WgradQueue(stream=self._wgrad_stream())
         wq.max_jobs = self.wgrad_max_jobs if wq.stream is not None else 0      # (on the current stream a burst should be whole rounds of the CUs)
+        wq.sqn = sqn
+        self.norm_covered = wq.covered
         if ctx["fctx"].get("taps_only"):
             dtaps = [None if d is None else ops.nchw_to_tokens((d.contiguous() if d.dtype in (F32, torch.bfloat16) else d.float().contiguous()),
                                                                self._e(T, C, dtype=F32), B, Hp, Wp, 0) for d in dfeats]

@@ -219,8 +219,12 @@ class WgradQueue:
         self.max_jobs = 0    # > 0: a burst goes out as soon as it holds this many problems (A/B of the burst size next to the side stream)
         self.launched = 0    # side-stream launches so far; launched - len(inflight) of them have been waited for by the current stream
         self.after = []      # callables run right after the launch (on its stream): e.g. copying a padded result into the gradient buffer
+        # squared-norm by-product (round 6): with `sqn` (a 1-element f32 device tensor) every unsplit problem of a grouped launch also adds sum(dW^2) to it; `covered`
+        # lists the gradient tensors whose norm has been accounted for that way (the clipping step sums the rest of the buffer only: FlatAdamW.step)
+        self.sqn, self.covered = None, []
 
-    def add(self, dy, x, dw, colsum=None, after=None):
+    def add(self, dy, x, dw, colsum=None, after=None, norm_of=None, norm_ok=True):
+        """norm_of: the gradient tensor dw's values end up in when that is not dw itself (a re-laid copy made by `after`); norm_ok=False: `after` changes the values"""
         K, M = dy.shape
         N = x.shape[1]
         t = grouped_tiles(M, N)
@@ -236,7 +240,10 @@ class WgradQueue:
         assert x.shape[0] == K and dw.dtype == torch.float32 and dw.numel() == M * N and dw.is_contiguous()
         splits = grouped_splits(K, t)
         part = torch.empty(splits, M, N, device=dw.device, dtype=torch.float32) if splits > 1 else None
-        self.jobs.append((dy, x, dw, colsum, splits, part))     # (the references keep dY / X / the partial images alive until the launch)
+        use_sqn = self.sqn is not None and splits == 1 and norm_ok
+        self.jobs.append((dy, x, dw, colsum, splits, part, use_sqn))     # (the references keep dY / X / the partial images alive until the launch)
+        if use_sqn:
+            self.covered.append(dw if norm_of is None else norm_of)
         if after is not None:
             self.after.append(after)
         self.tiles += t * splits
@@ -275,7 +282,7 @@ class WgradQueue:
         while self.jobs:
             chunk, self.jobs = self.jobs[:MAX_GROUPED], self.jobs[MAX_GROUPED:]
             arr = (GemmArgs * len(chunk))()
-            for g, (dy, x, dw, cs, splits, part) in zip(arr, chunk):
+            for g, (dy, x, dw, cs, splits, part, use_sqn) in zip(arr, chunk):
                 K, M = dy.shape
                 N = x.shape[1]
                 g.A, g.B, g.C = _p(dy), _p(x), _p(dw)
@@ -284,6 +291,8 @@ class WgradQueue:
                 g.in_dtype, g.out_dtype, g.variant = MTP_BF16, MTP_F32, self.variant
                 if splits > 1:
                     g.split_k, g.aux = splits, _p(part)
+                if use_sqn:
+                    g.workspace, g.workspace_bytes = _p(self.sqn), 4
                 if cs is not None:
                     assert cs.dtype == torch.float32 and cs.numel() == M and cs.is_contiguous()
                     g.colsum = _p(cs)
@@ -761,6 +770,13 @@ def zero_segments(base, start, count):
 
 def sqnorm(g, out):
     check(lib().mtp_sqnorm_f32(_f32(g), _f32(out), g.numel(), _s()), "mtp_sqnorm_f32")
+    return out
+
+
+def sqnorm_segments(base, start, count, out):
+    """out += sum(base[start[i] : start[i] + count[i]] ** 2) over the int64 device tables start / count (one launch)"""
+    assert base.dtype == torch.float32 and start.dtype == torch.int64 and count.dtype == torch.int64 and start.numel() == count.numel()
+    check(lib().mtp_sqnorm_segments_f32(_p(base), start.data_ptr(), count.data_ptr(), start.numel(), _f32(out), _s()), "mtp_sqnorm_segments_f32")
     return out
 
 

@@ -464,8 +464,37 @@ class FlatAdamW:
         self._fused = ops.AdamWImages.build(self.flat, wimg, wd)
         return self._fused is not None
 
-    def step(self):
-        """returns True when the step also refreshed the engine's weight images (fuse_images)"""
+    def _rest_table(self, covered):
+        """device tables (start, count) of the runs of [0, reduced) that `covered` (gradient tensors inside the flat buffer) leaves out, in pieces of at most 8 K
+        floats (one workgroup each, 16-byte loads); cached by the covered ranges (the same every step for one model / schedule).  None when a tensor is not a slice of the flat gradient buffer."""
+        f = self.flat
+        base, item = f.grad.data_ptr(), 4
+        rng = []
+        for t in covered:
+            off = t.data_ptr() - base
+            if off < 0 or off % item or off // item + t.numel() > f.reduced or not t.is_contiguous():
+                return None
+            rng.append((off // item, t.numel()))
+        key = tuple(sorted(rng))
+        if getattr(self, "_rest_key", None) != key:
+            ent, pos = [], 0
+            for a, c in key:
+                if a < pos:
+                    return None          # overlapping tensors: not a partition
+                if a > pos:
+                    ent += [(pos + o, min(8192, a - pos - o)) for o in range(0, a - pos, 8192)]
+                pos = a + c
+            if pos < f.reduced:
+                ent += [(pos + o, min(8192, f.reduced - pos - o)) for o in range(0, f.reduced - pos, 8192)]
+            dev = f.grad.device
+            self._rest_tab = (torch.tensor([e[0] for e in ent], dtype=torch.int64, device=dev), torch.tensor([e[1] for e in ent], dtype=torch.int64, device=dev)) if ent else None
+            self._rest_key = key
+        return self._rest_tab if self._rest_tab is not None else ()
+
+    def step(self, norm_covered=None):
+        """returns True when the step also refreshed the engine's weight images (fuse_images).
+        norm_covered: gradient tensors whose squared norm the weight-gradient launches have ALREADY added to self.sqn (BackboneEngine.backward(sqn=...)): only the
+        rest of the buffer is summed here.  None: one pass over the whole gradient buffer (every world size > 1: the norm is that of the REDUCED gradients)."""
         from . import ops
         self.scheduler_step()
         self.t += 1
@@ -475,8 +504,12 @@ class FlatAdamW:
         gs = 1.0 / self.world
         sq = None
         if self.max_norm and self.max_norm > 0:
-            self.sqn.zero_()
-            ops.sqnorm(f.grad[:n], self.sqn)
+            rest = self._rest_table(norm_covered) if norm_covered else None
+            if rest is None:
+                self.sqn.zero_()
+                ops.sqnorm(f.grad[:n], self.sqn)
+            elif len(rest):
+                ops.sqnorm_segments(f.grad, rest[0], rest[1], self.sqn)
             sq = self.sqn
         self.sched_pending = True     # scheduler.step() of MAIN:832 happens after the save point: see __init__
         if getattr(self, "_fused", None) is not None:
@@ -572,13 +605,22 @@ class DataParallelTrainer:
         self.reducer.begin_step()
         feats, ctx = self.engine.forward(img, training=True, need_grad=True, feature_dtype=self.feature_dtype)
         loss, dfeats = loss_and_grads(feats)
+        # the gradient norm of the clipping step as a by-product of the weight-gradient launches (one rank only: with an exchange the norm is that of the REDUCED
+        # gradients; MTP_FUSED_SQNORM=0: always the separate pass)
+        fold = (self.world == 1 and not self.reducer.active and self.flat.grad.is_cuda and bool(self.opt.max_norm) and os.environ.get("MTP_FUSED_SQNORM", "1") != "0"
+                and "sqn" in self.engine.backward.__code__.co_varnames)
+        kw = {}
+        if fold:
+            self.opt.sqn.zero_()
+            kw["sqn"] = self.opt.sqn
         # (split_last: with collectives in flight, block 0's weight gradients go out on their own so that only ~50 MB stay exposed)
-        self.engine.backward(ctx, dfeats, self.flat.G, on_block_done=self.reducer.on_block_done, split_last=self.reducer.active)
+        self.engine.backward(ctx, dfeats, self.flat.G, on_block_done=self.reducer.on_block_done, split_last=self.reducer.active, **kw)
         self.reducer.finish()
+        covered = list(getattr(self.engine, "norm_covered", None) or []) if fold else None
         wimg = getattr(self.engine, "_wimg", None)
         if getattr(self.opt, "_fused_for", 0) is not wimg:       # (first step, or the engine rebuilt its image buffers)
             self.opt.fuse_images(wimg if not getattr(self.engine, "_ls", None) else None)
-        fresh = self.opt.step()
+        fresh = self.opt.step(norm_covered=covered)
         self.engine._key = None   # parameters changed under torch's version counters: rebuild the GEMM weight images next forward ...
         self.engine._images_fresh = bool(fresh)       # ... unless the optimizer kernel has just written them (the packed ConvT / convolution weights still follow)
         return loss

@@ -184,3 +184,34 @@ def test_fused_adamw_writes_the_weight_images_it_would_otherwise_need_a_second_p
     # (two runs of the same configuration differ in the last bits: f32-atomic summation order in a few gradient by-products)
     for x, y in zip(a[:3], b[:3]):
         assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())
+
+
+def test_gradient_norm_as_a_by_product_of_the_weight_gradient_launches(monkeypatch):
+    """round 6: on one rank the grouped weight-gradient launches add sum(dW^2) of what they write to the optimizer's accumulator (mtp_gemm_args.workspace) and the
+    clipping step sums only the rest of the flat buffer (mtp_sqnorm_segments_f32) -- the same norm as one pass over the whole buffer, the same update."""
+    import mtp_amd
+    from mtp_amd.parallel import DataParallelTrainer
+    img = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda()      # 6272 token rows: the grouped kernel takes the problems
+
+    def run(fold):
+        monkeypatch.setenv("MTP_FUSED_SQNORM", "1" if fold else "0")
+        torch.manual_seed(5)
+        net = mtp_amd.ViT_Win_RVSA_V3_WSZ7(img_size=224, embed_dim=256, depth=4, num_heads=4, interval=2, qkv_bias=True, use_abs_pos_emb=True,
+                                           out_indices=[0, 1, 2, 3], drop_path_rate=0.0, precision="bf16")
+        tr = DataParallelTrainer(net.cuda().train(), lr=1e-3, total_steps=10, max_norm=0.05)      # (a norm bound that clips: the coefficient matters)
+        for _ in range(2):
+            tr.step(img, _loss)
+        torch.cuda.synchronize()
+        n = tr.flat.reduced
+        want = float((tr.flat.grad[:n].double() ** 2).sum())
+        got = float(tr.opt.sqn.item())
+        cov = list(tr.engine.norm_covered)
+        return want, got, cov, None, tr
+    w0, g0, c0, p0, _ = run(False)
+    w1, g1, c1, p1, tr = run(True)
+    assert abs(g0 - w0) <= 1e-5 * w0 and abs(g1 - w1) <= 1e-5 * w1
+    assert len(c1) >= 4 * 4 + 1 and len(c0) == 0                          # the blocks' four Linear weights + the patch embedding (+ unsplit FPN weights)
+    covered = sum(t.numel() for t in c1)
+    assert covered > 0.8 * tr.flat.reduced
+    assert tr.opt._rest_tab is not None and int(tr.opt._rest_tab[1].sum()) == tr.flat.reduced - covered      # the rest table is the complement
+    # (the parameters of two runs are not compared: Adam's first steps are +- lr per element, and the f32-atomic by-products flip the sign of near-zero gradients)
