@@ -133,6 +133,18 @@ __device__ __forceinline__ void put_col_t_bits(char* img, int col, const uint4 (
 }
 
 
+typedef short tr4s_t __attribute__((ext_vector_type(4)));
+// transposed fragment out of a row-major swizzled bf16 image (ds_read_b64_tr_b16): lane (fr, gq) gets column 16 dt + fr of rows row0 .. row0 + 3 and row0 + 16 .. + 19
+__device__ __forceinline__ uint4 rows_frag_tr(const char* img, int row0, int dt, int fr) {
+    const int c = 16 * dt + 4 * (fr & 3);
+    const int ra = row0 + (fr >> 2), rb = ra + 16;
+    const int oa = ra * 128 + (((c >> 3) ^ (ra & 7)) << 4) + (c & 7) * 2, ob = rb * 128 + (((c >> 3) ^ (rb & 7)) << 4) + (c & 7) * 2;
+    const tr4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4s_t*)(img + oa));
+    const tr4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4s_t*)(img + ob));
+    const uint2 l = __builtin_bit_cast(uint2, lo), hh = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, hh.x, hh.y);
+}
+
 // ===================================================================================================================
 // RVSA forward, 4 waves per (image, window, head): the bilinear gather is split over 256 threads (key x 16-channel quarter)
 // and wave w owns query tile w, so 24 waves share a CU (6 workgroups x 4) instead of 4-6 single-wave problems.
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
                                                             const float* __restrict__ rel_h, const float* __restrict__ rel_w, const float* __restrict__ bias_table,
                                                             RvsaGeom g, float scale) {
     __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
-    __shared__ __attribute__((aligned(16))) char Vt[64 * TP];
+    __shared__ __attribute__((aligned(16))) char Vs[64 * 128];      // V_sel rows like Ks (round 6; it was a [d][key] image written in 2-byte units)
     __shared__ float QR[26 * 64];
     __shared__ float tab[176];
     __shared__ float rec[8 * 64];      // per key: the four neighbour tokens and weights of its bilinear sample
@@ -234,8 +246,7 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
                 }
             }
             *reinterpret_cast<uint4*>(Ks + swz(key, ch)) = pack_bf16x8(ks[0], ks[1], ks[2], ks[3], ks[4], ks[5], ks[6], ks[7]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) *reinterpret_cast<uint16_t*>(Vt + (8 * ch + e) * TP + key * 2) = (uint16_t)f32_to_bf16_bits(vs[e]);
+            *reinterpret_cast<uint4*>(Vs + swz(key, ch)) = pack_bf16x8(vs[0], vs[1], vs[2], vs[3], vs[4], vs[5], vs[6], vs[7]);
         }
     }
     __syncthreads();
@@ -282,8 +293,7 @@ __global__ __launch_bounds__(256, 4) void rvsa_fwd4_mfma_kernel(const bf16_t* __
         const uint4 pf = pack_bf16x8(s[2 * kk][0], s[2 * kk][1], s[2 * kk][2], s[2 * kk][3], s[2 * kk + 1][0], s[2 * kk + 1][1], s[2 * kk + 1][2], s[2 * kk + 1][3]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const char* row = Vt + (16 * dt + fr) * TP;
-            oa[dt] = mma(ld8x2(row + (32 * kk + 4 * gq) * 2, row + (32 * kk + 16 + 4 * gq) * 2), pf, oa[dt]);
+            oa[dt] = mma(rows_frag_tr(Vs, 32 * kk + 4 * gq, dt, fr), pf, oa[dt]);      // V^T fragment (d = 16 dt + fr; keys 32 kk + 4 gq .. + 3, + 16 ..) by transpose read
         }
     }
     if (qtok >= 0) {
