@@ -7,6 +7,7 @@
 namespace {
 
 constexpr int HD = 64;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
 constexpr int TP = 136;   // byte pitch of the transposed [d][key|query] bf16 images (128 + 8: conflict-free 8-byte reads)
 
 struct RvsaGeom {
@@ -301,8 +302,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd5_mfma_kernel(const bf16_t* __
             const uint32_t aw[4] = {da[gi].x, da[gi].y, da[gi].z, da[gi].w}, cw[4] = {oc[gi].x, oc[gi].y, oc[gi].z, oc[gi].w};
             float dl = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                dl += bf16_bits_to_f32(aw[e] & 0xffffu) * bf16_bits_to_f32(cw[e] & 0xffffu) + bf16_bits_to_f32(aw[e] >> 16) * bf16_bits_to_f32(cw[e] >> 16);
+            for (int e = 0; e < 4; ++e) dl = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, aw[e]), __builtin_bit_cast(bf16x2v_t, cw[e]), dl, false);
             dl += lane_xor<1>(dl);
             dl += lane_xor<2>(dl);
             dl += lane_xor<4>(dl);
@@ -513,18 +513,21 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd5_mfma_kernel(const bf16_t* __
         for (int gi = 0; gi < 2; ++gi) {
             const int key = (wave + 4 * gi) * 8 + kl, kc = key < 48 ? key : 48;
             const float fx = smp[0 * 64 + kc], fy = smp[1 * 64 + kc];
-            float dk[8], dv[8];
-            load8(reinterpret_cast<const bf16_t*>(Pimg + swz(key, ch)), dk);
-            load8(reinterpret_cast<const bf16_t*>(dSimg + swz(key, ch)), dv);
+            // dK_sel / dV_sel chunk (8 bf16 each, as stored) . neighbour row chunk with v_dot2c_f32_bf16: two exact bf16 products + f32 accumulate per instruction
+            // (round 6: unpacked to f32 it was 16 conversions + 16 multiply-adds per neighbour)
+            const uint4 dkq = *reinterpret_cast<const uint4*>(Pimg + swz(key, ch)), dvq = *reinterpret_cast<const uint4*>(dSimg + swz(key, ch));
+            const uint32_t dkw[4] = {dkq.x, dkq.y, dkq.z, dkq.w}, dvw[4] = {dvq.x, dvq.y, dvq.z, dvq.w};
             float dix = 0.f, diy = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t kw[4] = {kq[gi][k].x, kq[gi][k].y, kq[gi][k].z, kq[gi][k].w}, vw[4] = {vq[gi][k].x, vq[gi][k].y, vq[gi][k].z, vq[gi][k].w};
-                float dot = 0.f;
+                float dot = 0.f, dot2 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    dot += dk[2 * e] * bf16_bits_to_f32(kw[e] & 0xffffu) + dk[2 * e + 1] * bf16_bits_to_f32(kw[e] >> 16)
-                         + dv[2 * e] * bf16_bits_to_f32(vw[e] & 0xffffu) + dv[2 * e + 1] * bf16_bits_to_f32(vw[e] >> 16);
+                for (int e = 0; e < 4; ++e) {
+                    dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, dkw[e]), __builtin_bit_cast(bf16x2v_t, kw[e]), dot, false);
+                    dot2 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, dvw[e]), __builtin_bit_cast(bf16x2v_t, vw[e]), dot2, false);
+                }
+                dot += dot2;
                 dot = live[gi][k] ? dot : 0.f;
                 dot += lane_xor<1>(dot);
                 dot += lane_xor<2>(dot);
