@@ -21,7 +21,7 @@ PEAK = 8.0e12
 FAMILIES = [
     ("ln_fwd (norm1 / norm2: f32 x in, bf16 y out, 2 f32 stats per row)", "ln_fwd_kernel<float", "ln_fwd_kernel", T * C * (4 + 2) + T * 8, "x f32 + y bf16 + mean / rstd"),
     ("ln_bwd (dy bf16 + x f32 + residual-gradient f32 in; dx f32 + dx bf16 copy out; partial d-gamma / d-beta rows)", "ln_bwd_kernel", "ln_bwd_kernel", T * C * (2 + 4 + 4 + 4 + 2), "dy + x + dres + dx + dx_act"),
-    ("rvsa_bwd4 (qkv rows gathered, o, do, lse in; dq rows + dK_sel / dV_sel rows + table partials out)", "rvsa_bwd4_mfma_kernel", "rvsa_bwd4", T * 3 * C * 2 + 2 * T * C * 2 + T * C * 2 + 2 * NWIN * H * 49 * 64 * 2 + NWIN * H * (26 * 64 + 169) * 4, "qkv + o + do + dq + dKs|dVs + partials"),
+    ("rvsa_bwd4 (qkv rows gathered, o, do, lse in; dq rows + dK_sel / dV_sel rows + table partials out)", "rvsa_bwd", "rvsa_bwd4", T * 3 * C * 2 + 2 * T * C * 2 + T * C * 2 + 2 * NWIN * H * 49 * 64 * 2 + NWIN * H * (26 * 64 + 169) * 4, "qkv + o + do + dq + dKs|dVs + partials"),
     ("rvsa_scatter_gemm (dK_sel / dV_sel rows in, dk / dv token rows out)", "rvsa_scatter_gemm_kernel", "rvsa_scatter_gemm", 2 * NWIN * H * 49 * 64 * 2 + 2 * T * C * 2, "dKs|dVs + dk|dv"),
     ("rvsa_fwd4 (qkv rows in, o + lse out)", "rvsa_fwd4_mfma_kernel", "rvsa_fwd4", T * 3 * C * 2 + T * C * 2 + NWIN * H * 49 * 4, "qkv + o + lse"),
     ("adamw (p, g, m, v in; p, m, v out: 28 B per parameter)", "adamw_kernel", "adamw", 28 * PARAMS, "28 B x parameters"),

@@ -14,10 +14,10 @@ import os
 import sys
 
 FAMILIES = [("gemm_nt", "gemm_nt_kernel"), ("gemm_tn_p8", "gemm_tn_kernel"), ("gemm_tn", "gemm_tn_split_kernel"), ("sum_partials", "sum_partials"), ("ln_fwd", "ln_fwd_kernel"),
-            ("ln_bwd", "ln_bwd_kernel"), ("rvsa_bwd4", "rvsa_bwd4"), ("rvsa_fwd4", "rvsa_fwd4"), ("full_bwd_a", "full_bwd_a"),
+            ("ln_bwd", "ln_bwd_kernel"), ("rvsa_bwd4", "rvsa_bwd4"), ("rvsa_bwd5", "rvsa_bwd4"), ("rvsa_fwd4", "rvsa_fwd4"), ("full_bwd_a", "full_bwd_a"),
             ("full_bwd_b", "full_bwd_b"), ("full_fwd", "full_fwd"), ("v3_bwd_a", "full_v3_bwd_a"), ("v3_bwd_b", "full_v3_bwd_b"), ("v3_fwd", "full_v3_fwd"), ("adamw", "adamw"), ("weight_images", "weight_images"),
             ("reduce_rows", "reduce_rows"), ("colsum", "colsum"), ("dkv_convert", "dkv_convert"), ("small_linear", "small_linear"),
-            ("rvsa_scatter_gemm", "rvsa_scatter_gemm"), ("sqnorm", "sqnorm"), ("rvsa_sampling_fwd", "rvsa_sampling_fwd"), ("rvsa_sampling_bwd", "rvsa_sampling_bwd"),
+            ("rvsa_scatter_gemm", "rvsa_scatter_gemm"), ("sqnorm_segments", "sqnorm_segments"), ("sqnorm", "sqnorm"), ("rvsa_sampling_fwd", "rvsa_sampling_fwd"), ("rvsa_sampling_bwd", "rvsa_sampling_bwd"),
             ("transpose_kernel", "transpose"), ("transpose8_bf16_kernel", "transpose")]
 
 
