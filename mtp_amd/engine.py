@@ -73,12 +73,20 @@ class BackboneEngine:
                 torch.mul(P[pre + "mlp.fc2.weight"].detach(), g2[:, None], out=b.w2_s)
                 torch.mul(P[pre + "attn.proj.bias"].detach(), g1, out=b.bproj)
                 torch.mul(P[pre + "mlp.fc2.bias"].detach(), g2, out=b.b2)
-        if not getattr(self, "_images_fresh", False):      # (set by DataParallelTrainer when the optimizer launch wrote the images itself)
+        # (the optimizer launch of DataParallelTrainer writes the images itself and says so: mark_images_fresh -- honoured only while no parameter has been
+        #  touched through torch since, i.e. the version counters still are what they were then)
+        if force or getattr(self, "_images_fresh", None) != key:
             self._wimg.refresh()
-        self._images_fresh = False
+        self._images_fresh = None
         for name, (wg, wgT) in self._fpn.items():
             ops.convt_pack(P[name + ".weight"].detach().contiguous(), wg, wgT)
         self._key = key
+
+    def mark_images_fresh(self):
+        """the GEMM-side weight images have just been written from the current parameters by somebody else (mtp_adamw_weight_images): the next
+        prepare_weights() skips its own image launch -- unless a parameter is modified through torch in between"""
+        self._images_fresh = self._weights_key(self.params())
+        self._key = None
 
     def _build_weight_images(self, P):
         dev = P["patch_embed.proj.weight"].device

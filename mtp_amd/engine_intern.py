@@ -58,6 +58,11 @@ class InternEngine:
             st = self._wstream = torch.cuda.Stream(device=self.dev)
         return st
 
+    def mark_images_fresh(self):
+        P = self.params()
+        self._images_fresh = (self.act,) + tuple((p.data_ptr(), p._version) for p in P.values())
+        self._key = None
+
     def warm_streams(self, device):
         """create and use the weight-gradient side stream now (BackboneEngine.warm_streams: hardware queues go to streams in the order of their first use)"""
         self.dev = torch.device(device)
@@ -80,9 +85,9 @@ class InternEngine:
         if ptrs != self._ptrs:
             self._build(P)
             self._ptrs = ptrs
-        if self._wimg is not None and not getattr(self, "_images_fresh", False):      # (set by DataParallelTrainer when the optimizer launch wrote the images itself)
+        if self._wimg is not None and getattr(self, "_images_fresh", None) != key:      # (BackboneEngine.mark_images_fresh: the optimizer launch wrote them)
             self._wimg.refresh()
-        self._images_fresh = False
+        self._images_fresh = None
         for L in self._padded:
             ops.pack_rows_padded(P[L.name].detach(), L.w, L.wt)
         for k in range(0, len(self._padded), 12):      # the padded layers' biases: R floats each, 12 per launch

@@ -552,7 +552,7 @@ class DataParallelTrainer:
             self.opt.total_steps = int(cnt[2]) or None
             self.opt.sched_pending = bool(int(cnt[3]))
         self.engine._key = None
-        self.engine._images_fresh = False
+        self.engine._images_fresh = None
 
     # ---- encoder checkpoint in the reference's dict format (MAIN:823-829 save, MAIN:483-499 resume) -------------------------
     def checkpoint(self, epoch=0, iteration=None, losses=()):
@@ -594,7 +594,7 @@ class DataParallelTrainer:
         if "scheduler" in ckpt:
             self.opt.load_scheduler_state_dict(ckpt["scheduler"])
         self.engine._key = None
-        self.engine._images_fresh = False
+        self.engine._images_fresh = None
         self.sync_replicas(optimizer_state=True)
         losses = ckpt.get("loss_pretrain", [])
         return ckpt.get("epoch", 0), ckpt.get("iteration", self.opt.t), (losses.tolist() if hasattr(losses, "tolist") else list(losses))
@@ -622,5 +622,6 @@ class DataParallelTrainer:
             self.opt.fuse_images(wimg if not getattr(self.engine, "_ls", None) else None)
         fresh = self.opt.step(norm_covered=covered)
         self.engine._key = None   # parameters changed under torch's version counters: rebuild the GEMM weight images next forward ...
-        self.engine._images_fresh = bool(fresh)       # ... unless the optimizer kernel has just written them (the packed ConvT / convolution weights still follow)
+        if fresh and hasattr(self.engine, "mark_images_fresh"):
+            self.engine.mark_images_fresh()       # ... unless the optimizer kernel has just written them (the packed ConvT / convolution weights still follow)
         return loss

@@ -163,10 +163,19 @@ def test_fused_adamw_writes_the_weight_images_it_would_otherwise_need_a_second_p
             eng._wimg.refresh()
             left = [(None if w is None else w.clone(), None if wt is None else wt.clone()) for _, w, wt, _ in eng._wimg.entries]
         else:
-            assert eng._images_fresh
+            assert eng._images_fresh is not None
             eng._wimg.refresh()          # what the image pass makes of the updated masters
             for (w0, t0), (_, w, wt, _) in zip(left, eng._wimg.entries):
                 assert (w0 is None or torch.equal(w0, w)) and (t0 is None or torch.equal(t0, wt))
+            # a parameter edited through torch after the fused step: the next forward must NOT trust the optimizer's images
+            wq = eng._blk[0].wqkv.clone()
+            with torch.no_grad():
+                tr.module.blocks[0].attn.qkv.weight.mul_(2.0)
+            tr.module(img)
+            assert torch.equal(eng._blk[0].wqkv.float(), wq.float() * 2.0)
+            with torch.no_grad():
+                tr.module.blocks[0].attn.qkv.weight.mul_(0.5)      # (exact: back to the same bits)
+            eng.prepare_weights(force=True)
             # the same update by both kernels from the same state: bit-identical parameters and moments
             from mtp_amd import ops
             f, o = tr.flat, tr.opt
