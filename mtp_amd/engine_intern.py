@@ -150,7 +150,8 @@ class InternEngine:
             self._wq.add(dy, x, G[wname], G[bname])
             return
         tw, tb = self._e(L.Rp, L.C, dtype=F32), torch.zeros(L.Rp, device=self.dev, dtype=F32)
-        self._wq.add(dy, x, tw, tb, after=lambda: ops.copy_segments([tw.view(-1)[:L.R * L.C], tb[:L.R]], [G[wname].view(-1), G[bname]]))
+        self._wq.add(dy, x, tw, tb, after=lambda: ops.copy_segments([tw.view(-1)[:L.R * L.C], tb[:L.R]], [G[wname].view(-1), G[bname]]),
+                     norm_of=G[wname])      # (the padded rows of dy are zero: the padded image has the norm of the part that is copied out)
 
     def _ln(self, x, P, key, out_dtype=None, gelu=False):
         rows = x.shape[0]
@@ -185,7 +186,8 @@ class InternEngine:
         """dy (rows, Cout) ACT.  Weight (+ bias) gradient into G; dx (f32, strided) = / += data gradient when dx is not None"""
         w2, w2t = self._conv[name]
         dw2 = self._e(*w2.shape, dtype=F32)
-        self._wq.add(dy, cols, dw2, (G[bias_name] if bias_name else None), after=lambda: ops.conv3x3_unpack_grad(dw2, G[name]))
+        self._wq.add(dy, cols, dw2, (G[bias_name] if bias_name else None), after=lambda: ops.conv3x3_unpack_grad(dw2, G[name]),
+                     norm_of=G[name])       # (the pad columns of `cols` are zero: same values, re-laid)
         if dx is not None:
             dcols = ops.gemm_nt(dy, w2t, self._e(dy.shape[0], w2.shape[1]))
             ops.col2im3x3(dcols, dx, strides, N, H, W, Cin, stride, accumulate=accumulate)
@@ -342,7 +344,7 @@ class InternEngine:
         return feats, ctx
 
     # ------------------------------------------------------------------ whole backward
-    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None, split_last=False):
+    def backward(self, ctx, dfeats, G, need_input_grad=False, on_block_done=None, split_last=False, sqn=None):
         """dfeats: one NCHW cotangent (or None) per entry of out_indices; G: name -> f32 gradient buffer, zero on entry.
         on_block_done(g): every gradient of layer group g (global layer index; InternImage._flat_param_order) and of all later layers is
         complete on the current stream; -1 = the stem (mtp_amd.parallel.GradReducer launches the all-reduces from it)."""
@@ -352,6 +354,8 @@ class InternEngine:
         self.dev = cols1.device
         self._wq = wq = ops.WgradQueue(stream=self._wgrad_stream())
         wq.max_jobs = self.wgrad_max_jobs if wq.stream is not None else 0
+        wq.sqn = sqn                      # the clipping step's gradient norm as a by-product of the grouped launches (BackboneEngine.backward)
+        self.norm_covered = wq.covered
         pending = []        # side-stream mode: the layers whose bursts are in flight (reported once the current stream has waited for them)
         self._ln_parts = []
         taps = {}

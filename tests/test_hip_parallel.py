@@ -224,3 +224,32 @@ def test_gradient_norm_as_a_by_product_of_the_weight_gradient_launches(monkeypat
     assert covered > 0.8 * tr.flat.reduced
     assert tr.opt._rest_tab is not None and int(tr.opt._rest_tab[1].sum()) == tr.flat.reduced - covered      # the rest table is the complement
     # (the parameters of two runs are not compared: Adam's first steps are +- lr per element, and the f32-atomic by-products flip the sign of near-zero gradients)
+
+
+def test_gradient_norm_by_product_on_internimage():
+    """the same by-product through InternEngine's weight-gradient queue (padded Linear layers and the 3x3 convolutions hand the norm of their re-laid images):
+    the optimizer's accumulator equals the squared norm of the whole gradient buffer"""
+    import mtp_amd
+    import recipe
+    from mtp_amd.parallel import DataParallelTrainer
+    c = recipe.II_CFG
+    torch.manual_seed(3)
+    net = mtp_amd.InternImage(channels=c["channels"], depths=c["depths"], groups=c["groups"], layer_scale=c["layer_scale"], offset_scale=c["offset_scale"],
+                              post_norm=True, drop_path_rate=0.0, precision="bf16")
+    with torch.no_grad():
+        for n, q in net.named_parameters():
+            if ".dcn.offset.weight" in n or ".dcn.mask.weight" in n:
+                q.normal_(0, 0.02)
+    tr = DataParallelTrainer(net.cuda().train(), lr=1e-4, total_steps=10, max_norm=0.05)
+    img = torch.randn(4, 3, 128, 128, generator=torch.Generator().manual_seed(4)).cuda()
+
+    def lg(feats):
+        loss = sum(f.float().mean() for f in feats)
+        return loss, [torch.full_like(f, 1.0 / f.numel()) for f in feats]
+    tr.step(img, lg)
+    tr.step(img, lg)
+    torch.cuda.synchronize()
+    n = tr.flat.reduced
+    want = float((tr.flat.grad[:n].double() ** 2).sum())
+    got = float(tr.opt.sqn.item())
+    assert len(tr.engine.norm_covered) > 0 and abs(got - want) <= 1e-5 * want, (len(tr.engine.norm_covered), got, want)
