@@ -174,8 +174,10 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd5_mfma_kernel(const bf16_t* __
     __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
     __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
     __shared__ __attribute__((aligned(16))) char R2[2 * 64 * 128];      // P | dS images [query][key], later the dK_sel | dV_sel rows
-    __shared__ float QR[26 * 64];
-    __shared__ float dQR[26 * 64];
+    __shared__ float QR[26 * 64];      // (a pitch of 80 floats would take the two-way conflicts out of the phase-A reads, but 1.6 KB more LDS is a workgroup per CU less: 130 vs 108 us)
+    constexpr int DQP = 65;      // row pitch of dQR: with 64 the table-gradient reads (16 lanes = 16 rows of one column) were 16-way bank conflicts --
+                                 // all of the kernel's SQ_LDS_BANK_CONFLICT (1000 cycles per wave; round 6)
+    __shared__ float dQR[26 * DQP];
     __shared__ float tab[176];
     __shared__ float lses[64];
     __shared__ float delta[64];
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd5_mfma_kernel(const bf16_t* __
     if (tid < 176) {
         tab[tid] = tid < 169 ? bias_table[tid * H + h] : 0.f;
     }
-    for (int i = tid; i < 26 * 64; i += 256) dQR[i] = 0.f;
+    for (int i = tid; i < 26 * DQP; i += 256) dQR[i] = 0.f;
     // ---- this wave's query tile: Q / dO fragments and QR = tables x Q^T  (first: these loads depend on nothing, so they are in
     // flight together with the gather's)
     const int qt = wave;
@@ -385,8 +387,8 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd5_mfma_kernel(const bf16_t* __
             for (int r = 0; r < 4; ++r) {
                 const int a = 4 * gq + r;
                 if (a < 7) {
-                    dQR[(aq - a + 6) * 64 + n] = dqh[r] * inv_scale;
-                    dQR[(13 + bq - a + 6) * 64 + n] = dqw[r] * inv_scale;
+                    dQR[(aq - a + 6) * DQP + n] = dqh[r] * inv_scale;
+                    dQR[(13 + bq - a + 6) * DQP + n] = dqw[r] * inv_scale;
                 }
             }
         }
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd5_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
             const int r = 8 * gq + x;
-            e[x] = r < 13 ? dQR[r * 64 + n] : 0.f;
-            f[x] = r < 13 ? dQR[(13 + r) * 64 + n] : 0.f;
+            e[x] = r < 13 ? dQR[r * DQP + n] : 0.f;
+            f[x] = r < 13 ? dQR[(13 + r) * DQP + n] : 0.f;
         }
         const uint4 eh = pack_bf16x8(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
         const uint4 ew = pack_bf16x8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256, 3) void rvsa_bwd5_mfma_kernel(const bf16_t* __
             for (int ks = 0; ks < 2; ++ks) {
                 float v[8];
 #pragma unroll
-                for (int x = 0; x < 8; ++x) v[x] = fr < 13 ? dQR[(t * 13 + fr) * 64 + 32 * ks + 4 * gq + (x & 3) + (x >> 2) * 16] : 0.f;      // queries in the transpose read's slot order
+                for (int x = 0; x < 8; ++x) v[x] = fr < 13 ? dQR[(t * 13 + fr) * DQP + 32 * ks + 4 * gq + (x & 3) + (x >> 2) * 16] : 0.f;      // queries in the transpose read's slot order
                 acc = mma(pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]), rows_frag_tr(Ks, 32 * ks + 4 * gq, dt, fr), acc);
             }
 #pragma unroll
