@@ -44,6 +44,28 @@ def test_bf16_vs_oracle_on_the_same_rounded_inputs(name):
         assert g.dtype == torch.float32 and rel(g.double().cpu(), rg) < 2e-5          # f32 math on identical inputs
 
 
+@pytest.mark.parametrize("name", ["base", "rmc"])
+def test_float16_runs_on_the_f32_kernels_and_float64_is_refused(name):
+    """the reference dispatches float / double / half (dcnv3_cuda.cu:69): float16 operands are accepted -- float32 arithmetic on the same rounded inputs, the
+    output back in float16, float32 gradients as for the reference's promoted half -- and through DCNv3Function with half leaves; float64 raises"""
+    from mtp_amd.ops_dcnv3 import DCNv3Function, dcnv3_backward, dcnv3_forward
+    from oracle import dcnv3_oracle as D
+    t, args, rmc = load_case(name)
+    r = {k: t[k].to(torch.float16) for k in ("input", "offset", "mask", "grad_output")}
+    ref_y = D.dcnv3_forward(r["input"].double(), r["offset"].double(), r["mask"].double(), *args, rmc)
+    ref_g = D.dcnv3_backward(r["input"].double(), r["offset"].double(), r["mask"].double(), *args, r["grad_output"].double(), rmc)
+    x, off, m, G = (r[k].cuda().contiguous() for k in ("input", "offset", "mask", "grad_output"))
+    y = dcnv3_forward(x, off, m, *args, 256, rmc)
+    assert y.dtype == torch.float16 and rel(y.double().cpu(), ref_y) < 1e-3          # one float16 rounding of the output
+    for g, rg in zip(dcnv3_backward(x, off, m, *args, G, 256, rmc), ref_g):
+        assert g.dtype == torch.float32 and rel(g.double().cpu(), rg) < 2e-5
+    xa, oa, ma = x.clone().requires_grad_(True), off.clone().requires_grad_(True), m.clone().requires_grad_(True)
+    DCNv3Function.apply(xa, oa, ma, *args, 256, rmc).backward(G)
+    assert xa.grad.dtype == torch.float16 and rel(xa.grad.double().cpu(), ref_g[0]) < 2e-3
+    with pytest.raises(RuntimeError, match="float64"):
+        dcnv3_forward(x.double(), off.double(), m.double(), *args, 256, rmc)
+
+
 def test_autograd_function_matches_the_extension_calls():
     from mtp_amd.ops_dcnv3 import DCNv3Function, dcnv3_backward
     t, args, rmc = load_case("base")
