@@ -49,6 +49,30 @@ def test_execution_order_and_layout():
     assert st.tolist() == sorted(st.tolist()) and all(s % 4 == 0 for s in st.tolist())
 
 
+def test_rest_table_of_the_gradient_norm_by_product_is_the_complement_of_the_covered_tensors():
+    """FlatAdamW._rest_table (round 6): the weight-gradient launches account for the norm of the tensors they write (`covered`); the table lists exactly the other
+    runs of [0, reduced) in pieces of at most 8192 floats; tensors that are not slices of the flat gradient buffer, or overlap, make it decline (None)"""
+    net = small()
+    flat = FlatParams(net, unused=net._unused_params)
+    opt = FlatAdamW(flat, total_steps=10)
+    names = [n for n in flat.names if flat.groups[n] is not None and n.endswith(".weight") and len(flat.shapes[n]) == 2]
+    covered = [flat.G[n] for n in names]
+    tab = opt._rest_table(covered)
+    start, count = tab
+    assert int(count.max()) <= 8192 and int(count.min()) > 0
+    mask = torch.zeros(flat.reduced, dtype=torch.int32)
+    for a, c in zip(start.tolist(), count.tolist()):
+        mask[a:a + c] += 1
+    for t in covered:
+        off = (t.data_ptr() - flat.grad.data_ptr()) // 4
+        mask[off:off + t.numel()] += 1
+    assert bool((mask == 1).all())                                   # a partition of the reduced range: nothing twice, nothing missing
+    assert opt._rest_table(covered) is tab                           # cached by the covered ranges
+    assert opt._rest_table(covered + [torch.zeros(8)]) is None       # a tensor outside the flat buffer
+    assert opt._rest_table(covered + [covered[0]]) is None           # overlapping tensors
+    assert opt._rest_table([flat.grad[:flat.reduced]]) == ()         # everything covered: nothing left to sum
+
+
 def test_cosine_schedule_and_bias_correction():
     class F:
         pass
