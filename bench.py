@@ -711,7 +711,16 @@ def main():
             except OSError:
                 pass
         ex = red.describe()
-        seen = ex["communicator"].get("nranks") if isinstance(ex.get("communicator"), dict) else (rccl or {}).get("nranks")
+        if isinstance(ex.get("communicator"), dict):
+            seen = ex["communicator"].get("nranks")       # what RCCL says about the communicator the collectives ran on (mtp_comm_info), on every rank
+        else:
+            # torch.distributed's collectives (MTP_NATIVE_COMM=0, or the agreed second choice when mtp_comm_init failed): every rank adds 1 through the
+            # process group's RCCL communicator; rank 0 also has RCCL's own log line, which wins when the two disagree
+            one = torch.ones(1, device="cuda")
+            dist.all_reduce(one)
+            seen = int(round(float(one.item())))
+            if rank == 0 and rccl and rccl.get("nranks") not in (None, seen):
+                seen = rccl.get("nranks")
         if world > 1 and seen != world:
             # the exchange did not run over the communicator the line would claim: no result line
             if rank == 0:

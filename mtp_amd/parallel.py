@@ -199,14 +199,30 @@ class GradReducer:
         # The collectives go through the C ABI (mtp_comm_* -> ncclAllReduce / ncclReduceScatter / ncclAllGather on the side stream): the exchange entry
         # points include/mtp_hip.h advertises are the ones every GPU run exercises (round 6; torch.distributed is the bootstrap: rendezvous, the
         # 128-byte id, barriers).  MTP_NATIVE_COMM=0: torch.distributed's collectives instead (same RCCL underneath).
-        self.native = None
+        self.native, self.native_error = None, None
         if self.stream is not None and os.environ.get("MTP_NATIVE_COMM", "1") != "0":
             from .comm import RcclComm
             # (the exchange stream takes its hardware queue at first use: use it BEFORE RCCL creates the communicator's own streams -- BackboneEngine.warm_streams)
             with torch.cuda.stream(self.stream):
                 torch.zeros(1, device=flat.grad.device).add_(1.0)
             self.stream.synchronize()
-            self.native = RcclComm(group)
+            try:
+                self.native = RcclComm(group)
+            except Exception as e:       # (MTP_NATIVE_COMM=strict: no second choice)
+                if os.environ.get("MTP_NATIVE_COMM") == "strict":
+                    raise
+                self.native_error = "%s: %s" % (type(e).__name__, e)
+            # every rank must exchange through the same library entry: if ANY rank could not create its communicator, all of them use torch.distributed's
+            # collectives (the same RCCL; said on stderr and in describe(), never silently) -- a mixed job would hang in its first collective
+            ok = torch.tensor([0.0 if self.native is None else 1.0], device=flat.grad.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if float(ok.item()) < 1.0:
+                if self.native is not None:
+                    self.native.close()
+                    self.native = None
+                    self.native_error = "another rank could not create its RCCL communicator through the C ABI"
+                import warnings
+                warnings.warn("mtp_comm_init failed (%s): the gradient exchange uses torch.distributed's collectives on the side stream" % self.native_error)
         self.works = []
         self.pending_casts = []   # bf16 mode: (scratch bucket, f32 slice) pairs whose cast back waits for the collective
         self.start = 0
@@ -326,6 +342,8 @@ class GradReducer:
     def describe(self):
         """what bench.py prints about the exchange (library, algorithm knobs in effect)"""
         d = dict(mode=self.mode, wire_dtype="bf16" if self.bf16 else "f32", native_c_abi=self.native is not None, bucket_bytes=self.bucket_bytes)
+        if getattr(self, "native_error", None):
+            d["native_error"] = self.native_error
         if self.native is not None:
             try:
                 d["communicator"] = self.native.info()       # ranks / rank / device / version as RCCL reports them for THIS communicator
