@@ -79,15 +79,21 @@ class InternImage(nn.Module):
         super().__init__()
         if core_op not in ("DCNv3", "DCNv3_pytorch"):
             raise NotImplementedError("core_op %r" % (core_op,))
-        unsupported = dict(dw_kernel_size=dw_kernel_size, level2_post_norm=level2_post_norm, res_post_norm=res_post_norm,
-                           center_feature_scale=center_feature_scale)
-        for k, v in unsupported.items():
-            if v:
-                raise NotImplementedError("InternImage-H/G option %s is not built on the HIP path" % k)
+        # the layer branches of II:407-427 are all scheduled (round 6): post_norm or pre-norm, with or without layer scale, res_post_norm, and the level-2
+        # post norms of InternImage-H/G (II:497-502, 512-515).  Still only on the reference: a depth-wise kernel other than 3 x 3 and center_feature_scale
+        # (both change the DCNv3 module itself, DCNM:124-173 / :209-215; no MTP configuration sets them).
+        if dw_kernel_size not in (None, 3):
+            raise NotImplementedError("InternImage-H/G option dw_kernel_size=%r is not built on the HIP path (the depth-wise kernel is 3 x 3)" % (dw_kernel_size,))
+        if center_feature_scale:
+            raise NotImplementedError("InternImage-H/G option center_feature_scale is not built on the HIP path")
         if act_layer != "GELU" or norm_layer != "LN" or drop_rate != 0.0:
             raise NotImplementedError("the HIP path schedules act_layer='GELU', norm_layer='LN', drop_rate=0 (what MTP uses, models.py:92-104)")
-        if not post_norm or layer_scale is None:
-            raise NotImplementedError("the HIP path schedules the layer_scale + post_norm branch (II:424-426) that InternImage-XL / MTP use")
+        if res_post_norm and (post_norm or layer_scale is not None):
+            # (II:408-417: res_post_norm is only looked at in the branch without layer scale and without post_norm; refusing the combinations the reference
+            #  would silently build as something else keeps a configuration's meaning the same on both sides)
+            raise ValueError("res_post_norm takes effect only with post_norm=False and layer_scale=None (II:408-417)")
+        if level2_post_norm and not level2_post_norm_block_ids:
+            raise ValueError("level2_post_norm needs level2_post_norm_block_ids")
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         self.core_op = core_op
@@ -101,8 +107,11 @@ class InternImage(nn.Module):
         self.init_cfg = init_cfg
         self.out_indices = tuple(out_indices)
         self.level2_post_norm_block_ids = level2_post_norm_block_ids
+        self.level2_post_norm = bool(level2_post_norm)
+        self.res_post_norm = bool(res_post_norm)
         self.offset_scale = float(offset_scale)
-        self.layer_scale = float(layer_scale)
+        self.has_layer_scale = layer_scale is not None
+        self.layer_scale = float(layer_scale) if layer_scale is not None else None
         self.kernel_size = 3
         self.with_cp = with_cp
         self.precision = precision
@@ -160,8 +169,9 @@ class InternImage(nn.Module):
             hid = int(C * self.mlp_ratio)
             for j in range(depth):
                 p = "levels.%d.blocks.%d." % (i, j)
-                _put(self, p + "gamma1", self.layer_scale * torch.ones(C))
-                _put(self, p + "gamma2", self.layer_scale * torch.ones(C))
+                if self.has_layer_scale:
+                    _put(self, p + "gamma1", self.layer_scale * torch.ones(C))
+                    _put(self, p + "gamma2", self.layer_scale * torch.ones(C))
                 ln(p + "norm1.0", C)
                 w, b = conv(C, C, 3, groups=C)
                 _put(self, p + "dcn.dw_conv.0.weight", w)
@@ -178,11 +188,22 @@ class InternImage(nn.Module):
                 w, b = linear(C, hid, "trunc")
                 _put(self, p + "mlp.fc2.weight", w)
                 _put(self, p + "mlp.fc2.bias", b)
+                if self.res_post_norm:
+                    ln(p + "res_post_norm1.0", C)
+                    ln(p + "res_post_norm2.0", C)
+            if not self.post_norm:                       # II:497-498: the level's closing norm of the pre-norm forms
+                ln("levels.%d.norm.0" % i, C)
+            for k in range(len(self.post_norm_ids(i))):   # II:499-502
+                ln("levels.%d.post_norms.%d.0" % (i, k), C)
             if i < self.num_levels - 1:
                 p = "levels.%d.downsample." % i
                 w, _ = conv(2 * C, C, 3, bias=False)
                 _put(self, p + "conv.weight", w)
                 ln(p + "norm.1", 2 * C)
+
+    def post_norm_ids(self, level):
+        """the blocks of `level` that are followed by an extra LayerNorm (II:593-594: level 2 only, when level2_post_norm is set)"""
+        return list(self.level2_post_norm_block_ids) if (self.level2_post_norm and level == 2) else []
 
     def init_weights(self, pretrained):
         """II:639-670: checkpoint dict -> 'state_dict' / 'model' / itself, strip 'backbone.' and 'module.' prefixes, non-strict load"""
@@ -205,7 +226,12 @@ class InternImage(nn.Module):
             parts = n.split(".")
             if parts[0] == "levels":
                 i = int(parts[1])
-                groups[n] = base[i] + int(parts[3]) if parts[2] == "blocks" else base[i + 1] - 1
+                if parts[2] == "blocks":
+                    groups[n] = base[i] + int(parts[3])
+                elif parts[2] == "post_norms":      # its gradient is written right before the backward of the block it follows
+                    groups[n] = base[i] + self.post_norm_ids(i)[int(parts[3])]
+                else:                               # downsample, the level's closing norm
+                    groups[n] = base[i + 1] - 1
             else:
                 groups[n] = -1
         names = sorted(groups, key=lambda k: -groups[k])        # stable: the module's order inside a group

@@ -182,7 +182,12 @@ class ViT_Win_RVSA_V3_WSZ7(nn.Module):
                  precision="bf16", feature_dtype=None):
         super().__init__()
         if hybrid_backbone is not None:
-            raise NotImplementedError("hybrid_backbone (VIT:542-574) is not part of the MTP hot path")
+            # the reference accepts the keyword but cannot run it: with a full-attention block in the schedule the constructor reads
+            # `self.patch_embed.patch_shape` (VIT:628), which HybridEmbed (VIT:543-573) does not define -> AttributeError; without one, forward_features
+            # unpacks `x, (Hp, Wp) = self.patch_embed(x)` (VIT:790) from HybridEmbed.forward's single tensor -> ValueError.  Checked against the reference
+            # itself; there is no behaviour to be a drop-in for.
+            raise NotImplementedError("hybrid_backbone: the reference's HybridEmbed (VIT:543-573) cannot be constructed or run with this class (VIT:628 reads "
+                                      "patch_embed.patch_shape, VIT:790 unpacks a tuple HybridEmbed.forward does not return) -- nothing to reproduce")
         if drop_rate != 0. or attn_drop_rate != 0.:
             raise NotImplementedError("dropout is p=0 in both MTP factories (VIT:833-834)")
         if (embed_dim // num_heads) != 64:

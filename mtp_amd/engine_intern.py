@@ -1,7 +1,8 @@
 """Explicit forward / backward kernel schedule of the InternImage backbone on the HIP operators.
 
 Reference: Multi-Task_Pretrain/backbone/intern_image.py ("II") -- StemLayer II:239-276, DownsampleLayer II:279-300, MLPLayer
-II:303-333, InternImageLayer II:336-433 (the layer_scale + post_norm branch II:424-426), InternImageBlock II:436-524,
+II:303-333, InternImageLayer II:336-433 (every branch of II:407-427: post- / pre-norm, with / without layer scale, res_post_norm),
+InternImageBlock II:436-524 (level norm, level-2 post norms),
 InternImage.forward II:690-698 -- and ops_dcnv3/modules/dcnv3.py ("DCNM") DCNv3.forward :318-356.
 
 Everything is channels-last, `rows = N * H * W` rows of C channels:
@@ -201,7 +202,22 @@ class InternEngine:
         return ((u < keep).to(F32) / keep).contiguous()
 
     # ------------------------------------------------------------------ one InternImageLayer
-    def _layer_fwd(self, pre, x32, xa, N, H, W, C, G, scales, save):
+    def _vec(self, C, value):
+        """cached constant vectors: ones = the layer scale of a configuration without one; zeros = where its (unused) gradient is accumulated"""
+        key = (C, value, str(self.dev))
+        cache = self.__dict__.setdefault("_vecs", {})
+        if key not in cache:
+            cache[key] = torch.full((C,), float(value), device=self.dev, dtype=F32)
+        return cache[key]
+
+    def _gam(self, pre, k, C):
+        return self.P[pre + "gamma%d" % k] if self.m.has_layer_scale else self._vec(C, 1.0)
+
+    def _dgam(self, Gd, pre, k, C):
+        return Gd[pre + "gamma%d" % k] if self.m.has_layer_scale else self._vec(C, 0.0)
+
+    def _dcn_fwd(self, pre, xa, N, H, W, C, G):
+        """the DCNv3 module (DCNM:318-356) on the ACT rows xa -> h (rows, C) ACT and what its backward needs"""
         P = self.P
         rows = N * H * W
         K = self.m.kernel_size
@@ -211,52 +227,100 @@ class InternEngine:
         x1c = ops.dwconv3x3_fwd(xa, P[d + "dw_conv.0.weight"], P[d + "dw_conv.0.bias"], self._e(rows, C), N, H, W)
         x1, m0, r0 = self._ln(x1c, P, d + "dw_conv.1.1", gelu=True)
         off = self._linear(x1, d + "offset.weight", P[d + "offset.bias"])
-        Lm = self._lin[d + "mask.weight"]
         logits = self._linear(x1, d + "mask.weight", P[d + "mask.bias"], padded_out=True)
         mask = ops.softmax_groups_fwd(logits, self._e(rows, G * Pn), G, Pn)
         pad = K // 2
         y = dcn.dcnv3_forward(xp.view(N, H, W, C), off.view(N, H, W, -1), mask.view(N, H, W, -1), K, K, 1, 1, pad, pad, 1, 1, G, C // G,
                               self.m.offset_scale, 256).view(rows, C)
         h = self._linear(y, d + "output_proj.weight", P[d + "output_proj.bias"])
-        # x2 = x + s1 * gamma1 * LN1(h): LayerNorm and the layer-scale residual in one pass (round 4: were two launches and a bf16 round trip)
-        s1 = scales[0] if scales is not None else None
-        x32b, xab = self._e(rows, C, dtype=F32), self._e(rows, C)
-        m1, r1 = self._e(rows, dtype=F32), self._e(rows, dtype=F32)
-        ops.layernorm_residual_fwd(h, P[pre + "norm1.0.weight"], P[pre + "norm1.0.bias"], x32, P[pre + "gamma1"], x32b, xab, m1, r1, s1, H * W)
-        # MLPLayer: fc1 -> GELU -> fc2 (dropout p = 0); fc1 stores gelu'(u) next to gelu(u) for the backward
+        return h, dict(xa=xa, xp=xp, x1c=x1c, m0=m0, r0=r0, x1=x1, off=off, mask=mask, y=y, h=h)
+
+    def _mlp_fwd(self, pre, xab):
+        """MLPLayer: fc1 -> GELU -> fc2 (dropout p = 0); fc1 stores gelu'(u) next to gelu(u) for the backward"""
+        P = self.P
+        rows = xab.shape[0]
         L1 = self._lin[pre + "mlp.fc1.weight"]
         u = self._e(rows, L1.R)
         ug = self._e(rows, L1.R)      # (also when nothing is saved: the GELU epilogues always write their side output -- the inference forward of bench.py's
         ops.gemm_nt(xab, L1.w, u, epi=ops.EPI_BIAS_GELU_DG, bias=P[pre + "mlp.fc1.bias"], aux=ug)      #  `forward_only` found the aux = NULL call of rounds 2-3)
         v = self._linear(u, pre + "mlp.fc2.weight", P[pre + "mlp.fc2.bias"])
+        return v, dict(xab=xab, u=u, ug=ug, v=v)
+
+    def _layer_fwd(self, pre, x32, xa, N, H, W, C, G, scales, save):
+        """x32 (rows, C) f32 residual stream, xa its ACT copy (None when the previous layer did not produce one) -> (x32', xa', context)"""
+        if not self.m.post_norm:
+            return self._layer_fwd_pre(pre, x32, N, H, W, C, G, scales, save)
+        P = self.P
+        rows = N * H * W
+        if xa is None:
+            xa = self._to_act(x32)
+        h, cd = self._dcn_fwd(pre, xa, N, H, W, C, G)
+        # x2 = x + s1 * gamma1 * LN1(h): LayerNorm and the layer-scale residual in one pass (round 4: were two launches and a bf16 round trip)
+        s1 = scales[0] if scales is not None else None
+        x32b, xab = self._e(rows, C, dtype=F32), self._e(rows, C)
+        m1, r1 = self._e(rows, dtype=F32), self._e(rows, dtype=F32)
+        ops.layernorm_residual_fwd(h, P[pre + "norm1.0.weight"], P[pre + "norm1.0.bias"], x32, self._gam(pre, 1, C), x32b, xab, m1, r1, s1, H * W)
+        v, cm = self._mlp_fwd(pre, xab)
         s2 = scales[1] if scales is not None else None
         x32c, xac = self._e(rows, C, dtype=F32), self._e(rows, C)
         m2, r2 = self._e(rows, dtype=F32), self._e(rows, dtype=F32)
-        ops.layernorm_residual_fwd(v, P[pre + "norm2.0.weight"], P[pre + "norm2.0.bias"], x32b, P[pre + "gamma2"], x32c, xac, m2, r2, s2, H * W)
+        ops.layernorm_residual_fwd(v, P[pre + "norm2.0.weight"], P[pre + "norm2.0.bias"], x32b, self._gam(pre, 2, C), x32c, xac, m2, r2, s2, H * W)
         ctx = None
         if save:
-            ctx = dict(xa=xa, xp=xp, x1c=x1c, m0=m0, r0=r0, x1=x1, off=off, mask=mask, y=y, h=h, m1=m1, r1=r1, xab=xab, u=u, ug=ug, v=v,
-                       m2=m2, r2=r2, s1=s1, s2=s2)
+            ctx = dict(m1=m1, r1=r1, m2=m2, r2=r2, s1=s1, s2=s2)
+            ctx.update(cd)
+            ctx.update(cm)
         return x32c, xac, ctx
 
-    def _layer_bwd(self, pre, c, dx32, N, H, W, C, G, Gd):
-        """dx32 (rows, C) f32: gradient of the layer's output; returns the gradient of its input (f32, new buffer or in place)"""
+    def _layer_fwd_pre(self, pre, x32, N, H, W, C, G, scales, save):
+        """the pre-norm branches (II:412-417, 426-427): x += s1 * gamma1 * [res_post_norm1](dcn(norm1(x))); x += s2 * gamma2 * [res_post_norm2](mlp(norm2(x)))"""
+        P = self.P
+        rows = N * H * W
+        rpn = self.m.res_post_norm
+        s1 = scales[0] if scales is not None else None
+        s2 = scales[1] if scales is not None else None
+        xn, ma, ra = self._ln(x32, P, pre + "norm1.0")
+        h, cd = self._dcn_fwd(pre, xn, N, H, W, C, G)
+        x32b = self._e(rows, C, dtype=F32)
+        m1 = r1 = m2 = r2 = None
+        if rpn:
+            m1, r1 = self._e(rows, dtype=F32), self._e(rows, dtype=F32)
+            ops.layernorm_residual_fwd(h, P[pre + "res_post_norm1.0.weight"], P[pre + "res_post_norm1.0.bias"], x32, self._gam(pre, 1, C), x32b, None, m1, r1, s1, H * W)
+        else:
+            ops.scale_residual_fwd(x32, h, self._gam(pre, 1, C), x32b, None, s1, H * W)
+        xn2, mb, rb = self._ln(x32b, P, pre + "norm2.0")
+        v, cm = self._mlp_fwd(pre, xn2)
+        x32c = self._e(rows, C, dtype=F32)
+        if rpn:
+            m2, r2 = self._e(rows, dtype=F32), self._e(rows, dtype=F32)
+            ops.layernorm_residual_fwd(v, P[pre + "res_post_norm2.0.weight"], P[pre + "res_post_norm2.0.bias"], x32b, self._gam(pre, 2, C), x32c, None, m2, r2, s2, H * W)
+        else:
+            ops.scale_residual_fwd(x32b, v, self._gam(pre, 2, C), x32c, None, s2, H * W)
+        ctx = None
+        if save:
+            ctx = dict(pre_norm=True, x32=x32, ma=ma, ra=ra, x32b=x32b, mb=mb, rb=rb, m1=m1, r1=r1, m2=m2, r2=r2, s1=s1, s2=s2)
+            ctx.update(cd)
+            ctx.update(cm)
+        return x32c, None, ctx
+
+    def _mlp_bwd(self, pre, c, dv, Gd, res=None, out_dtype=F32):
+        """dv (rows, C) ACT = gradient of fc2's output -> gradient of fc1's input ([res] + ..., `out_dtype`); weight gradients queued"""
+        rows = dv.shape[0]
+        L1, L2 = self._lin[pre + "mlp.fc1.weight"], self._lin[pre + "mlp.fc2.weight"]
+        self._wq.add(dv, c["u"], Gd[pre + "mlp.fc2.weight"], Gd[pre + "mlp.fc2.bias"])
+        du = ops.gemm_nt(dv, L2.wt, self._e(rows, L1.R), epi=ops.EPI_MUL, aux=c["ug"])
+        self._wq.add(du, c["xab"], Gd[pre + "mlp.fc1.weight"], Gd[pre + "mlp.fc1.bias"])
+        if res is not None:
+            return ops.gemm_nt(du, L1.wt, self._e(rows, L1.C, dtype=F32), epi=ops.EPI_BIAS_RES, res=res)      # + the residual path
+        return ops.gemm_nt(du, L1.wt, self._e(rows, L1.C, dtype=out_dtype))
+
+    def _dcn_bwd(self, pre, c, dh, N, H, W, C, G, Gd, res=None):
+        """dh (rows, C) ACT = gradient of output_proj's output -> f32 gradient of the module's input ([res] + ...); weight gradients queued"""
         P = self.P
         rows = N * H * W
         K = self.m.kernel_size
         Pn = K * K
         d = pre + "dcn."
-        # ---- x3 = x2 + s2 * gamma2 * LN2(fc2(gelu(fc1(x2))))
-        dv = ops.layernorm_residual_bwd(dx32, c["v"], c["m2"], c["r2"], P[pre + "norm2.0.weight"], P[pre + "norm2.0.bias"], P[pre + "gamma2"], self._e(rows, C),
-                                        Gd[pre + "norm2.0.weight"], Gd[pre + "norm2.0.bias"], Gd[pre + "gamma2"], c["s2"], H * W, defer=self._ln_parts)
-        L1, L2 = self._lin[pre + "mlp.fc1.weight"], self._lin[pre + "mlp.fc2.weight"]
-        self._wq.add(dv, c["u"], Gd[pre + "mlp.fc2.weight"], Gd[pre + "mlp.fc2.bias"])
-        du = ops.gemm_nt(dv, L2.wt, self._e(rows, L1.R), epi=ops.EPI_MUL, aux=c["ug"])
-        self._wq.add(du, c["xab"], Gd[pre + "mlp.fc1.weight"], Gd[pre + "mlp.fc1.bias"])
-        dx2 = ops.gemm_nt(du, L1.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx32)      # + the residual path
-        # ---- x2 = x + s1 * gamma1 * LN1(output_proj(dcnv3(...)))
-        dh = ops.layernorm_residual_bwd(dx2, c["h"], c["m1"], c["r1"], P[pre + "norm1.0.weight"], P[pre + "norm1.0.bias"], P[pre + "gamma1"], self._e(rows, C),
-                                        Gd[pre + "norm1.0.weight"], Gd[pre + "norm1.0.bias"], Gd[pre + "gamma1"], c["s1"], H * W, defer=self._ln_parts)
         Lo = self._lin[d + "output_proj.weight"]
         self._wq.add(dh, c["y"], Gd[d + "output_proj.weight"], Gd[d + "output_proj.bias"])
         dy = ops.gemm_nt(dh, Lo.wt, self._e(rows, C))
@@ -283,9 +347,60 @@ class InternEngine:
         Li = self._lin[d + "input_proj.weight"]
         dxpa = self._to_act(dxp.view(rows, C))
         self._wq.add(dxpa, c["xa"], Gd[d + "input_proj.weight"], Gd[d + "input_proj.bias"])
-        dxin = ops.gemm_nt(dxpa, Li.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx2)
+        if res is not None:
+            dxin = ops.gemm_nt(dxpa, Li.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=res)
+        else:
+            dxin = ops.gemm_nt(dxpa, Li.wt, self._e(rows, C, dtype=F32))
         ops.dwconv3x3_bwd_dx(dx1c, P[d + "dw_conv.0.weight"], dxin, N, H, W, accumulate=True)
         return dxin
+
+    def _layer_bwd(self, pre, c, dx32, N, H, W, C, G, Gd):
+        """dx32 (rows, C) f32: gradient of the layer's output; returns the gradient of its input (f32, new buffer or in place)"""
+        if c.get("pre_norm"):
+            return self._layer_bwd_pre(pre, c, dx32, N, H, W, C, G, Gd)
+        P = self.P
+        rows = N * H * W
+        # ---- x3 = x2 + s2 * gamma2 * LN2(fc2(gelu(fc1(x2))))
+        dv = ops.layernorm_residual_bwd(dx32, c["v"], c["m2"], c["r2"], P[pre + "norm2.0.weight"], P[pre + "norm2.0.bias"], self._gam(pre, 2, C), self._e(rows, C),
+                                        Gd[pre + "norm2.0.weight"], Gd[pre + "norm2.0.bias"], self._dgam(Gd, pre, 2, C), c["s2"], H * W, defer=self._ln_parts)
+        dx2 = self._mlp_bwd(pre, c, dv, Gd, res=dx32)
+        # ---- x2 = x + s1 * gamma1 * LN1(output_proj(dcnv3(...)))
+        dh = ops.layernorm_residual_bwd(dx2, c["h"], c["m1"], c["r1"], P[pre + "norm1.0.weight"], P[pre + "norm1.0.bias"], self._gam(pre, 1, C), self._e(rows, C),
+                                        Gd[pre + "norm1.0.weight"], Gd[pre + "norm1.0.bias"], self._dgam(Gd, pre, 1, C), c["s1"], H * W, defer=self._ln_parts)
+        return self._dcn_bwd(pre, c, dh, N, H, W, C, G, Gd, res=dx2)
+
+    def _branch_bwd(self, pre, k, c, dout, z, mean, rstd, s, HW, C, Gd):
+        """gradient of  s * gamma_k * [res_post_norm_k](z)  with respect to z (ACT), parameter gradients accumulated"""
+        rows = dout.shape[0]
+        if self.m.res_post_norm:
+            key = pre + "res_post_norm%d.0" % k
+            return ops.layernorm_residual_bwd(dout, z, mean, rstd, self.P[key + ".weight"], self.P[key + ".bias"], self._gam(pre, k, C), self._e(rows, C),
+                                              Gd[key + ".weight"], Gd[key + ".bias"], self._dgam(Gd, pre, k, C), s, HW, defer=self._ln_parts)
+        return ops.scale_residual_bwd(dout, z, self._gam(pre, k, C), self._e(rows, C), self._dgam(Gd, pre, k, C), s, HW, accumulate=True)
+
+    def _layer_bwd_pre(self, pre, c, dx32, N, H, W, C, G, Gd):
+        P = self.P
+        HW = H * W
+        dv = self._branch_bwd(pre, 2, c, dx32, c["v"], c["m2"], c["r2"], c["s2"], HW, C, Gd)
+        dxn2 = self._mlp_bwd(pre, c, dv, Gd, out_dtype=F32)
+        dx2 = self._e(*dx32.shape, dtype=F32)
+        ops.layernorm_bwd(dxn2, c["x32b"], c["mb"], c["rb"], P[pre + "norm2.0.weight"], dx2, Gd[pre + "norm2.0.weight"], Gd[pre + "norm2.0.bias"], dres=dx32,
+                          accumulate=True, defer=self._ln_parts)
+        dh = self._branch_bwd(pre, 1, c, dx2, c["h"], c["m1"], c["r1"], c["s1"], HW, C, Gd)
+        dxn = self._dcn_bwd(pre, c, dh, N, H, W, C, G, Gd)
+        dx = self._e(*dx32.shape, dtype=F32)
+        ops.layernorm_bwd(dxn, c["x32"], c["ma"], c["ra"], P[pre + "norm1.0.weight"], dx, Gd[pre + "norm1.0.weight"], Gd[pre + "norm1.0.bias"], dres=dx2,
+                          accumulate=True, defer=self._ln_parts)
+        return dx
+
+    def _norm_f32(self, x32, key):
+        """a LayerNorm of the f32 residual stream itself (the level's closing norm II:516-517, the level-2 post norms II:512-515): f32 in, f32 out"""
+        y, mean, rstd = self._ln(x32, self.P, key, out_dtype=F32)
+        return y, (x32, mean, rstd, key)
+
+    def _norm_f32_bwd(self, dy, saved, Gd):
+        x32, mean, rstd, key = saved
+        return self._ln_bwd(dy, x32, mean, rstd, self.P, Gd, key)
 
     # ------------------------------------------------------------------ whole forward
     def forward(self, img, training=False, need_grad=False, feature_dtype=None):
@@ -315,6 +430,8 @@ class InternEngine:
         li = 0
         for i, (depth, G) in enumerate(zip(m.depths, m.groups)):
             lctx = []
+            pn_ids = m.post_norm_ids(i)
+            pn_saved = {}
             for j in range(depth):
                 sc = (scales[2 * li], scales[2 * li + 1]) if scales is not None else None
                 if save and ckpt:
@@ -327,10 +444,21 @@ class InternEngine:
                     x32, xa, c = self._layer_fwd("levels.%d.blocks.%d." % (i, j), x32, xa, N, Hc, Wc, C, G, sc, save)
                 lctx.append(c)
                 li += 1
+                if j in pn_ids:       # InternImage-H/G: an extra LayerNorm behind chosen blocks of level 2 (II:512-515)
+                    x32, sv = self._norm_f32(x32, "levels.%d.post_norms.%d.0" % (i, pn_ids.index(j)))
+                    xa = None
+                    pn_saved[j] = sv if save else None
+            lnorm = None
+            if not m.post_norm:      # the pre-norm forms close a level with its own LayerNorm (II:516-517); the taps are taken behind it
+                x32, sv = self._norm_f32(x32, "levels.%d.norm.0" % i)
+                xa = None
+                lnorm = sv if save else None
             if i in m.out_indices:
                 feats.append(ops.tokens_to_nchw(x32, self._e(N, C, Hc, Wc, dtype=fdt), N, Hc, Wc, 0))
             down = None
             if i < len(m.depths) - 1:
+                if xa is None:
+                    xa = self._to_act(x32)
                 pre = "levels.%d.downsample." % i
                 yd, colsd, Hn, Wn = self._conv_fwd(xa, (Hc * Wc * C, Wc * C, C, 1), pre + "conv.weight", None, N, Hc, Wc, C, 2)
                 x32, dm, dr = self._ln(yd, P, pre + "norm.1", out_dtype=F32)
@@ -338,7 +466,7 @@ class InternEngine:
                 down = (colsd, yd, dm, dr)
                 geom_next = (Hn, Wn, 2 * C)
             if save:
-                ctx["levels"].append(dict(layers=lctx, down=down, geom=(Hc, Wc, C, G)))
+                ctx["levels"].append(dict(layers=lctx, down=down, geom=(Hc, Wc, C, G), norm=lnorm, post_norms=pn_saved))
             if i < len(m.depths) - 1:
                 Hc, Wc, C = geom_next
         return feats, ctx
@@ -383,8 +511,12 @@ class InternEngine:
                     ops.axpy(dx32, ops.nchw_to_tokens(d, self._e(rows, C, dtype=F32), N, Hc, Wc, 0))
             if dx32 is None:      # nothing downstream of this level has a gradient
                 continue
+            if lv.get("norm") is not None:
+                dx32 = self._norm_f32_bwd(dx32, lv["norm"], G)
             for j in range(len(lv["layers"]) - 1, -1, -1):
                 c = lv["layers"][j]
+                if lv.get("post_norms") and lv["post_norms"].get(j) is not None:
+                    dx32 = self._norm_f32_bwd(dx32, lv["post_norms"][j], G)
                 if c.get("ckpt"):      # with_cp: the layer's forward once more, this time keeping what its backward needs
                     c = self._layer_fwd("levels.%d.blocks.%d." % (i, j), c["x32"], c["xa"], N, Hc, Wc, C, Gr, c["sc"], True)[2]
                 dx32 = self._layer_bwd("levels.%d.blocks.%d." % (i, j), c, dx32, N, Hc, Wc, C, Gr, G)

@@ -3,12 +3,13 @@
 Groundwork for the next widening step: the HIP operator (mtp_amd/ops_dcnv3) covers the reference's native extension; the
 layers around it are plain torch modules in the reference ("II" = /root/reference/Multi-Task_Pretrain/backbone/intern_image.py,
 "DCNM" = .../backbone/ops_dcnv3/modules/dcnv3.py).  This file restates them channels-last, from a flat parameter dict with the
-reference's state-dict keys, for the configuration family BASELINE config 5 uses (II:700-712: norm_layer='LN',
-act_layer='GELU', layer_scale set, post_norm=True, no center_feature_scale / res_post_norm / level2_post_norm).
+reference's state-dict keys, for norm_layer='LN', act_layer='GELU': the configuration family BASELINE config 5 uses (II:700-712:
+layer_scale set, post_norm=True) and, since round 6, the other layer branches (pre-norm, no layer scale, res_post_norm, level-2 post
+norms); not center_feature_scale / dw_kernel_size.
 The DCNv3 core inside is oracle/dcnv3_oracle.py (explicit bilinear gather), so gradients flow through torch autograd.
 
-PINNED: tests/golden/f12_internimage.npz = outputs and gradients of the reference's own `InternImage(core_op='DCNv3_pytorch')`
-(tests/golden/make_golden.py f12); tests/test_internimage_oracle.py holds this file to them (fp32, 2e-5) and checks
+PINNED: tests/golden/f12_internimage.npz (and f15_internimage_variants.npz for the other branches) = outputs and gradients of the
+reference's own `InternImage(core_op='DCNv3_pytorch')` (tests/golden/make_golden.py f12 / f15); tests/test_internimage_oracle.py holds this file to them (fp32, 2e-5) and checks
 `state_shapes()` against the reference's state_dict() keys / shapes / order stored in the fixture.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
@@ -21,8 +22,10 @@ from . import dcnv3_oracle as D
 EPS = 1e-6   # build_norm_layer default (II:39-43, DCNM:37-41)
 
 
-def state_shapes(channels=192, depths=(5, 5, 24, 5), groups=(12, 24, 48, 96), mlp_ratio=4.0, kernel_size=3):
-    """reference state-dict keys and shapes in the reference's order, for layer_scale + post_norm configurations"""
+def state_shapes(channels=192, depths=(5, 5, 24, 5), groups=(12, 24, 48, 96), mlp_ratio=4.0, kernel_size=3, post_norm=True, layer_scale=True,
+                 res_post_norm=False, level2_post_norm_block_ids=None):
+    """reference state-dict keys and shapes in the reference's order (own parameters of a module before its sub-modules'): the defaults are the
+    layer_scale + post_norm family of BASELINE config 5; the other branches of II:407-427 / II:497-502 by the keyword flags (fixture f15)"""
     s = {}
     c2 = channels // 2
     s["patch_embed.conv1.weight"] = (c2, 3, 3, 3)
@@ -39,8 +42,9 @@ def state_shapes(channels=192, depths=(5, 5, 24, 5), groups=(12, 24, 48, 96), ml
         hid = int(C * mlp_ratio)
         for j in range(depth):
             p = "levels.%d.blocks.%d." % (i, j)
-            s[p + "gamma1"] = (C,)
-            s[p + "gamma2"] = (C,)
+            if layer_scale:
+                s[p + "gamma1"] = (C,)
+                s[p + "gamma2"] = (C,)
             s[p + "norm1.0.weight"] = (C,)
             s[p + "norm1.0.bias"] = (C,)
             s[p + "dcn.dw_conv.0.weight"] = (C, 1, kernel_size, kernel_size)
@@ -61,6 +65,17 @@ def state_shapes(channels=192, depths=(5, 5, 24, 5), groups=(12, 24, 48, 96), ml
             s[p + "mlp.fc1.bias"] = (hid,)
             s[p + "mlp.fc2.weight"] = (C, hid)
             s[p + "mlp.fc2.bias"] = (C,)
+            if res_post_norm:
+                for k in (1, 2):
+                    s[p + "res_post_norm%d.0.weight" % k] = (C,)
+                    s[p + "res_post_norm%d.0.bias" % k] = (C,)
+        if not post_norm:                                   # II:497-498
+            s["levels.%d.norm.0.weight" % i] = (C,)
+            s["levels.%d.norm.0.bias" % i] = (C,)
+        if level2_post_norm_block_ids and i == 2:           # II:499-502, 593-594
+            for k in range(len(level2_post_norm_block_ids)):
+                s["levels.2.post_norms.%d.0.weight" % k] = (C,)
+                s["levels.2.post_norms.%d.0.bias" % k] = (C,)
         if i < len(depths) - 1:
             p = "levels.%d.downsample." % i
             s[p + "conv.weight"] = (2 * C, C, 3, 3)
@@ -113,12 +128,27 @@ def dcnv3_module(x, p, pre, group, offset_scale, kernel_size=3):
     return F.linear(y, p[pre + "output_proj.weight"], p[pre + "output_proj.bias"])
 
 
-def layer(x, p, pre, group, offset_scale):
-    """InternImageLayer II:407-434, the layer_scale + post_norm branch (II:424-426): x += g1 * LN1(dcn(x)); x += g2 * LN2(mlp(x))"""
-    x = x + p[pre + "gamma1"] * _ln(dcnv3_module(x, p, pre + "dcn.", group, offset_scale), p, pre + "norm1.0")
+def _mlp(x, p, pre):
     h = F.gelu(F.linear(x, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"]))           # MLPLayer II:327-333, dropout p = 0
-    h = F.linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
-    return x + p[pre + "gamma2"] * _ln(h, p, pre + "norm2.0")
+    return F.linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+
+
+def layer(x, p, pre, group, offset_scale, post_norm=True):
+    """InternImageLayer II:407-434, every branch (the reference picks it from `post_norm`, `res_post_norm` and whether the layer has gammas; here the
+    presence of the gamma / res_post_norm parameters in `p` says the same):
+      post_norm:      x += g1 * LN1(dcn(x));            x += g2 * LN2(mlp(x))             (II:409-411, 424-425; g = 1 without layer scale)
+      res_post_norm:  x += RPN1(dcn(LN1(x)));           x += RPN2(mlp(LN2(x)))            (II:412-414)
+      pre-norm:       x += g1 * dcn(LN1(x));            x += g2 * mlp(LN2(x))             (II:415-417, 426-427)"""
+    g1 = p.get(pre + "gamma1", 1.0)
+    g2 = p.get(pre + "gamma2", 1.0)
+    if post_norm:
+        x = x + g1 * _ln(dcnv3_module(x, p, pre + "dcn.", group, offset_scale), p, pre + "norm1.0")
+        return x + g2 * _ln(_mlp(x, p, pre), p, pre + "norm2.0")
+    rpn = (pre + "res_post_norm1.0.weight") in p
+    h = dcnv3_module(_ln(x, p, pre + "norm1.0"), p, pre + "dcn.", group, offset_scale)
+    x = x + g1 * (_ln(h, p, pre + "res_post_norm1.0") if rpn else h)
+    h = _mlp(_ln(x, p, pre + "norm2.0"), p, pre)
+    return x + g2 * (_ln(h, p, pre + "res_post_norm2.0") if rpn else h)
 
 
 def downsample(x, p, pre):
@@ -126,14 +156,19 @@ def downsample(x, p, pre):
     return _ln(_conv_nhwc(x, p[pre + "conv.weight"], None, 2), p, pre + "norm.1")
 
 
-def backbone_forward(img, p, depths, groups, offset_scale=2.0, out_indices=(0, 1, 2, 3)):
-    """InternImage.forward II:690-698 (+ InternImageBlock.forward II:509-525 with post_norm: no level norm): list of NCHW maps
-    at strides 4, 8, 16, 32 taken before each level's downsample"""
+def backbone_forward(img, p, depths, groups, offset_scale=2.0, out_indices=(0, 1, 2, 3), post_norm=True, level2_post_norm_block_ids=None):
+    """InternImage.forward II:690-698 (+ InternImageBlock.forward II:509-525: the level-2 post norms behind their blocks, the level's closing norm of the
+    pre-norm forms): list of NCHW maps at strides 4, 8, 16, 32 taken before each level's downsample"""
     x = stem(img, p)
     outs = []
     for i, (depth, G) in enumerate(zip(depths, groups)):
+        ids = list(level2_post_norm_block_ids) if (level2_post_norm_block_ids and i == 2) else []
         for j in range(depth):
-            x = layer(x, p, "levels.%d.blocks.%d." % (i, j), G, offset_scale)
+            x = layer(x, p, "levels.%d.blocks.%d." % (i, j), G, offset_scale, post_norm)
+            if j in ids:
+                x = _ln(x, p, "levels.2.post_norms.%d.0" % ids.index(j))
+        if not post_norm:
+            x = _ln(x, p, "levels.%d.norm.0" % i)
         if i in out_indices:
             outs.append(x.permute(0, 3, 1, 2).contiguous())
         if i < len(depths) - 1:

@@ -7,7 +7,7 @@ are stored.  Tests re-create inputs/params from the seeds in recipe.py.  Fixture
   f0 state-dict keys/shapes         f1 integer/index ops           f2 calc_rel_pos_spatial
   f3 Attention (full)               f4 RVSA sampling grid          f5 RVSA attention fwd+grads
   f6 Mlp/Block/PatchEmbed/Norm2d/fpn  f7 ViT-B whole forward (cfg 1)  f8 small whole model fwd+grads (fp32 and bf16 autocast)
-  f9 / f10 fine-tune variants  f11 DCNv3 core  f12 InternImage  f13 ViT-L (the headline model), fwd + grads, fp32 and bf16 autocast
+  f9 / f10 fine-tune variants  f11 DCNv3 core  f12 InternImage (f15: its other layer branches)  f13 ViT-L (the headline model), fwd + grads, fp32 and bf16 autocast
 """
 import contextlib
 import io
@@ -424,6 +424,46 @@ def f12():
     save("f12_internimage.npz", **out)
 
 
+# ------------------------------------------------------------------ f15: the other InternImageLayer branches (II:407-427) and block norms (II:497-517)
+F15_VARIANTS = recipe.II_VARIANTS
+
+
+def f15():
+    from oracle import internimage_oracle as IO
+    II = ref_loader.load_reference_internimage()
+    cfg = recipe.II_CFG
+    out = {}
+    for name, kw in F15_VARIANTS.items():
+        net = quiet(II.InternImage, core_op="DCNv3_pytorch", channels=cfg["channels"], depths=cfg["depths"], groups=cfg["groups"], mlp_ratio=4.0,
+                    drop_path_rate=0.0, norm_layer="LN", offset_scale=cfg["offset_scale"], with_cp=False, out_indices=(0, 1, 2, 3), **kw)
+        sd = net.state_dict()
+        shapes = IO.state_shapes(cfg["channels"], cfg["depths"], cfg["groups"], post_norm=kw["post_norm"], layer_scale=kw["layer_scale"] is not None,
+                                 res_post_norm=kw.get("res_post_norm", False), level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"))
+        assert list(sd.keys()) == list(shapes.keys()), "state_shapes() order/names differ from the reference (%s)" % name
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(shapes[k]), k
+        net.load_state_dict(recipe.internimage_variant_params(shapes), strict=True)
+        net = net.double().eval()
+        img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(recipe.II_VARIANT_SEEDS[name])).double().requires_grad_(True)
+        feats = net(img)
+        gs = [torch.randn(f.shape, generator=torch.Generator().manual_seed(200 + i)).double() for i, f in enumerate(feats)]
+        sum((f * g).sum() for f, g in zip(feats, gs)).backward()
+        grads = dict(net.named_parameters())
+        keep = ["patch_embed.conv1.weight", "levels.0.blocks.0.dcn.offset.weight", "levels.0.blocks.0.norm1.0.weight", "levels.1.blocks.0.dcn.dw_conv.0.weight",
+                "levels.2.blocks.0.norm2.0.bias", "levels.2.blocks.1.dcn.input_proj.weight", "levels.0.downsample.conv.weight", "levels.3.blocks.0.mlp.fc2.bias",
+                "levels.3.blocks.0.dcn.output_proj.weight"]
+        keep += [k for k in ("levels.0.blocks.0.gamma1", "levels.2.blocks.1.gamma2", "levels.1.norm.0.weight", "levels.3.norm.0.bias", "levels.2.post_norms.0.0.weight",
+                             "levels.2.blocks.0.res_post_norm1.0.weight", "levels.3.blocks.0.res_post_norm2.0.bias") if k in grads]
+        out[name + ".keys"] = np.array(list(sd.keys()))
+        out[name + ".shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        out[name + ".grad_img"] = img.grad.float()           # (stored as float32: the float64 run's own error against an exact evaluation is 1e-5, see f12)
+        for i, f in enumerate(feats):
+            out[name + ".feat%d" % i] = f.float()
+        for k in keep:
+            out[name + ".grad." + k] = grads[k].grad.float()
+    save("f15_internimage_variants.npz", **out)
+
+
 # ------------------------------------------------------------------ f13: ViT-L (BASELINE configs 3/4: the headline model), fp32 + bf16 autocast
 F13_GRADS = ("pos_embed", "patch_embed.proj.weight", "blocks.0.attn.sampling_offsets.2.weight", "blocks.3.attn.relative_position_bias_table",
              "blocks.5.attn.full_attn_rel_pos_h", "blocks.11.mlp.fc1.weight", "blocks.17.attn.qkv.weight", "blocks.23.attn.proj.bias",
@@ -537,6 +577,6 @@ def f14():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f13_hard", "f14"]
+    which = sys.argv[1:] or ["f0", "f1", "f2", "f3", "f45", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f13_hard", "f14", "f15"]
     for w in which:
         globals()[w]()

@@ -483,3 +483,128 @@ def test_internimage_with_cp_recomputes_each_layer_and_gives_the_same_gradients(
     for n in ga:
         assert rel_err(gb[n], ga[n]) < 1e-4, (n, rel_err(gb[n], ga[n]))      # (f32 atomics in the bias-gradient / depth-wise partial sums: order varies from run to run)
     assert mb < 0.6 * ma, (ma, mb)              # activations held between forward and backward
+
+
+# ------------------------------------------------------------------------------------------------ the other layer branches (round 6; fixture f15)
+VARIANTS = recipe.II_VARIANTS
+
+
+def _variant_params(shapes, precision):
+    """f15's seeded parameters (offset heads at a quarter of f12's scale: recipe.internimage_variant_params); for the bf16 run at a tenth of f12's, as _params"""
+    p = recipe.internimage_variant_params(shapes)
+    if precision == "bf16":
+        p = {k: (0.4 * v if ".dcn.offset." in k else v) for k, v in p.items()}
+    return p
+
+
+def _variant_net(name, precision, **extra):
+    kw = dict(VARIANTS[name])
+    shapes = IO.state_shapes(CFG["channels"], CFG["depths"], CFG["groups"], post_norm=kw["post_norm"], layer_scale=kw["layer_scale"] is not None,
+                             res_post_norm=kw.get("res_post_norm", False), level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"))
+    kw.update(extra)
+    net = mtp_amd.InternImage(core_op="DCNv3", channels=CFG["channels"], depths=CFG["depths"], groups=CFG["groups"], mlp_ratio=4.0, norm_layer="LN",
+                              offset_scale=CFG["offset_scale"], out_indices=(0, 1, 2, 3), precision=precision, feature_dtype=torch.float32,
+                              **dict(dict(drop_path_rate=0.0, with_cp=False), **kw))
+    net.load_state_dict(_variant_params(shapes, precision), strict=True)
+    return net.cuda().train(), shapes, VARIANTS[name]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_internimage_layer_variants_forward_and_every_gradient(name, precision):
+    """the pre-norm branches (with / without layer scale, res_post_norm), post-norm without layer scale, the level's closing norm and the level-2 post norms on
+    the HIP schedule: fp32 mode against the reference's own run (fixture f15) and against the oracle's autograd for EVERY parameter (1e-3); bf16 mode against the oracle with torch's own bf16
+    autocast of the oracle as the yardstick (as for the XL family above)."""
+    FIX = np.load(os.path.join(ROOT, "tests", "golden", "f15_internimage_variants.npz"))
+    net, shapes, kw = _variant_net(name, precision)
+    assert [k for k in net.state_dict()] == [str(k) for k in FIX[name + ".keys"]]
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(recipe.II_VARIANT_SEEDS[name]))
+    x = img.cuda().requires_grad_(True)
+    feats = net(x)
+    gs = [torch.randn(f.shape, generator=torch.Generator().manual_seed(200 + i)) for i, f in enumerate(feats)]
+    sum((f * g.cuda()).sum() for f, g in zip(feats, gs)).backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in _variant_params(shapes, precision).items()}
+    xr = img.clone().requires_grad_(True)
+    okw = dict(post_norm=kw["post_norm"], level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"))
+    ref = IO.backbone_forward(xr, p, CFG["depths"], CFG["groups"], CFG["offset_scale"], **okw)
+    sum((f * g).sum() for f, g in zip(ref, gs)).backward()
+    group = "internimage_%s_%s" % (name, precision)
+    grads = dict(net.named_parameters())
+    assert set(grads) == set(p)
+    if precision == "fp32":
+        tol_fix = 2e-4       # (measured: <= 2.8e-5 against the reference's float64 run, <= 2.6e-5 against the oracle for every parameter)
+        for i, f in enumerate(feats):
+            assert rel_err(f.cpu(), torch.from_numpy(FIX["%s.feat%d" % (name, i)])) < tol_fix, i
+        v = rel_err(x.grad.cpu(), torch.from_numpy(FIX[name + ".grad_img"]))
+        record_parity(group + "_vs_reference_f64", "grad_img", v)
+        assert v < tol_fix, v
+        for k in FIX.files:
+            if k.startswith(name + ".grad."):
+                v = rel_err(grads[k[len(name) + 6:]].grad.cpu(), torch.from_numpy(FIX[k]))
+                record_parity(group + "_vs_reference_f64", k[len(name) + 6:], v)
+                assert v < tol_fix, (k, v)
+        for n, q in grads.items():
+            v = rel_err(q.grad.cpu(), p[n].grad)
+            record_parity(group, n, v)
+            assert v < tol_fix, (n, v)
+    else:
+        for i, (f, r) in enumerate(zip(feats, ref)):
+            v = _l2(f.detach().cpu(), r.detach())
+            record_parity(group, "feat%d_l2" % i, v)
+            assert v < 2e-2, (i, v)
+        v = _l2(x.grad.cpu(), xr.grad)
+        record_parity(group, "grad_img_l2", v)
+        assert v < 0.15
+        pa = {k: v.clone().requires_grad_(True) for k, v in _variant_params(shapes, precision).items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            fa = IO.backbone_forward(img.clone(), pa, CFG["depths"], CFG["groups"], CFG["offset_scale"], **okw)
+        sum((f.float() * g).sum() for f, g in zip(fa, gs)).backward()
+        for n, q in grads.items():
+            v = _l2(q.grad.cpu(), p[n].grad)
+            va = _l2(pa[n].grad.float(), p[n].grad)
+            record_parity(group, n + "_l2", v)
+            assert v < max(0.1, 1.5 * va), (n, v, va)
+
+
+@pytest.mark.parametrize("name", ["prenorm_ls", "respostnorm_l2"])
+def test_internimage_layer_variants_with_cp_and_drop_path(name):
+    """with_cp on the pre-norm schedules recomputes each layer and gives the same gradients (same explicit drop-path factors); drop path > 0 trains finite"""
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(4)).cuda()
+    out = {}
+    for cp in (False, True):
+        net, _, _ = _variant_net(name, "fp32", with_cp=cp, drop_path_rate=0.3)
+        torch.manual_seed(7)
+        f = net(img)
+        sum((t * t).sum() for t in f).backward()
+        out[cp] = ([t.detach().clone() for t in f], {n: q.grad.clone() for n, q in net.named_parameters()})
+    for a, b in zip(out[False][0], out[True][0]):
+        assert torch.equal(a, b)
+    for n in out[False][1]:
+        assert torch.isfinite(out[True][1][n]).all(), n
+        assert rel_err(out[True][1][n], out[False][1][n]) < 1e-5, n
+    with torch.no_grad():
+        g = net.eval()(img)
+    assert not torch.equal(g[3], out[True][0][3])       # some branches were dropped / rescaled in training
+
+
+@pytest.mark.parametrize("name", ["prenorm_ls", "respostnorm_l2"])
+def test_internimage_layer_variants_through_the_data_parallel_trainer(name):
+    """the flat-buffer trainer (fused AdamW + weight images, gradient norm as a by-product of the weight-gradient launches) over a pre-norm model: one step's gradients
+    equal the autograd path's, the parameters move, a second step runs -- the level norms / post norms / res_post_norms sit in the flat order their backward follows"""
+    from mtp_amd.parallel import DataParallelTrainer
+    net_a, _, _ = _variant_net(name, "bf16")
+    net_b, _, _ = _variant_net(name, "bf16")
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def loss_and_grads(feats):
+        return sum(f.float().mean() for f in feats), [torch.full_like(f, 1.0 / f.numel()) for f in feats]
+    sum(f.float().mean() for f in net_a(img)).backward()
+    want = {n: p.grad.clone() for n, p in net_a.named_parameters()}
+    tr = DataParallelTrainer(net_b, lr=1e-3, weight_decay=0.05, max_norm=5.0, total_steps=10, feature_dtype=torch.float32)
+    before = tr.flat.data.clone()
+    tr.step(img, loss_and_grads)
+    torch.cuda.synchronize()
+    for n, g in want.items():
+        assert rel_err(tr.flat.G[n], g) < 2e-3, n
+    assert float((tr.flat.data - before).abs().max()) > 0
+    assert torch.isfinite(tr.step(img, loss_and_grads))

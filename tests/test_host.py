@@ -227,6 +227,9 @@ def test_unsupported_configs_fail_loudly():
     with pytest.raises(NotImplementedError):
         mtp_amd.ViT_Win_RVSA_V3_WSZ7(patch_size=4)                   # the reference defines FPN tails for 16 and 8 only
     mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=3, num_heads=2, interval=3, out_indices=[0, 1, 2, 2], init_values=0.1)   # accepted since round 5 (fixture f14)
+    # hybrid_backbone: the reference's own constructor dies on it (HybridEmbed has no patch_shape, VIT:628) -- refused here with that explanation
+    with pytest.raises(NotImplementedError, match="patch_shape"):
+        mtp_amd.ViT_Win_RVSA_V3_WSZ7(embed_dim=128, depth=3, num_heads=2, hybrid_backbone=torch.nn.Conv2d(3, 8, 16, 16))
 
 
 def test_import_sets_the_hardware_queue_count_unless_the_user_did():

@@ -14,7 +14,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import recipe  # noqa: E402
 
 FIX = np.load(os.path.join(ROOT, "tests", "golden", "f12_internimage.npz"))
+FIX15 = np.load(os.path.join(ROOT, "tests", "golden", "f15_internimage_variants.npz"))
 CFG = recipe.II_CFG
+# fixture f15 (make_golden.py F15_VARIANTS): the reference's other InternImageLayer branches (II:407-427) and block norms (II:497-517)
+VARIANTS = recipe.II_VARIANTS
+
+
+def variant_shapes(kw):
+    return IO.state_shapes(CFG["channels"], CFG["depths"], CFG["groups"], post_norm=kw["post_norm"], layer_scale=kw["layer_scale"] is not None,
+                           res_post_norm=kw.get("res_post_norm", False), level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"))
 
 
 def rel(a, b):
@@ -66,7 +74,9 @@ def test_hip_backbone_class_has_the_reference_state_dict_and_init_rules():
     with pytest.raises(NotImplementedError):
         mtp_amd.InternImage(layer_scale=1.0, post_norm=True, center_feature_scale=True)
     with pytest.raises(NotImplementedError):
-        mtp_amd.InternImage(layer_scale=None, post_norm=False)
+        mtp_amd.InternImage(layer_scale=1.0, post_norm=True, dw_kernel_size=5)
+    with pytest.raises(ValueError):
+        mtp_amd.InternImage(layer_scale=1.0, post_norm=False, res_post_norm=True)      # (the reference would silently ignore res_post_norm here, II:408-427)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 64, 64))          # no CPU path
 
@@ -87,3 +97,42 @@ def test_flat_gradient_layout_follows_the_backward_order_of_the_levels():
     assert b[0][1] == 0 and b[-1][2] == flat.total and all(x[2] == y[1] for x, y in zip(b, b[1:]))
     # parameters now live in the flat buffer (views), values unchanged
     assert net.state_dict()["levels.0.blocks.0.gamma1"].data_ptr() == flat.view(flat.data, "levels.0.blocks.0.gamma1").data_ptr()
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_layer_variants_oracle_and_class_surface_vs_reference(name):
+    """fixture f15 = the reference's InternImage(core_op='DCNv3_pytorch') built with the other layer branches: pre-norm with / without layer scale
+    (InternImage-T/S/B), post-norm without layer scale, res_post_norm + level-2 post norms (the H/G layer form).  The oracle reproduces features and
+    gradients; mtp_amd.InternImage has the same state-dict keys / shapes / order and a flat-gradient order that follows its backward."""
+    import mtp_amd
+    from mtp_amd.parallel import FlatParams
+    kw = VARIANTS[name]
+    shapes = variant_shapes(kw)
+    assert list(shapes.keys()) == [str(k) for k in FIX15[name + ".keys"]]
+    assert [str(tuple(v)) for v in shapes.values()] == [str(s) for s in FIX15[name + ".shapes"]]
+    p = {k: v.double().requires_grad_(True) for k, v in recipe.internimage_variant_params(shapes).items()}
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(recipe.II_VARIANT_SEEDS[name])).double().requires_grad_(True)
+    feats = IO.backbone_forward(img, p, CFG["depths"], CFG["groups"], CFG["offset_scale"], post_norm=kw["post_norm"],
+                                level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"))
+    tol_f, tol_g = 2e-5, 2e-4      # (as for f12: what is left is the float32 sampling grid of the reference's dcnv3_core_pytorch)
+    for i, f in enumerate(feats):
+        assert rel(f.detach(), torch.from_numpy(FIX15["%s.feat%d" % (name, i)]).double()) < tol_f, i
+    gs = [torch.randn(f.shape, generator=torch.Generator().manual_seed(200 + i)).double() for i, f in enumerate(feats)]
+    sum((f * g).sum() for f, g in zip(feats, gs)).backward()
+    assert rel(img.grad, torch.from_numpy(FIX15[name + ".grad_img"]).double()) < tol_g
+    n = 0
+    for k in FIX15.files:
+        if k.startswith(name + ".grad."):
+            assert rel(p[k[len(name) + 6:]].grad, torch.from_numpy(FIX15[k]).double()) < tol_g, k
+            n += 1
+    assert n >= 9
+    net = mtp_amd.InternImage(channels=CFG["channels"], depths=CFG["depths"], groups=CFG["groups"], offset_scale=CFG["offset_scale"], **kw)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in FIX15[name + ".keys"]] and [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in FIX15[name + ".shapes"]]
+    flat = FlatParams(net, unused=net._unused_params)
+    gids = [flat.groups[m] for m in flat.names]
+    assert gids == sorted(gids, reverse=True) and gids[-1] == -1
+    if not kw["post_norm"]:
+        assert flat.groups["levels.1.norm.0.weight"] == flat.groups["levels.1.blocks.0.mlp.fc1.weight"]
+    if kw.get("level2_post_norm"):
+        assert flat.groups["levels.2.post_norms.0.0.weight"] == flat.groups["levels.2.blocks.0.mlp.fc1.weight"]
