@@ -346,7 +346,8 @@ typedef struct {
     int variant;   /* 0 = default; bit0 = plain workgroup order instead of one contiguous pixel range per XCD (A/B);
                     * bit1 = backward always as the per-corner f32-atomic scatter (default: the gather form where the geometry allows it);
                     * bit2 = the gather backward in its 3 x 3 form (dilation 1, offset_scale 1 or 2): 81 instead of 441 candidate samples per input
-                    *        pixel, faster while the offsets stay below one pixel, slower beyond (its reach is narrower than the window form's) */
+                    *        pixel, faster while the offsets stay below one pixel, slower beyond (its reach is narrower than the window form's);
+                    * bit3 = the generic forward kernel also for 3 x 3 kernels (default there: the unrolled 9-point forward, round 6) */
 } mtp_dcnv3_geom;
 /* Ho = (H + 2 pad_h - (dilation_h (kernel_h - 1) + 1)) / stride_h + 1, Wo likewise (dcnv3_cuda.cu:40-45) */
 int mtp_dcnv3_out_size(const mtp_dcnv3_geom* geom, int64_t* Ho, int64_t* Wo);

@@ -20,6 +20,7 @@ struct DcnGeom {
     float os;
     int xcd_order;   // 1: each of the 8 XCDs takes a contiguous range of workgroups (= of pixels), see block_index()
     int scatter_bwd; // 1: always the per-corner atomic scatter backward (A/B, variant bit 1)
+    int fwd_generic; // 1: the generic forward also for 3 x 3 kernels (A/B: MTP_DCN_FWD=generic)
     int form3x3_bwd; // 1: the 3 x 3 form of the gather backward where it applies (variant bit 2): faster while offsets stay below a pixel, slower beyond
     void* goff_act;  // mtp_dcnv3_bwd_act: also write grad_offset in the input dtype, rows of goff_act_ld >= G * P * 2 elements (pad columns zeroed)
     int goff_act_ld;
@@ -137,6 +138,91 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T* __restrict__ in
         }
     }
     store_chunk<T, CPL>(out + it.pix * C + chan, acc);
+}
+
+// The 3 x 3 forward (every DCNv3 layer of InternImage: kernel 3, no remove_center), 8 channels per lane: compile-time point loops, the 18 offsets and 9 mask
+// values of the lane's (pixel, group) loaded up front ((dx, dy) of a point = one 4-byte load for bf16), and the gathers issued three points = 12 loads at a time
+// before the first is used -- the generic kernel above walks the points in a run-time loop, 3 two-byte loads then 4 gathers per trip, one round trip after the other.
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+    struct type { float4 a, b; };
+    static __device__ __forceinline__ type load(const float* p) { return type{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
+    static __device__ __forceinline__ void cvt(const type& v, float (&o)[8]) { o[0] = v.a.x; o[1] = v.a.y; o[2] = v.a.z; o[3] = v.a.w; o[4] = v.b.x; o[5] = v.b.y; o[6] = v.b.z; o[7] = v.b.w; }
+};
+template <> struct Raw8<bf16_t> {
+    typedef uint4 type;
+    static __device__ __forceinline__ type load(const bf16_t* p) { return ldg16(reinterpret_cast<const char*>(p)); }
+    static __device__ __forceinline__ void cvt(const type& v, float (&o)[8]) {
+        o[0] = bf16_bits_to_f32(v.x & 0xffffu); o[1] = bf16_bits_to_f32(v.x >> 16); o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
+        o[4] = bf16_bits_to_f32(v.z & 0xffffu); o[5] = bf16_bits_to_f32(v.z >> 16); o[6] = bf16_bits_to_f32(v.w & 0xffffu); o[7] = bf16_bits_to_f32(v.w >> 16);
+    }
+};
+
+template <typename T> struct OffPair;
+template <> struct OffPair<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float& a, float& b) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+        a = bf16_bits_to_f32(w & 0xffffu);
+        b = bf16_bits_to_f32(w >> 16);
+    }
+};
+template <> struct OffPair<float> {
+    static __device__ __forceinline__ void load(const float* p, float& a, float& b) {
+        const float2 w = *reinterpret_cast<const float2*>(p);
+        a = w.x;
+        b = w.y;
+    }
+};
+template <typename T>
+__global__ __launch_bounds__(256) void dcnv3_fwd9_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, T* __restrict__ out,
+                                                         DcnGeom g, int64_t total) {
+    const int64_t idx = block_index(g) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int chunks = g.GC / 8;
+    const Item it = decode(g, idx, chunks);
+    const int C = g.G * g.GC;
+    const int chan = it.gi * g.GC + it.chunk * 8;
+    const T* in_n = input + (int64_t)it.n * g.H * g.W * C + chan;
+    const T* offp = offset + it.item * 18;
+    const T* mp = mask + it.item * 9;
+    const float p0w = (float)(g.dw - g.pw + it.wo * g.sw) - (float)g.dw * g.os;
+    const float p0h = (float)(g.dh - g.ph + it.ho * g.sh) - (float)g.dh * g.os;
+    float ow[9], oh[9], m[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        OffPair<T>::load(offp + 2 * p, ow[p], oh[p]);
+        m[p] = Elem<T>::load(mp + p);
+    }
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {      // point p = 3 i + j: i over kernel_w, j over kernel_h
+        float w[3][4];
+        typename Raw8<T>::type raw[3][4];      // (kept as loaded: 4 registers per 16-byte gather, converted when used)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = 3 * i + j;
+            const Point pt = make_point(g, p0h + ((float)(j * g.dh) + oh[p]) * g.os, p0w + ((float)(i * g.dw) + ow[p]) * g.os, C);
+            const float hh = 1.f - pt.lh, hw = 1.f - pt.lw;
+            w[j][0] = hh * hw * pt.k00 * m[p]; w[j][1] = hh * pt.lw * pt.k01 * m[p]; w[j][2] = pt.lh * hw * pt.k10 * m[p]; w[j][3] = pt.lh * pt.lw * pt.k11 * m[p];
+            raw[j][0] = Raw8<T>::load(in_n + pt.o00);
+            raw[j][1] = Raw8<T>::load(in_n + pt.o01);
+            raw[j][2] = Raw8<T>::load(in_n + pt.o10);
+            raw[j][3] = Raw8<T>::load(in_n + pt.o11);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[8];
+                Raw8<T>::cvt(raw[j][k], v);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += w[j][k] * v[c];
+            }
+        __builtin_amdgcn_sched_barrier(0);      // (three points = 12 gathers in flight per lane: without it hipcc either hoists all 36 -- 318 VGPRs with converted values -- or, on raw registers, schedules them so that the bf16 kernel is 5 % and the f32 kernel 25 % slower)
+    }
+    store8(out + it.pix * C + chan, acc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -446,29 +532,21 @@ __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input3x3_kernel(const T* __r
 // through LDS.  NEAR = 1: the window form's reach R around the output pixel; NEAR = 2: the 3 x 3 form's reach of one pixel around the nominal
 // position (OS = R - 1).
 // eight consecutive elements as loaded (16 bytes of bf16 stay packed until they are used)
-template <typename T> struct Raw8;
-template <> struct Raw8<float> {
-    struct type { float4 a, b; };
-    static __device__ __forceinline__ type load(const float* p) { return type{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
-    static __device__ __forceinline__ void cvt(const type& v, float (&o)[8]) { o[0] = v.a.x; o[1] = v.a.y; o[2] = v.a.z; o[3] = v.a.w; o[4] = v.b.x; o[5] = v.b.y; o[6] = v.b.z; o[7] = v.b.w; }
-};
-template <> struct Raw8<bf16_t> {
-    typedef uint4 type;
-    static __device__ __forceinline__ type load(const bf16_t* p) { return ldg16(reinterpret_cast<const char*>(p)); }
-    static __device__ __forceinline__ void cvt(const type& v, float (&o)[8]) {
-        o[0] = bf16_bits_to_f32(v.x & 0xffffu); o[1] = bf16_bits_to_f32(v.x >> 16); o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
-        o[4] = bf16_bits_to_f32(v.z & 0xffffu); o[5] = bf16_bits_to_f32(v.z >> 16); o[6] = bf16_bits_to_f32(v.w & 0xffffu); o[7] = bf16_bits_to_f32(v.w >> 16);
-    }
-};
-
 template <typename T, int NEAR>
 __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__ input, const T* __restrict__ offset, const T* __restrict__ mask, const T* __restrict__ grad_out,
                                                            float* __restrict__ grad_input, float* __restrict__ grad_offset, float* __restrict__ grad_mask, DcnGeom g, int64_t total,
                                                            int R) {
     __shared__ float tops[4][64][9];
+    // the wave's results -- d(mask) 32 items x 9, d(offset) 32 items x 18 f32 -- collected here and written out as whole 16-byte pieces of the wave's contiguous
+    // output ranges (round 6): item by item they were 9 four-byte + 9 eight-byte (+ 18 two-byte) stores per lane, 40 % of the kernel at the 128 x 128 level
+    __shared__ __attribute__((aligned(16))) float stage[4][32 * 27];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t idx_raw = block_index(g) * 256 + threadIdx.x;
     const bool live = idx_raw < 2 * total;               // (no early return: the far-sample scatter below needs all 64 lanes)
+    const int64_t item0 = (idx_raw - lane) >> 1;         // first item of this wave
+    const bool staged = g.P == 9 && item0 + 32 <= total; // (wave-uniform) all 32 items live, 9 points: the coalesced write-out below
+    float* stM = stage[wave];
+    float* stO = stage[wave] + 32 * 9;
     const int64_t idx = live ? idx_raw : 2 * total - 1;
     const int half = (int)(idx & 1);
     const int64_t item = idx >> 1;
@@ -543,7 +621,13 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
             }
             const float d00 = d[0] * pt[q].k00, d01 = d[1] * pt[q].k01, d10 = d[2] * pt[q].k10, d11 = d[3] * pt[q].k11;
             const float lh = pt[q].lh, lw = pt[q].lw, hh = 1.f - lh, hw = 1.f - lw;
-            if (live && half == 0 && have) {
+            if (staged) {
+                if (half == 0) {      // (both lanes of the pair hold the sums)
+                    const float gw_ = g.os * m * (hh * (d01 - d00) + lh * (d11 - d10)), gh_ = g.os * m * (hw * (d10 - d00) + lw * (d11 - d01));
+                    stM[(lane >> 1) * 9 + p] = hh * hw * d00 + hh * lw * d01 + lh * hw * d10 + lh * lw * d11;
+                    *reinterpret_cast<float2*>(stO + (lane >> 1) * 18 + 2 * p) = make_float2(gw_, gh_);
+                }
+            } else if (live && half == 0 && have) {
                 gmp[p] = hh * hw * d00 + hh * lw * d01 + lh * hw * d10 + lh * lw * d11;
                 const float gw_ = g.os * m * (hh * (d01 - d00) + lh * (d11 - d10)), gh_ = g.os * m * (hw * (d10 - d00) + lw * (d11 - d01));
                 *reinterpret_cast<float2*>(goffp + 2 * p) = make_float2(gw_, gh_);
@@ -563,6 +647,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
             const bool far = w00 != 0.f || w01 != 0.f || w10 != 0.f || w11 != 0.f;
             uint64_t fm = __builtin_amdgcn_ballot_w64(far);
             if (fm) {
+                // (round 6 tried the far CORNERS of the wave as one list in LDS, 16 lanes per corner and four corners per atomic instruction -- 28 instead of 66 atomic
+                //  instructions per wave on 32 x 32 maps: 108.8 vs 110.0 us there, 327 vs 282 us on 128 x 128 maps where few samples are far; what the section costs
+                //  is the atomics themselves (25 us of 108 with the instructions not issued) and the per-sample reach tests, not the readlanes)
                 const int k = lane >> 4, c = lane & 15;
                 const uint32_t img_lo = (uint32_t)((uint64_t)img & 0xffffffffu), img_hi = (uint32_t)((uint64_t)img >> 32);
                 while (fm) {
@@ -577,6 +664,39 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_om_kernel(const T* __restrict__
                     const float wk = k == 0 ? x00 : k == 1 ? x01 : k == 2 ? x10 : x11;
                     if (wk != 0.f) atomicAdd(grad_input + imgL + ok + c, wk * tops[wave][L + (c >> 3)][c & 7]);
                 }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the batches of 12 gathers apart: with the results going to LDS nothing else orders the next batch's loads behind this one's use)
+    }
+    if (staged) {
+        // (the staging rows cross lanes: wavefront-scope fences around a wave barrier -- one wave's LDS operations execute in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float4* gm4 = reinterpret_cast<float4*>(grad_mask + item0 * 9);        // 288 floats = 72 pieces; item0 is a multiple of 32: 16-byte aligned
+        float4* go4 = reinterpret_cast<float4*>(grad_offset + item0 * 18);     // 576 floats = 144 pieces
+        const float4* sm4 = reinterpret_cast<const float4*>(stM);
+        const float4* so4 = reinterpret_cast<const float4*>(stO);
+        gm4[lane] = sm4[lane];
+        if (lane < 8) gm4[64 + lane] = sm4[64 + lane];
+        go4[lane] = so4[lane];
+        go4[64 + lane] = so4[64 + lane];
+        if (lane < 16) go4[128 + lane] = so4[128 + lane];
+        if (g.goff_act) {
+            T* ga = reinterpret_cast<T*>(g.goff_act);
+            if (g.goff_act_ld == g.G * 18 && sizeof(T) == 2) {      // the operand rows are contiguous too (every InternImage level: 18 G is a multiple of 8): 576 bf16 = 72 pieces
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int i8 = 64 * r + lane;
+                    if (i8 < 72) {
+                        const float4 a = so4[2 * i8], b = so4[2 * i8 + 1];
+                        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ga) + (item0 * 18 + 8 * i8) * 2) = pack_bf16x8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+                    }
+                }
+            } else if (half == 0) {
+                T* row = ga + pix * g.goff_act_ld + gi * 18;
+#pragma unroll
+                for (int e = 0; e < 18; ++e) Elem<T>::store(row + e, stO[(lane >> 1) * 18 + e]);
             }
         }
     }
@@ -605,6 +725,7 @@ int make_geom(const mtp_dcnv3_geom* a, DcnGeom& g) {
     g.xcd_order = (a->variant & 1) ? 0 : 1;
     g.scatter_bwd = (a->variant & 2) ? 1 : 0;
     g.form3x3_bwd = (a->variant & 4) ? 1 : 0;
+    g.fwd_generic = (a->variant & 8) ? 1 : 0;
     g.goff_act = nullptr;
     g.goff_act_ld = 0;
     return 0;
@@ -614,7 +735,11 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 template <typename T>
 int launch_fwd(const void* input, const void* offset, const void* mask, void* output, const DcnGeom& g, hipStream_t s) {
     const int64_t items = (int64_t)g.N * g.Ho * g.Wo * g.G;
-    if (g.GC % 8 == 0 && aligned16(input) && aligned16(output)) {
+    if (g.GC % 8 == 0 && aligned16(input) && aligned16(output) && g.kh == 3 && g.kw == 3 && !g.remove_center && !g.fwd_generic &&
+        (reinterpret_cast<uintptr_t>(offset) & 7u) == 0) {
+        const int64_t total = items * (g.GC / 8);
+        hipLaunchKernelGGL((dcnv3_fwd9_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (T*)output, g, total);
+    } else if (g.GC % 8 == 0 && aligned16(input) && aligned16(output)) {
         const int64_t total = items * (g.GC / 8);
         hipLaunchKernelGGL((dcnv3_fwd_kernel<T, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)input, (const T*)offset, (const T*)mask, (T*)output, g, total);
     } else {
