@@ -237,6 +237,14 @@ class InternImage(nn.Module):
         names = sorted(groups, key=lambda k: -groups[k])        # stable: the module's order inside a group
         return names, groups, base[-1]
 
+    @staticmethod
+    def _overwritten_grads(name):
+        """gradients the engine writes with a full overwrite whenever it writes them (mtp_amd.parallel.FlatParams skips clearing them; 98 % of the buffer): the Linear
+        and dense-convolution weights -- grouped TN GEMM outputs.  A level no cotangent reaches is skipped by the backward, which then clears these itself
+        (InternEngine.backward), so an unused tap still leaves zeros."""
+        return name.endswith((".dcn.input_proj.weight", ".dcn.output_proj.weight", ".dcn.offset.weight", ".dcn.mask.weight", ".mlp.fc1.weight", ".mlp.fc2.weight",
+                              ".downsample.conv.weight", "patch_embed.conv1.weight", "patch_embed.conv2.weight"))
+
     # ------------------------------------------------------------------ execution
     def _engine(self):
         from ..engine_intern import InternEngine

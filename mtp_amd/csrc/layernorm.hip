@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int LN_THREADS = 256;   // 4 rows per block pass
-constexpr int MAXV = 8;           // float4 per lane kept in registers: kernels are instantiated for 4 (C <= 1024: the ViTs) and 8 (C <= 2048: InternImage-XL's 1536)
+constexpr int MAXV = 8;           // float4 per lane kept in registers: kernels are instantiated for 1, 2, 3, 4, 6 and 8 (C <= 2048), see MTP_LN_MV
 
 // All row loads are UNCONDITIONAL on a clamped column (lanes past the row end re-read the last group and are masked in the
 // arithmetic / at the store): with `if (c4 < nv)` around them hipcc emitted an exec-masked block + s_waitcnt vmcnt(0) per load,
@@ -440,18 +440,30 @@ int ln_grid(int64_t rows) {
     return (int)(nb < 2048 ? nb : 2048);
 }
 
+// float4 groups per lane the row kernels keep in registers: instantiated for 1, 2, 3, 4, 6, 8 (C <= 256 ... 2048).  Every load, store and arithmetic step of a
+// row runs MV times per lane, masked or not (the loads are unconditional on clamped columns), so a 192-channel row on the MV = 4 kernel did four times its work --
+// round 6: InternImage's 96- / 192-channel stem and first level ran at a quarter of their bandwidth (the stem's LayerNorm backward: 617 us for 300 MB).
+#define MTP_LN_MV(C_, CALL)                                      \
+    do {                                                         \
+        const int mv_ = (int)(((C_) / 4 + 63) / 64);             \
+        if (mv_ <= 1) { CALL(1); }                               \
+        else if (mv_ == 2) { CALL(2); }                          \
+        else if (mv_ == 3) { CALL(3); }                          \
+        else if (mv_ == 4) { CALL(4); }                          \
+        else if (mv_ <= 6) { CALL(6); }                          \
+        else { CALL(8); }                                        \
+    } while (0)
+
 template <typename Tx, typename Ty>
 int launch_ln_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t rows, int64_t C, float eps, int gelu, hipStream_t s) {
     dim3 grid(ln_grid(rows)), block(LN_THREADS);
-    if (C > 1024) {
-        if (gelu)
-            hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, true, 8>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
-        else
-            hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, false, 8>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
-    } else if (gelu)
-        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, true, 4>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
-    else
-        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, false, 4>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);
+#define MTP_CALL(MV_)                                                                                                                                        \
+    if (gelu)                                                                                                                                                \
+        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, true, MV_>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps);                \
+    else                                                                                                                                                     \
+        hipLaunchKernelGGL((ln_fwd_kernel<Tx, Ty, false, MV_>), grid, block, 0, s, (const Tx*)x, g, b, (Ty*)y, mean, rstd, rows, (int)C, eps)
+    MTP_LN_MV(C, MTP_CALL);
+#undef MTP_CALL
     return mtp_launch_status();
 }
 
@@ -460,19 +472,15 @@ int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float*
                   const float* dres, const float* extra, void* dx, void* dx_copy, const float* copy_scale, int64_t rps,
                   float* dgp, float* dbp, int64_t part_ld, int64_t rows, int64_t C, hipStream_t s, const float* win_add = nullptr, LnWin wg = LnWin{1, 1, 0, 0, 1, 1}) {
     dim3 grid((unsigned)mtp_layernorm_bwd_partial_rows(rows)), block(LN_THREADS);
-    if (C > 1024) {
-        if (gelu)
-            hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true, 8>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);
-        else
-            hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false, 8>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);
-    } else if (gelu)
-        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true, 4>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);
-    else
-        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false, 4>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra,
-                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);
+#define MTP_CALL(MV_)                                                                                                                                        \
+    if (gelu)                                                                                                                                                \
+        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, true, MV_>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra, \
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg);                    \
+    else                                                                                                                                                     \
+        hipLaunchKernelGGL((ln_bwd_kernel<Tact, Tx, Tdx, false, MV_>), grid, block, 0, s, (const Tact*)dy, (const Tx*)x, mean, rstd, gamma, beta, dres, extra, \
+                           (Tdx*)dx, (Tact*)dx_copy, copy_scale, (int)(rps > 0 ? rps : 1), dgp, dbp, part_ld, rows, (int)C, win_add, wg)
+    MTP_LN_MV(C, MTP_CALL);
+#undef MTP_CALL
     return mtp_launch_status();
 }
 
@@ -495,16 +503,14 @@ static int launch_ln_res(bool fwd, const void* a0, const void* h, const float* m
                          hipStream_t s) {
     if (fwd) {
         const dim3 grid(ln_grid(rows)), block(LN_THREADS);
-        if (C > 1024)
-            hipLaunchKernelGGL((ln_res_fwd_kernel<Th, 8>), grid, block, 0, s, (const Th*)h, gamma, beta, x, ls, ss, rps, out, (Th*)oact, mean, rstd, rows, (int)C, eps);
-        else
-            hipLaunchKernelGGL((ln_res_fwd_kernel<Th, 4>), grid, block, 0, s, (const Th*)h, gamma, beta, x, ls, ss, rps, out, (Th*)oact, mean, rstd, rows, (int)C, eps);
+#define MTP_CALL(MV_) hipLaunchKernelGGL((ln_res_fwd_kernel<Th, MV_>), grid, block, 0, s, (const Th*)h, gamma, beta, x, ls, ss, rps, out, (Th*)oact, mean, rstd, rows, (int)C, eps)
+        MTP_LN_MV(C, MTP_CALL);
+#undef MTP_CALL
     } else {
-        const dim3 grid((unsigned)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512)), block(LN_THREADS);
-        if (C > 1024)
-            hipLaunchKernelGGL((ln_res_bwd_kernel<Th, 8>), grid, block, 0, s, (const float*)a0, (const Th*)h, mean_c, rstd_c, gamma, beta, ls, ss, rps, (Th*)dh, part, rows, (int)C);
-        else
-            hipLaunchKernelGGL((ln_res_bwd_kernel<Th, 4>), grid, block, 0, s, (const float*)a0, (const Th*)h, mean_c, rstd_c, gamma, beta, ls, ss, rps, (Th*)dh, part, rows, (int)C);
+        const dim3 grid((unsigned)mtp_layernorm_bwd_partial_rows(rows)), block(LN_THREADS);
+#define MTP_CALL(MV_) hipLaunchKernelGGL((ln_res_bwd_kernel<Th, MV_>), grid, block, 0, s, (const float*)a0, (const Th*)h, mean_c, rstd_c, gamma, beta, ls, ss, rps, (Th*)dh, part, rows, (int)C)
+        MTP_LN_MV(C, MTP_CALL);
+#undef MTP_CALL
     }
     return mtp_launch_status();
 }
@@ -532,8 +538,12 @@ extern "C" int mtp_layernorm_residual_bwd(const float* dout, const void* h, int 
 }
 
 extern "C" int64_t mtp_layernorm_bwd_partial_rows(int64_t rows) {
-    int64_t nb = (rows + 3) / 4;
-    return nb < 512 ? nb : 512;
+    // workgroups of the backward kernels = rows of their parameter-gradient partials.  512 (two per CU) up to 64 K rows -- every ViT shape; maps with more rows
+    // (InternImage's 128 x 128 level and its stem at 512^2: 131 K / 524 K rows of 192 / 96 channels) get 1024 / 2048: their rows are short, the wave-serial row loop
+    // is latency-bound and the partial buffer small (round 6)
+    const int64_t nb = (rows + 3) / 4;
+    const int64_t cap = rows > 262144 ? 2048 : rows > 65536 ? 1024 : 512;
+    return nb < cap ? nb : cap;
 }
 
 extern "C" int mtp_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,

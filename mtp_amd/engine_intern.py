@@ -502,6 +502,8 @@ class InternEngine:
                 dprev = self._e(rows, C, dtype=F32)
                 self._conv_bwd(dyd, colsd, pre + "conv.weight", G, None, dprev, (Hc * Wc * C, Wc * C, C, 1), N, Hc, Wc, C, 2)
                 dx32 = dprev
+            elif lv["down"] is not None:      # no gradient arrives through this level's downsample: its overwrite-only weight gradient must read zero
+                G["levels.%d.downsample.conv.weight" % i].zero_()
             d = taps.get(i)
             if d is not None:
                 d = d if (d.dtype in (F32, torch.bfloat16) and d.is_contiguous()) else d.float().contiguous()
@@ -509,7 +511,11 @@ class InternEngine:
                     dx32 = ops.nchw_to_tokens(d, self._e(rows, C, dtype=F32), N, Hc, Wc, 0)
                 else:
                     ops.axpy(dx32, ops.nchw_to_tokens(d, self._e(rows, C, dtype=F32), N, Hc, Wc, 0))
-            if dx32 is None:      # nothing downstream of this level has a gradient
+            if dx32 is None:      # nothing downstream of this level has a gradient: its overwrite-only gradients are not written -- they must read zero
+                pre = "levels.%d." % i       # (FlatParams does not clear them, InternImage._overwritten_grads)
+                for n, gbuf in G.items():
+                    if n.startswith(pre) and m._overwritten_grads(n):
+                        gbuf.zero_()
                 continue
             if lv.get("norm") is not None:
                 dx32 = self._norm_f32_bwd(dx32, lv["norm"], G)

@@ -608,3 +608,40 @@ def test_internimage_layer_variants_through_the_data_parallel_trainer(name):
         assert rel_err(tr.flat.G[n], g) < 2e-3, n
     assert float((tr.flat.data - before).abs().max()) > 0
     assert torch.isfinite(tr.step(img, loss_and_grads))
+
+
+def test_internimage_trainer_clears_only_what_accumulates_and_unused_taps_still_read_zero():
+    """FlatParams clears only the accumulating gradients of InternImage (InternImage._overwritten_grads: the Linear / convolution weights are TN GEMM outputs, 98 % of
+    the buffer).  A step whose loss ignores the deeper maps leaves the deeper levels' weight gradients unwritten: the backward zeroes them itself, so they do not keep
+    the previous step's values."""
+    from mtp_amd.parallel import DataParallelTrainer
+    net, _ = _net("bf16")
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    tr = DataParallelTrainer(net, lr=1e-4, weight_decay=0.05, max_norm=5.0, total_steps=10, feature_dtype=torch.float32)
+    assert tr.flat._zero_tab is not None
+    cleared = int(tr.flat._zero_tab[1].sum())
+    assert cleared < 0.1 * tr.flat.total      # (the small test model: 6 % accumulates; InternImage-XL: 2 %)
+
+    def full(feats):
+        return sum(f.float().mean() for f in feats), [torch.full_like(f, 1.0 / f.numel()) for f in feats]
+
+    def shallow(feats):      # only the stride-8 map carries a gradient
+        return feats[1].float().mean(), [None, torch.full_like(feats[1], 1.0 / feats[1].numel()), None, None]
+    tr.step(img, full)
+    torch.cuda.synchronize()
+    assert float(tr.flat.G["levels.3.blocks.0.mlp.fc1.weight"].abs().max()) > 0 and float(tr.flat.G["levels.1.downsample.conv.weight"].abs().max()) > 0
+    tr.step(img, shallow)
+    torch.cuda.synchronize()
+    for n, g in tr.flat.G.items():
+        deep = n.startswith(("levels.2.", "levels.3.", "levels.1.downsample."))
+        if deep:
+            assert float(g.abs().max()) == 0.0, n
+    assert float(tr.flat.G["levels.1.blocks.0.mlp.fc1.weight"].abs().max()) > 0 and float(tr.flat.G["levels.0.downsample.conv.weight"].abs().max()) > 0
+    # the autograd path (fresh zero buffers) on the same loss and the same parameters: the same non-zero gradients
+    net2, _ = _net("bf16")
+    net2.load_state_dict(net.state_dict())
+    net2(img)[1].float().mean().backward()
+    tr.step(img, shallow)
+    torch.cuda.synchronize()
+    for n, p in net2.named_parameters():
+        assert rel_err(tr.flat.G[n], p.grad) < 2e-3 or float(p.grad.abs().max()) == 0.0, n

@@ -4,7 +4,8 @@ import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 whole = "--all" in sys.argv        # every launch of the trace instead of the last step
-args = [a for a in sys.argv[2:] if a != "--all"]
+top = "--top" in sys.argv          # also: the 40 longest single launches of the step that are not GEMMs / DCNv3
+args = [a for a in sys.argv[2:] if a not in ("--all", "--top")]
 idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"].lower()]
 step = rows if whole else rows[idx[-2] + 1: idx[-1] + 1]
 needles = args or ["dcnv3", "ln_res", "dwconv", "softmax_groups"]
@@ -20,3 +21,13 @@ tot = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)
 print("last step: %d launches, kernel time %.2f ms" % (len(step), tot / 1e6))
 for key in sorted(c, key=lambda k: (k[0], -k[1])):
     print("%-44s grid %9d wg %4d vgpr %4s lds %6s  x%3d  avg %8.1f us  sum %7.3f ms" % (key + (c[key], t[key] / c[key] / 1e3, t[key] / 1e6)))
+
+if top:
+    def short(n):
+        m = re.search(r"(\w+)(<[^(]*>)?\(", n.replace("(anonymous namespace)::", ""))
+        return ((m.group(1) + (m.group(2) or "")) if m else n)[:70]
+    rest = [r for r in step if "gemm" not in r["Kernel_Name"] and "dcnv3" not in r["Kernel_Name"]]
+    rest.sort(key=lambda r: int(r["Start_Timestamp"]) - int(r["End_Timestamp"]))
+    print("longest single launches (GEMMs and DCNv3 aside):")
+    for r in rest[:40]:
+        print("  %8.1f us  grid %9s  %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Grid_Size_X"], short(r["Kernel_Name"])))
