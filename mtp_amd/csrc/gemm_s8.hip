@@ -562,7 +562,7 @@ int mtp_nt_s8_fits(const KArgs& k, int out_dtype, int epi) {
     if ((uint64_t)k.lda * 2 * 8 + (uint64_t)k.K * 2 >= lim || (uint64_t)k.ldb * 2 * 8 + (uint64_t)k.K * 2 >= lim) return 0;
     if ((uint64_t)k.M * (uint64_t)k.ldc * 4 >= lim) return 0;
     const bool hasb = k.bias != nullptr;
-    if (epi == MTP_EPI_BIAS_RES) return out_dtype == MTP_F32 && hasb && k.res && k.res_mod <= 0 && (uint64_t)k.M * (uint64_t)k.res_ld * 4 < lim;
+    if (epi == MTP_EPI_BIAS_RES) return out_dtype == MTP_F32 && k.res && k.res_mod <= 0 && (uint64_t)k.M * (uint64_t)k.res_ld * 4 < lim;      // (with or without a bias: the data-gradient GEMMs of InternImage add a residual gradient and have none)
     if (epi == MTP_EPI_BIAS) return out_dtype == MTP_BF16 || out_dtype == MTP_F32;
     if (out_dtype != MTP_BF16) return 0;
     if (epi == MTP_EPI_BIAS_GELU_DG) return hasb && k.aux && (uint64_t)k.M * (uint64_t)k.aux_ld * 2 < lim;
@@ -573,7 +573,7 @@ int mtp_nt_s8_fits(const KArgs& k, int out_dtype, int epi) {
 int mtp_nt_s8_launch(const KArgs& k, int out_dtype, int epi, int flags, hipStream_t stream) {
     if (!mtp_nt_s8_fits(k, out_dtype, epi)) return MTP_ERR_UNSUPPORTED;
     const bool hasb = k.bias != nullptr;
-    if (epi == MTP_EPI_BIAS_RES) return launch_s8_kernel<float, MTP_EPI_BIAS_RES, true, 2>(k, flags, stream);
+    if (epi == MTP_EPI_BIAS_RES) return hasb ? launch_s8_kernel<float, MTP_EPI_BIAS_RES, true, 2>(k, flags, stream) : launch_s8_kernel<float, MTP_EPI_BIAS_RES, false, 2>(k, flags, stream);
     if (epi == MTP_EPI_BIAS_GELU_DG) return launch_s8_kernel<bf16_t, MTP_EPI_BIAS_GELU_DG, true, 1>(k, flags, stream);
     if (epi == MTP_EPI_MUL) return launch_s8_kernel<bf16_t, MTP_EPI_MUL, false, 1>(k, flags, stream);
     if (out_dtype == MTP_BF16) return hasb ? launch_s8_kernel<bf16_t, MTP_EPI_BIAS, true, 1>(k, flags, stream) : launch_s8_kernel<bf16_t, MTP_EPI_BIAS, false, 1>(k, flags, stream);

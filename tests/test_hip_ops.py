@@ -233,12 +233,14 @@ def test_gemm_nt_s8_bit_identical_to_128_wide_kernels(ops, M, N, K):
         dg = e(M, N, dtype=dtype)
         h2 = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_BIAS_GELU_DG, bias=b, aux=dg, variant=v)
         mu = ops.gemm_nt(a, w, e(M, N, dtype=dtype), epi=ops.EPI_MUL, aux=uu, variant=v)
-        return r, r0, f, f0, y, y0, dg, h2, mu
+        rn = ops.gemm_nt(a, w, e(M, N), epi=ops.EPI_BIAS_RES, res=res, variant=v)      # residual without a bias: InternImage's data-gradient GEMMs (round 6)
+        return r, r0, f, f0, y, y0, dg, h2, mu, rn
     ref = run(1024)
+    assert ops.gemm_nt_tile(a, w, e(M, N), epi=ops.EPI_BIAS_RES, res=res, variant=S8) == 64
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), bias=b, variant=S8) == 64
     assert ops.gemm_nt_tile(a, w, e(M, N, dtype=dtype), epi=ops.EPI_MUL, aux=uu, variant=S8) == 64
     assert ops.gemm_nt_tile(a, w, e(M, N), epi=ops.EPI_BIAS_RES, bias=b, res=res, rowscale=rs, rows_per_sample=rps, variant=S8) == 64
-    names = ("res+rowscale", "res", "f32 bias", "f32", "bf16 bias", "bf16", "gelu' out", "gelu out", "mul")
+    names = ("res+rowscale", "res", "f32 bias", "f32", "bf16 bias", "bf16", "gelu' out", "gelu out", "mul", "res, no bias")
     for v in (S8, S8 + 2):
         for rep in range(3):
             for nm, x, y in zip(names, ref, run(v)):
