@@ -158,7 +158,7 @@ def test_layernorm_beyond_1024_channels(C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,C", [(300, 192), (70, 1536)])
+@pytest.mark.parametrize("rows,C", [(300, 192), (70, 1536), (130, 384), (50, 768), (20, 1024), (9, 2048), (70000, 96)])      # (per-width kernels 1, 6, 2, 3, 4, 8; > 64 K rows: 1024 workgroups)
 def test_layernorm_residual_fused_fwd_bwd(dtype, rows, C):
     """out = x + s[sample] * layer_scale * LayerNorm(h) (intern_image.py:424-426) in one pass each way, against torch autograd: forward,
     dh and the three parameter gradients (LayerNorm weight / bias, layer scale); 1536 channels = the 8-float4-per-lane instantiation"""

@@ -450,7 +450,7 @@ def test_weight_images_one_launch(ops, dtype):
 
 # ------------------------------------------------------------------------------------------------ LayerNorm & reductions
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("rows,C", [(392, 128), (50, 768), (7, 1024)])
+@pytest.mark.parametrize("rows,C", [(392, 128), (50, 768), (7, 1024), (33, 96), (130, 384), (21, 260), (9, 1280)])      # (every per-width instantiation: 1, 3, 4, 1, 2, 2, 6 groups per lane)
 def test_layernorm_fwd_bwd(ops, dtype, rows, C):
     x, g, b = rnd(rows, C, scale=2.0) + 0.5, 1 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
     mean, rstd = e(rows), e(rows)
