@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 whole = "--all" in sys.argv        # every launch of the trace instead of the last step
 top = "--top" in sys.argv          # also: the 40 longest single launches of the step that are not GEMMs / DCNv3
-args = [a for a in sys.argv[2:] if a not in ("--all", "--top")]
+args = [a for a in sys.argv[2:] if a not in ("--all", "--top", "--gemms")]
 idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"].lower()]
 step = rows if whole else rows[idx[-2] + 1: idx[-1] + 1]
 needles = args or ["dcnv3", "ln_res", "dwconv", "softmax_groups"]
@@ -26,7 +26,7 @@ if top:
     def short(n):
         m = re.search(r"(\w+)(<[^(]*>)?\(", n.replace("(anonymous namespace)::", ""))
         return ((m.group(1) + (m.group(2) or "")) if m else n)[:70]
-    rest = [r for r in step if "gemm" not in r["Kernel_Name"] and "dcnv3" not in r["Kernel_Name"]]
+    rest = [r for r in step if ("gemm_nt" not in r["Kernel_Name"] and "gemm_tn" not in r["Kernel_Name"] and "dcnv3" not in r["Kernel_Name"]) or "--gemms" in sys.argv]
     rest.sort(key=lambda r: int(r["Start_Timestamp"]) - int(r["End_Timestamp"]))
     print("longest single launches (GEMMs and DCNv3 aside):")
     for r in rest[:40]:
