@@ -44,6 +44,20 @@ __device__ __forceinline__ void stage_rows_swz(const bf16_t* __restrict__ src, i
         *reinterpret_cast<uint4*>(img + swz(row, c)) = row_frag(src, ld, row, row < N, 8 * c);
     }
 }
+// K^T fragment (MFMA A operand: row d = 16 dt + fr, k = keys key0 .. key0+3 and key0+16 .. key0+19) out of the swizzled row-major K image:
+// in each 16-lane group, lane i supplies the address of row i >> 2, columns 4 (i & 3) .. +3 of a [4 keys][16 d] block and receives
+// column i of its four rows
+typedef short tr4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 kt_frag_tr(const char* Ks, int key0, int dt, int fr) {
+    const int c = 16 * dt + 4 * (fr & 3);
+    const int ra = key0 + (fr >> 2), rb = ra + 16;
+    const int oa = ra * 128 + ((((c >> 3) ^ (ra & 7))) << 4) + (c & 7) * 2, ob = rb * 128 + ((((c >> 3) ^ (rb & 7))) << 4) + (c & 7) * 2;
+    const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_t*)(Ks + oa));
+    const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_t*)(Ks + ob));
+    const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l.x, l.y, h.x, h.y);
+}
+
 // 64-wide rows -> transposed image img[d][row] (pitch TPV bytes), columns >= N zeroed, up to `cols` columns
 __device__ __forceinline__ void stage_rows_t(const bf16_t* __restrict__ src, int64_t ld, int N, int cols, int TPV, char* img, int tid, int nthreads = 256) {
     for (int idx = tid; idx < cols * 8; idx += nthreads) {

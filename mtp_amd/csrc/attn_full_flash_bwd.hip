@@ -19,7 +19,6 @@
 namespace {
 
 constexpr int QTP = 40;             // byte pitch of the per-wave transposed 16-query tile [d][16 q]
-constexpr int QBP = 64 * 2 + 8;     // byte pitch of the Q^T / dO^T images (dkv kernel)
 
 struct FlashGeom {
     int N, Hp, Wp, heads, HW, HWP, RH, RW, WT;
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(256) void flash_prep_kernel(const bf16_t* __restric
 
 // ===================================================================================================================
 // dQ and the table gradients.  grid (B*heads, ceil(N / 64)); wave = one 16-query tile.
-// dynamic LDS: Ks | Vs (KB x 128 B) | Kt[64][KTP] | E[(1 + WT)][4][64] x 16 B | bias[64][HWP] f32 | dbias[64][HWP] f32 |
+// dynamic LDS: Ks | Vs (KB x 128 B) | E[(1 + WT)][KB / 32][64] x 16 B | bias[64][HWP] f32 | dbias[64][HWP] f32 |
 //              Qtt[4 waves][64][QTP] | kpos[KB] u32 | qpos[64] u32
 // ===================================================================================================================
 template <int KB>      // keys per block: 128, or 64 when that lets two workgroups share a CU
@@ -91,12 +90,11 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
                                                           bf16_t* __restrict__ dqkv, const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                           const float* __restrict__ bias_g, const float* __restrict__ delta_g, float* __restrict__ drel_part,
                                                           FlashGeom g, float scale) {
-    constexpr int KTP = KB * 2 + 8;     // byte pitch of the K^T image
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* Ks = sm;
     char* Vs = Ks + KB * 128;
-    char* Kt = Vs + KB * 128;
-    char* Eimg = Kt + 64 * KTP;
+    char* Eimg = Vs + KB * 128;      // (no K^T image since round 6: the K^T fragments of dQ^T += K^T.dS^T come out of the K rows with ds_read_b64_tr_b16 -- the image cost a
+                                     //  second global read of the key block and 16 two-byte LDS stores per thread and block)
     float* bias = reinterpret_cast<float*>(Eimg + (1 + g.WT) * (KB / 32) * 64 * 16);
     float* dbias = bias + 64 * g.HWP;
     char* Qttall = reinterpret_cast<char*>(dbias + 64 * g.HWP);
@@ -148,7 +146,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
         __syncthreads();   // the previous block's K / V / E reads are done
         stage_rows_swz(base + C + (int64_t)kb0 * ld, ld, rem, KB, Ks, tid);
         stage_rows_swz(base + 2 * C + (int64_t)kb0 * ld, ld, rem, KB, Vs, tid);
-        stage_rows_t(base + C + (int64_t)kb0 * ld, ld, rem, KB, KTP, Kt, tid);
         if (tid < KB) {   // (grid row relative to the block's first row) | column << 8 | valid << 16
             const bool ok = kb0 + tid < N;
             const int key = ok ? kb0 + tid : N - 1;
@@ -199,10 +196,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
             const uint4 dsf = pack_bf16x8(dsT[2 * kk][0], dsT[2 * kk][1], dsT[2 * kk][2], dsT[2 * kk][3],
                                           dsT[2 * kk + 1][0], dsT[2 * kk + 1][1], dsT[2 * kk + 1][2], dsT[2 * kk + 1][3]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const char* row = Kt + (16 * dt + fr) * KTP;
-                dq[dt] = mma(ld8x2(row + (32 * kk + 4 * gq) * 2, row + (32 * kk + 16 + 4 * gq) * 2), dsf, dq[dt]);
-            }
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = mma(kt_frag_tr(Ks, 32 * kk + 4 * gq, dt, fr), dsf, dq[dt]);
             dqh = mma(ld16(Eimg + (kk * 64 + lane) * 16), dsf, dqh);      // D[relative key row 4gq + r][query fr]
 #pragma unroll
             for (int wt = 0; wt < 4; ++wt)
@@ -286,7 +280,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
 
 // ===================================================================================================================
 // dK, dV.  grid (B*heads, ceil(N / 64)); wave = one 16-key tile; loop over blocks of 64 queries.
-// dynamic LDS: Qs | dOs (64 x 128 B, swizzled rows) | Qt | dOt ([64 d][QBP]) | bw[64][WPP] f32 | bhs[64][9] f32 | lses[64] | dels[64]
+// dynamic LDS: Qs | dOs (64 x 128 B, swizzled rows) | bw[64][WPP] f32 | bhs[64][9] f32 | lses[64] | dels[64]
 // ===================================================================================================================
 __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, const float* __restrict__ bias_g, const float* __restrict__ delta_g,
@@ -294,10 +288,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const bf16_t* __rest
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* Qs = sm;
     char* dOs = Qs + 64 * 128;
-    char* Qt = dOs + 64 * 128;
-    char* dOt = Qt + 64 * QBP;
     const int WPP = g.Wp | 1;
-    float* bw = reinterpret_cast<float*>(dOt + 64 * QBP);
+    float* bw = reinterpret_cast<float*>(dOs + 64 * 128);      // (no Q^T / dO^T images since round 6: transposed reads of the row images)
     float* bhs = bw + 64 * WPP;
     float* lses = bhs + 64 * 9;
     float* dels = lses + 64;
@@ -330,8 +322,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const bf16_t* __rest
         __syncthreads();
         stage_rows_swz(base + (int64_t)qb0 * ld, ld, rem, 64, Qs, tid);
         stage_rows_swz(dob + (int64_t)qb0 * C, C, rem, 64, dOs, tid);
-        stage_rows_t(base + (int64_t)qb0 * ld, ld, rem, 64, QBP, Qt, tid);
-        stage_rows_t(dob + (int64_t)qb0 * C, C, rem, 64, QBP, dOt, tid);
         for (int idx = tid; idx < 64 * Wp; idx += 256) {
             const int q = idx / Wp, c = idx - q * Wp;
             bw[q * WPP + c] = q < rem ? bias_g[((int64_t)bh * N + qb0 + q) * g.HW + Hp + c] : 0.f;
@@ -371,10 +361,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const bf16_t* __rest
             const uint4 dsfb = pack_bf16x8(dv[0][0], dv[0][1], dv[0][2], dv[0][3], dv[1][0], dv[1][1], dv[1][2], dv[1][3]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const char* rq = Qt + (16 * dt + fr) * QBP;
-                const char* rd = dOt + (16 * dt + fr) * QBP;
-                dks[dt] = mma(ld8x2(rq + (32 * kk + 4 * gq) * 2, rq + (32 * kk + 16 + 4 * gq) * 2), dsfb, dks[dt]);   // D[d 16dt + 4gq + r][key fr]
-                dvs[dt] = mma(ld8x2(rd + (32 * kk + 4 * gq) * 2, rd + (32 * kk + 16 + 4 * gq) * 2), pfb, dvs[dt]);
+                dks[dt] = mma(kt_frag_tr(Qs, 32 * kk + 4 * gq, dt, fr), dsfb, dks[dt]);   // D[d 16dt + 4gq + r][key fr]
+                dvs[dt] = mma(kt_frag_tr(dOs, 32 * kk + 4 * gq, dt, fr), pfb, dvs[dt]);
             }
         }
     }
@@ -407,8 +395,8 @@ int mtp_full_bwd_flash_launch(const void* qkv, const void* o, const void* dout, 
     float* delta = workspace + B * heads * N * g.HW;
     hipError_t e = hipMemsetAsync(drel_part, 0, sizeof(float) * (size_t)(B * heads) * (size_t)(g.RH + g.RW) * HD, s);
     if (e != hipSuccess) return (int)e;
-    const auto lds_q = [&](int kb) { return 2 * (size_t)kb * 128 + (size_t)64 * (kb * 2 + 8) + (size_t)(1 + g.WT) * (kb / 32) * 64 * 16 + 2 * (size_t)64 * g.HWP * 4 + 4 * 64 * QTP + kb * 4 + 64 * 4; };
-    const size_t lds_k = 2 * (size_t)64 * 128 + 2 * (size_t)64 * QBP + (size_t)64 * (g.Wp | 1) * 4 + 64 * 9 * 4 + 2 * 64 * 4;
+    const auto lds_q = [&](int kb) { return 2 * (size_t)kb * 128 + (size_t)(1 + g.WT) * (kb / 32) * 64 * 16 + 2 * (size_t)64 * g.HWP * 4 + 4 * 64 * QTP + kb * 4 + 64 * 4; };
+    const size_t lds_k = 2 * (size_t)64 * 128 + (size_t)64 * (g.Wp | 1) * 4 + 64 * 9 * 4 + 2 * 64 * 4;
     // key block of the dq kernel: 64 keys when that brings its LDS under half a CU's (two workgroups = 8 waves per CU; 28 x 28: 70 KiB)
     // and the indicator rows still fit one MFMA tile (64 / Wp + 2 <= 16 always holds for Wp >= 10)
     const bool small = lds_q(64) <= 80 * 1024;

@@ -136,18 +136,17 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const bf16_t* __rest
 // (wave = one 16-query tile), loop over blocks of 256 keys with an online softmax; per block the same S^T = K.Q^T /
 // in-lane softmax / O^T = V^T.P^T scheme as above.  RT = 16-row tiles per table: 4 (Hp, Wp <= 32) or 8 (<= 64: the 1024^2
 // detection fine-tunes, 4096 tokens).
-// dynamic LDS: Ks[256*128] | Vt[64*FTPV] | QR[4 waves][32 RT][16] f32 | kpos[256] u32
+// dynamic LDS: Ks[FKB*128] | Vs[FKB*128] | QR[4 waves][32 RT][16] f32 | kpos[FKB] u32
 // ===================================================================================================================
 
 template <int RT, int FKB>
 __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                                  const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                                  int N, int Hp, int Wp, int heads, float scale) {
-    constexpr int FTPV = FKB * 2 + 8;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* Ks = sm;
-    char* Vt = Ks + FKB * 128;
-    float* QRall = reinterpret_cast<float*>(Vt + 64 * FTPV);
+    char* Vs = Ks + FKB * 128;      // V rows like the K rows (round 6): the V^T operand of O^T = V^T.P^T comes out of ds_read_b64_tr_b16, not out of a transposed image written
+    float* QRall = reinterpret_cast<float*>(Vs + FKB * 128);      // in 2-byte pieces (32 ds_write_b16 per thread and key block)
     uint32_t* kpos = reinterpret_cast<uint32_t*>(QRall + 4 * 32 * RT * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, gq = lane >> 4;
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
         const int kb0 = jb * FKB, rem = N - kb0;
         __syncthreads();   // the previous block's K / V^T reads are done (first pass: the QR tiles are visible)
         stage_rows_swz(base + C + (int64_t)kb0 * ld, ld, rem, FKB, Ks, tid);
-        stage_rows_t(base + 2 * C + (int64_t)kb0 * ld, ld, rem, FKB, FTPV, Vt, tid);
+        stage_rows_swz(base + 2 * C + (int64_t)kb0 * ld, ld, rem, FKB, Vs, tid);
         if (tid < FKB) {
             const int key = kb0 + tid < N ? kb0 + tid : N - 1;
             kpos[tid] = (uint32_t)(key / Wp) | ((uint32_t)(key % Wp) << 8);
@@ -237,10 +236,7 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
             if (kk < kkb) {
                 const uint4 pf = pack_bf16x8(s[2 * kk][0], s[2 * kk][1], s[2 * kk][2], s[2 * kk][3], s[2 * kk + 1][0], s[2 * kk + 1][1], s[2 * kk + 1][2], s[2 * kk + 1][3]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const char* row = Vt + (16 * dt + fr) * FTPV;
-                    oa[dt] = mma(ld8x2(row + (32 * kk + 4 * gq) * 2, row + (32 * kk + 16 + 4 * gq) * 2), pf, oa[dt]);
-                }
+                for (int dt = 0; dt < 4; ++dt) oa[dt] = mma(kt_frag_tr(Vs, 32 * kk + 4 * gq, dt, fr), pf, oa[dt]);
             }
         }
     }
@@ -258,20 +254,6 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
 // dynamic LDS: Ks | Vs (NP2 x 128 each) | QR[NW][64][16] f32 | dQR[NW][64][16] f32 | Qtt[NW][64*40 B] | kpos[NP2] | E[2][KK][64] x16 B
 // ===================================================================================================================
 constexpr int QTP = 40;   // byte pitch of the per-wave transposed 16-query tile [d][16 q] (32 + 8)
-
-// K^T fragment (MFMA A operand: row d = 16 dt + fr, k = keys key0 .. key0+3 and key0+16 .. key0+19) out of the swizzled row-major K image:
-// in each 16-lane group, lane i supplies the address of row i >> 2, columns 4 (i & 3) .. +3 of a [4 keys][16 d] block and receives
-// column i of its four rows
-typedef short tr4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 kt_frag_tr(const char* Ks, int key0, int dt, int fr) {
-    const int c = 16 * dt + 4 * (fr & 3);
-    const int ra = key0 + (fr >> 2), rb = ra + 16;
-    const int oa = ra * 128 + ((((c >> 3) ^ (ra & 7))) << 4) + (c & 7) * 2, ob = rb * 128 + ((((c >> 3) ^ (rb & 7))) << 4) + (c & 7) * 2;
-    const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_t*)(Ks + oa));
-    const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_t*)(Ks + ob));
-    const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
-    return make_uint4(l.x, l.y, h.x, h.y);
-}
 
 // NW waves per workgroup: 8 (two per SIMD, the second hides the first one's LDS / exp latency) when the per-wave tiles fit next to
 // the K / V images, else 4.  K^T fragments for dQ^T = K^T.dS^T come out of the row-major K image with the hardware transpose read
@@ -662,13 +644,13 @@ int mtp_full_fwd_mfma_launch(const void* qkv, void* o, float* lse, const float* 
         const dim3 grid((unsigned)(B * heads), (unsigned)((N + 63) / 64));
         if (big) {
             constexpr int KBLK = 256;
-            const size_t lds = (size_t)KBLK * 128 + (size_t)64 * (KBLK * 2 + 8) + (size_t)4 * 32 * 8 * 16 * 4 + KBLK * 4;
+            const size_t lds = 2 * (size_t)KBLK * 128 + (size_t)4 * 32 * 8 * 16 * 4 + KBLK * 4;
             (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel<8, KBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((full_fwd_flash_mfma_kernel<8, KBLK>), grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
         } else {
             // 128-key blocks: 65 KiB of LDS, two workgroups (8 waves) per CU instead of one
             constexpr int KBLK = 128;
-            const size_t lds = (size_t)KBLK * 128 + (size_t)64 * (KBLK * 2 + 8) + (size_t)4 * 32 * 4 * 16 * 4 + KBLK * 4;
+            const size_t lds = 2 * (size_t)KBLK * 128 + (size_t)4 * 32 * 4 * 16 * 4 + KBLK * 4;
             (void)hipFuncSetAttribute((const void*)full_fwd_flash_mfma_kernel<4, KBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((full_fwd_flash_mfma_kernel<4, KBLK>), grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, rel_h, rel_w, (int)N, (int)Hp, (int)Wp, (int)heads, scale);
         }
