@@ -58,6 +58,24 @@ __device__ __forceinline__ uint4 kt_frag_tr(const char* Ks, int key0, int dt, in
     return make_uint4(l.x, l.y, h.x, h.y);
 }
 
+// the same in two steps, for a software-pipelined block loop: the global loads of the NEXT block are issued into registers right behind the barrier that
+// publishes the current one (prefetch_rows) and written to LDS at the top of the next trip (commit_rows) -- their latency runs under the block's MFMAs
+template <int ROWS>
+__device__ __forceinline__ void prefetch_rows(const bf16_t* __restrict__ src, int64_t ld, int N, int tid, uint4 (&r)[ROWS * 8 / 256]) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 8 / 256; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+        r[i] = row_frag(src, ld, row, row < N, 8 * c);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void commit_rows(char* img, int tid, const uint4 (&r)[ROWS * 8 / 256]) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 8 / 256; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+        *reinterpret_cast<uint4*>(img + swz(row, c)) = r[i];
+    }
+}
 // 64-wide rows -> transposed image img[d][row] (pitch TPV bytes), columns >= N zeroed, up to `cols` columns
 __device__ __forceinline__ void stage_rows_t(const bf16_t* __restrict__ src, int64_t ld, int N, int cols, int TPV, char* img, int tid, int nthreads = 256) {
     for (int idx = tid; idx < cols * 8; idx += nthreads) {

@@ -141,11 +141,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const bf16_t* __restr
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nblk = (N + KB - 1) / KB;
+    uint4 kpre[KB * 8 / 256], vpre[KB * 8 / 256];      // the next key block's rows, in flight while this one is worked on (round 6)
+    prefetch_rows<KB>(base + C, ld, N, tid, kpre);
+    prefetch_rows<KB>(base + 2 * C, ld, N, tid, vpre);
     for (int jb = 0; jb < nblk; ++jb) {
         const int kb0 = jb * KB, rem = N - kb0, kh0 = kb0 / Wp;
         __syncthreads();   // the previous block's K / V / E reads are done
-        stage_rows_swz(base + C + (int64_t)kb0 * ld, ld, rem, KB, Ks, tid);
-        stage_rows_swz(base + 2 * C + (int64_t)kb0 * ld, ld, rem, KB, Vs, tid);
+        commit_rows<KB>(Ks, tid, kpre);
+        commit_rows<KB>(Vs, tid, vpre);
+        if (jb + 1 < nblk) {
+            prefetch_rows<KB>(base + C + (int64_t)(kb0 + KB) * ld, ld, rem - KB, tid, kpre);
+            prefetch_rows<KB>(base + 2 * C + (int64_t)(kb0 + KB) * ld, ld, rem - KB, tid, vpre);
+        }
         if (tid < KB) {   // (grid row relative to the block's first row) | column << 8 | valid << 16
             const bool ok = kb0 + tid < N;
             const int key = ok ? kb0 + tid : N - 1;
@@ -317,11 +324,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const bf16_t* __rest
         dvs[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     const int nblk = (N + 63) / 64;
+    uint4 qpre[2], dpre[2];      // the next query block's Q / dO rows, in flight while this one is worked on (round 6)
+    prefetch_rows<64>(base, ld, N, tid, qpre);
+    prefetch_rows<64>(dob, C, N, tid, dpre);
     for (int qb = 0; qb < nblk; ++qb) {
         const int qb0 = 64 * qb, rem = N - qb0;
         __syncthreads();
-        stage_rows_swz(base + (int64_t)qb0 * ld, ld, rem, 64, Qs, tid);
-        stage_rows_swz(dob + (int64_t)qb0 * C, C, rem, 64, dOs, tid);
+        commit_rows<64>(Qs, tid, qpre);
+        commit_rows<64>(dOs, tid, dpre);
+        if (qb + 1 < nblk) {
+            prefetch_rows<64>(base + (int64_t)(qb0 + 64) * ld, ld, rem - 64, tid, qpre);
+            prefetch_rows<64>(dob + (int64_t)(qb0 + 64) * C, C, rem - 64, tid, dpre);
+        }
         for (int idx = tid; idx < 64 * Wp; idx += 256) {
             const int q = idx / Wp, c = idx - q * Wp;
             bw[q * WPP + c] = q < rem ? bias_g[((int64_t)bh * N + qb0 + q) * g.HW + Hp + c] : 0.f;

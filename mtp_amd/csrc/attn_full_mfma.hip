@@ -180,14 +180,21 @@ __global__ __launch_bounds__(256) void full_fwd_flash_mfma_kernel(const bf16_t* 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int nblk = (N + FKB - 1) / FKB;
+    uint4 kpre[FKB * 8 / 256], vpre[FKB * 8 / 256];      // the next key block's rows, in flight while this one is worked on (round 6)
+    prefetch_rows<FKB>(base + C, ld, N, tid, kpre);
+    prefetch_rows<FKB>(base + 2 * C, ld, N, tid, vpre);
     for (int jb = 0; jb < nblk; ++jb) {
         const int kb0 = jb * FKB, rem = N - kb0;
-        __syncthreads();   // the previous block's K / V^T reads are done (first pass: the QR tiles are visible)
-        stage_rows_swz(base + C + (int64_t)kb0 * ld, ld, rem, FKB, Ks, tid);
-        stage_rows_swz(base + 2 * C + (int64_t)kb0 * ld, ld, rem, FKB, Vs, tid);
+        __syncthreads();   // the previous block's K / V reads are done (first pass: the QR tiles are visible)
+        commit_rows<FKB>(Ks, tid, kpre);
+        commit_rows<FKB>(Vs, tid, vpre);
         if (tid < FKB) {
             const int key = kb0 + tid < N ? kb0 + tid : N - 1;
             kpos[tid] = (uint32_t)(key / Wp) | ((uint32_t)(key % Wp) << 8);
+        }
+        if (jb + 1 < nblk) {
+            prefetch_rows<FKB>(base + C + (int64_t)(kb0 + FKB) * ld, ld, rem - FKB, tid, kpre);
+            prefetch_rows<FKB>(base + 2 * C + (int64_t)(kb0 + FKB) * ld, ld, rem - FKB, tid, vpre);
         }
         __syncthreads();
         const int keys = rem < FKB ? rem : FKB, tiles = (keys + 15) / 16, kkb = (keys + 31) / 32;
