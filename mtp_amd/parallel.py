@@ -207,6 +207,8 @@ class GradReducer:
                 torch.zeros(1, device=flat.grad.device).add_(1.0)
             self.stream.synchronize()
             try:
+                if os.environ.get("MTP_NATIVE_COMM") == "fail":      # (test switch: behave as if mtp_comm_init had failed on this rank)
+                    raise RuntimeError("mtp_comm_init: injected failure (MTP_NATIVE_COMM=fail)")
                 self.native = RcclComm(group)
             except Exception as e:       # (MTP_NATIVE_COMM=strict: no second choice)
                 if os.environ.get("MTP_NATIVE_COMM") == "strict":

@@ -53,9 +53,18 @@ def _worker(rank, world, port, q, native=False, mode="allreduce", bf16=False):
         if native is None:       # the default: the C-ABI communicator (round 6)
             os.environ.pop("MTP_NATIVE_COMM", None)
             native = True
+        elif native == "fail":   # the communicator cannot be created: every rank agrees on torch.distributed's collectives, and says so
+            os.environ["MTP_NATIVE_COMM"] = "fail"
+            native = False
         else:
             os.environ["MTP_NATIVE_COMM"] = "1" if native else "0"
-        tr = DataParallelTrainer(_net(0 if rank == 0 else 123).to(dev), total_steps=10, bucket_bytes=1 << 20, comm_mode=mode, comm_bf16=bf16)
+        import warnings
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            tr = DataParallelTrainer(_net(0 if rank == 0 else 123).to(dev), total_steps=10, bucket_bytes=1 << 20, comm_mode=mode, comm_bf16=bf16)
+        if os.environ.get("MTP_NATIVE_COMM") == "fail":
+            d = tr.reducer.describe()
+            assert d["native_c_abi"] is False and "injected failure" in d["native_error"] and any("mtp_comm_init failed" in str(w.message) for w in wlist)
         assert tr.reducer.active and tr.reducer.stream is not None and (tr.reducer.native is not None) == native
         if native:      # what RCCL itself says about the communicator behind mtp_comm_* (mtp_comm_info)
             info = tr.reducer.native.info()
@@ -107,6 +116,13 @@ def test_forced_comm_single_rank_through_the_c_abi_communicator():
     """the same with MTP_NATIVE_COMM=1: the buckets go through mtp_comm_allreduce_bucket (ncclAllReduce via the C ABI, communicator from
     mtp_comm_unique_id / mtp_comm_init) on the side stream"""
     (rank, err, dparam, ncoll, all_bytes), = _run(1, native=True)
+    assert err < 1e-5 and dparam < 1e-6 and ncoll >= 2 and all_bytes
+
+
+def test_failed_c_abi_communicator_falls_back_to_torch_distributed_on_every_rank():
+    """mtp_comm_init fails (injected): the ranks agree through one MIN all-reduce, the exchange runs on torch.distributed's collectives on the same side stream,
+    describe() carries the reason and a warning is issued; MTP_NATIVE_COMM=strict would raise instead"""
+    (rank, err, dparam, ncoll, all_bytes), = _run(1, native="fail")
     assert err < 1e-5 and dparam < 1e-6 and ncoll >= 2 and all_bytes
 
 
