@@ -584,6 +584,16 @@ def test_tokens_nchw_roundtrip(ops, dtype, L):
     f3 = ops.tokens_to_nchw(dev(x3, dtype), e(2, 72, 4 << L, 6 << L, dtype=dtype), 2, 4, 6, L)
     assert torch.equal(f3.float().cpu(), O.tokens_to_nchw(x3, 2, 4, 6, L))
     assert torch.equal(ops.nchw_to_tokens(f3, e(x3.shape[0], 72, dtype=dtype), 2, 4, 6, L).float().cpu(), x3)
+    if L == 0:      # the 7 x 7 tap behind the max-pool: 49 positions per plane (not a multiple of 4: the element-wise edge path), whole and ragged channel tiles, mixed dtypes
+        for Cc in (128, 72):
+            x4 = rnd(3 * 49, Cc, dtype=dtype)
+            f4 = ops.tokens_to_nchw(dev(x4, dtype), e(3, Cc, 7, 7, dtype=dtype), 3, 7, 7, 0)
+            assert torch.equal(f4.float().cpu(), O.tokens_to_nchw(x4, 3, 7, 7, 0))
+            assert torch.equal(ops.nchw_to_tokens(f4, e(3 * 49, Cc, dtype=dtype), 3, 7, 7, 0).float().cpu(), x4)
+            f5 = ops.tokens_to_nchw(dev(x4.float()), e(3, Cc, 7, 7, dtype=dtype), 3, 7, 7, 0)       # f32 tokens -> ACT map (what the FPN tail does)
+            assert torch.equal(f5.float().cpu(), O.tokens_to_nchw(x4.float(), 3, 7, 7, 0).to(dtype).float())
+            b5 = ops.nchw_to_tokens(f5, e(3 * 49, Cc), 3, 7, 7, 0)                                   # ACT map -> f32 tokens
+            assert torch.equal(b5.cpu(), f5.float().cpu().permute(0, 2, 3, 1).reshape(3 * 49, Cc))
 
 
 @pytest.mark.parametrize("dtype", DT)
