@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* mtp_stream_t; /* hipStream_t */
 
-typedef enum { MTP_F32 = 0, MTP_BF16 = 1 } mtp_dtype;
+typedef enum { MTP_F32 = 0, MTP_BF16 = 1, MTP_F64 = 2 /* mtp_dcnv3_fwd / mtp_dcnv3_bwd only: the reference's double dispatch, dcnv3_cuda.cu:69 */ } mtp_dtype;
 
 enum { MTP_OK = 0, MTP_ERR_ARG = -1, MTP_ERR_UNSUPPORTED = -2 };
 
@@ -358,6 +358,9 @@ int mtp_dcnv3_fwd(const void* input, const void* offset, const void* mask, void*
  * than a pixel beyond the kernel's reach; any other geometry -> bilinear scatter with f32 atomics, like the reference. */
 int mtp_dcnv3_bwd(const void* input, const void* offset, const void* mask, const void* grad_output, int dtype, float* grad_input, float* grad_offset,
                   float* grad_mask, const mtp_dcnv3_geom* geom, mtp_stream_t stream);
+/* dtype MTP_F64 (round 6; the reference dispatches float / double / half, dcnv3_cuda.cu:69, and its own test-suite checks gradients numerically in double,
+ * ops_dcnv3/test.py): every operand, the output and -- through the same three pointers -- the three gradients are double; plain per-(pixel, group, channel)
+ * kernels with double arithmetic and f64 atomics, any geometry.  A validation path, not a fast one. */
 /* The same, and grad_offset once more in the input dtype as rows of act_ld >= group * P * 2 elements (pad columns zero): the operand the offset
  * head's dgrad / wgrad GEMMs read, written by the kernel that computes it instead of a cast-and-pad pass (round 4).  Only in the gather form of
  * the backward (every InternImage level); MTP_ERR_UNSUPPORTED otherwise, with nothing launched. */

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTP_HIP_LIB") or os.path.join(_HERE, "libmtp_hip.so")   # MTP_HIP_LIB: A/B builds of the same ABI
 
-MTP_F32, MTP_BF16 = 0, 1
+MTP_F32, MTP_BF16, MTP_F64 = 0, 1, 2      # (MTP_F64: the DCNv3 entry points only)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_BIAS_GELU_DG, EPI_MUL = 0, 1, 2, 3, 4, 5
 
 p, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float

@@ -523,6 +523,79 @@ __global__ __launch_bounds__(256, 2) void dcnv3_bwd_input3x3_kernel(const T* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// float64 (MTP_F64): the reference's double dispatch.  One lane = (pixel, group, channel), double arithmetic throughout (sample locations included), f64
+// atomics for the three gradients (zero-filled by the launcher).  Same formulas as dcnv3_fwd_kernel / dcnv3_bwd_kernel above.
+struct PointD {
+    int o00, o01, o10, o11;
+    double lh, lw, k00, k01, k10, k11;
+};
+__device__ __forceinline__ PointD make_point_d(const DcnGeom& g, double loc_h, double loc_w, int C) {
+    PointD p;
+    const bool valid = loc_h > -1.0 && loc_w > -1.0 && loc_h < (double)g.H && loc_w < (double)g.W;
+    const double ch = fmin(fmax(loc_h, -2.0), (double)g.H + 1.0), cw = fmin(fmax(loc_w, -2.0), (double)g.W + 1.0);
+    const double fh = floor(ch), fw = floor(cw);
+    const int h0 = (int)fh, w0 = (int)fw, h1 = h0 + 1, w1 = w0 + 1;
+    p.lh = ch - fh;
+    p.lw = cw - fw;
+    const bool a0 = h0 >= 0, a1 = h1 <= g.H - 1, b0 = w0 >= 0, b1 = w1 <= g.W - 1;
+    p.k00 = (valid && a0 && b0) ? 1.0 : 0.0;
+    p.k01 = (valid && a0 && b1) ? 1.0 : 0.0;
+    p.k10 = (valid && a1 && b0) ? 1.0 : 0.0;
+    p.k11 = (valid && a1 && b1) ? 1.0 : 0.0;
+    const int h0c = min(max(h0, 0), g.H - 1), h1c = min(max(h1, 0), g.H - 1), w0c = min(max(w0, 0), g.W - 1), w1c = min(max(w1, 0), g.W - 1);
+    p.o00 = (h0c * g.W + w0c) * C;
+    p.o01 = (h0c * g.W + w1c) * C;
+    p.o10 = (h1c * g.W + w0c) * C;
+    p.o11 = (h1c * g.W + w1c) * C;
+    return p;
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void dcnv3_f64_kernel(const double* __restrict__ input, const double* __restrict__ offset, const double* __restrict__ mask,
+                                                       const double* __restrict__ grad_out, double* __restrict__ out, double* __restrict__ grad_input,
+                                                       double* __restrict__ grad_offset, double* __restrict__ grad_mask, DcnGeom g, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const Item it = decode(g, idx, g.GC);
+    const int C = g.G * g.GC;
+    const int chan = it.gi * g.GC + it.chunk;
+    const int64_t img = (int64_t)it.n * g.H * g.W * C + chan;
+    const double* in_n = input + img;
+    const double* offp = offset + it.item * (2 * g.P);
+    const double* mp = mask + it.item * g.P;
+    const double os = (double)g.os;
+    const int halfw = (g.dw * (g.kw - 1)) >> 1, halfh = (g.dh * (g.kh - 1)) >> 1;
+    const double p0w = (double)(halfw - g.pw + it.wo * g.sw) - (double)halfw * os;
+    const double p0h = (double)(halfh - g.ph + it.ho * g.sh) - (double)halfh * os;
+    const int cw = g.kw / 2, chh = g.kh / 2;
+    const double top = BWD ? grad_out[it.pix * C + chan] : 0.0;
+    double acc = 0.0;
+    int p = 0;
+    for (int i = 0; i < g.kw; ++i)
+        for (int j = 0; j < g.kh; ++j) {
+            if (g.remove_center && i == cw && j == chh) continue;
+            const double ow = offp[2 * p], oh = offp[2 * p + 1], m = mp[p];
+            const PointD pt = make_point_d(g, p0h + ((double)(j * g.dh) + oh) * os, p0w + ((double)(i * g.dw) + ow) * os, C);
+            const double hh = 1.0 - pt.lh, hw = 1.0 - pt.lw;
+            const double v00 = in_n[pt.o00] * pt.k00, v01 = in_n[pt.o01] * pt.k01, v10 = in_n[pt.o10] * pt.k10, v11 = in_n[pt.o11] * pt.k11;
+            if constexpr (!BWD) {
+                acc += m * (hh * hw * v00 + hh * pt.lw * v01 + pt.lh * hw * v10 + pt.lh * pt.lw * v11);
+            } else {
+                const double tg = top * m;
+                double* gin_n = grad_input + img;
+                if (pt.k00 != 0.0) atomicAdd(gin_n + pt.o00, hh * hw * tg);
+                if (pt.k01 != 0.0) atomicAdd(gin_n + pt.o01, hh * pt.lw * tg);
+                if (pt.k10 != 0.0) atomicAdd(gin_n + pt.o10, pt.lh * hw * tg);
+                if (pt.k11 != 0.0) atomicAdd(gin_n + pt.o11, pt.lh * pt.lw * tg);
+                atomicAdd(grad_mask + it.item * g.P + p, top * (hh * hw * v00 + hh * pt.lw * v01 + pt.lh * hw * v10 + pt.lh * pt.lw * v11));
+                atomicAdd(grad_offset + it.item * (2 * g.P) + 2 * p, os * tg * (hh * (v01 - v00) + pt.lh * (v11 - v10)));
+                atomicAdd(grad_offset + it.item * (2 * g.P) + 2 * p + 1, os * tg * (hw * (v10 - v00) + pt.lw * (v11 - v01)));
+            }
+            ++p;
+        }
+    if constexpr (!BWD) out[it.pix * C + chan] = acc;
+}
+
 // d(offset), d(mask): one lane = (output pixel, group, 8-channel half) -- the sample location is computed twice (not once per channel lane as in the
 // scatter kernel), the channel sums are 8 in-lane terms + one exchange with the neighbour lane, the four corner rows are one (bf16) / two (f32)
 // 16-byte loads each, exactly the forward's gather.
@@ -823,6 +896,12 @@ extern "C" int mtp_dcnv3_fwd(const void* input, const void* offset, const void* 
     const int rc = make_geom(geom, g);
     if (rc) return rc;
     MTP_CHECK_ARG(input && offset && mask && output);
+    if (dtype == MTP_F64) {
+        const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G * g.GC;
+        hipLaunchKernelGGL(dcnv3_f64_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const double*)input, (const double*)offset,
+                           (const double*)mask, (const double*)nullptr, (double*)output, (double*)nullptr, (double*)nullptr, (double*)nullptr, g, total);
+        return mtp_launch_status();
+    }
     MTP_CHECK_ARG(dtype == MTP_F32 || dtype == MTP_BF16);
     if ((int64_t)g.N * g.Ho * g.Wo * g.G * g.GC >= ((int64_t)1 << 32) - 256) return MTP_ERR_UNSUPPORTED;   // one lane per element at most
     hipStream_t s = (hipStream_t)stream;
@@ -851,9 +930,20 @@ extern "C" int mtp_dcnv3_bwd(const void* input, const void* offset, const void* 
     const int rc = make_geom(geom, g);
     if (rc) return rc;
     MTP_CHECK_ARG(input && offset && mask && grad_output && grad_input && grad_offset && grad_mask);
-    MTP_CHECK_ARG(dtype == MTP_F32 || dtype == MTP_BF16);
+    MTP_CHECK_ARG(dtype == MTP_F32 || dtype == MTP_BF16 || dtype == MTP_F64);
     if ((int64_t)g.N * g.Ho * g.Wo * g.G * g.GC >= ((int64_t)1 << 32) - 256) return MTP_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_F64) {      // (the three gradient pointers are double buffers here, see mtp_hip.h)
+        const int64_t items = (int64_t)g.N * g.Ho * g.Wo * g.G, total = items * g.GC;
+        hipError_t e = hipMemsetAsync(grad_input, 0, sizeof(double) * (size_t)g.N * g.H * g.W * g.G * g.GC, s);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_offset, 0, sizeof(double) * (size_t)items * 2 * g.P, s);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_mask, 0, sizeof(double) * (size_t)items * g.P, s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(dcnv3_f64_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const double*)input, (const double*)offset, (const double*)mask,
+                           (const double*)grad_output, (double*)nullptr, reinterpret_cast<double*>(grad_input), reinterpret_cast<double*>(grad_offset),
+                           reinterpret_cast<double*>(grad_mask), g, total);
+        return mtp_launch_status();
+    }
     return dtype == MTP_F32 ? launch_bwd<float>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s)
                             : launch_bwd<bf16_t>(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g, s);
 }

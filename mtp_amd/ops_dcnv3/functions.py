@@ -10,11 +10,11 @@ so the reference's dcnv3_func.py runs unchanged with `import DCNv3` pointing at 
 (INTEGRATION.md).  All compute is libmtp_hip.so (mtp_dcnv3_fwd / mtp_dcnv3_bwd, mtp_amd/csrc/dcnv3.hip); there is no CPU
 or torch fallback (the reference's CPU entry points throw too: src/cpu/dcnv3_cpu.cpp:25,36).
 
-Dtypes: float32 and bfloat16 run on their own kernel instantiations; float16 (round 6; the reference dispatches float / double / half,
-dcnv3_cuda.cu:69) runs on the float32 kernels -- the casts at the boundary are torch's, the arithmetic is at least as exact as a native half
-kernel's, the output comes back as float16.  float64 is refused: a float32 kernel behind a double signature would silently lose what a caller
-of the double path asks for.  Gradients of a bfloat16 / float16 call are float32, as the reference promotes half to float
-(dcnv3_cuda.cu:125-128).
+Dtypes (the reference dispatches float / double / half, dcnv3_cuda.cu:69): float32 and bfloat16 run on their own kernel instantiations; float16
+(round 6) runs on the float32 kernels -- the casts at the boundary are torch's, the arithmetic is at least as exact as a native half kernel's, the
+output comes back as float16; float64 (round 6) runs on plain double kernels with f64 atomics (MTP_F64: a validation path -- the reference's own
+test-suite checks its gradients numerically in double -- not a fast one), gradients in float64.  Gradients of a bfloat16 / float16 call are
+float32, as the reference promotes half to float (dcnv3_cuda.cu:125-128).
 """
 import ctypes as C
 import os
@@ -38,14 +38,17 @@ def _geom(input, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_
     return g
 
 
+def _dtc(t):
+    """dtype code of the C ABI; float64 exists for the DCNv3 entry points only (MTP_F64)"""
+    return _lib.MTP_F64 if t.dtype == torch.float64 else _dt(t)
+
+
 def _as_f32(*ts):
     """float16 operands -> contiguous float32 copies (the half path of the reference, on the float32 kernels)"""
     return [t.float() if t.dtype == torch.float16 else t for t in ts]
 
 
 def _check_inputs(names_tensors, input, group, group_channels, im2col_step):
-    if input.dtype == torch.float64:
-        raise RuntimeError("float64 is not built on the HIP path (float32, bfloat16 and float16 are); cast the operands")
     for name, t in names_tensors:                                     # dcnv3_cuda.cu:28-33, 96-105
         if not t.is_contiguous():
             raise RuntimeError("%s tensor has to be contiguous" % name)
@@ -82,7 +85,7 @@ def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, p
     half = input.dtype == torch.float16
     input, offset, mask = _as_f32(input, offset, mask)
     output = torch.empty((N, Ho, Wo, group * group_channels), dtype=input.dtype, device=input.device)
-    _lib.check(lib().mtp_dcnv3_fwd(input.data_ptr(), offset.data_ptr(), mask.data_ptr(), output.data_ptr(), _dt(input), C.byref(g), _s()), "mtp_dcnv3_fwd")
+    _lib.check(lib().mtp_dcnv3_fwd(input.data_ptr(), offset.data_ptr(), mask.data_ptr(), output.data_ptr(), _dtc(input), C.byref(g), _s()), "mtp_dcnv3_fwd")
     return output.half() if half else output
 
 
@@ -94,10 +97,10 @@ def dcnv3_backward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, 
     Ho, Wo = out_size(g)
     if tuple(grad_output.shape) != (input.shape[0], Ho, Wo, group * group_channels):
         raise RuntimeError("grad_output must be (N, %d, %d, %d)" % (Ho, Wo, group * group_channels))
-    kw = dict(dtype=torch.float32, device=input.device)
+    kw = dict(dtype=torch.float64 if input.dtype == torch.float64 else torch.float32, device=input.device)
     input, offset, mask, grad_output = _as_f32(input, offset, mask, grad_output)
     grad_input, grad_offset, grad_mask = torch.empty(input.shape, **kw), torch.empty(offset.shape, **kw), torch.empty(mask.shape, **kw)
-    _lib.check(lib().mtp_dcnv3_bwd(input.data_ptr(), offset.data_ptr(), mask.data_ptr(), grad_output.data_ptr(), _dt(input), grad_input.data_ptr(),
+    _lib.check(lib().mtp_dcnv3_bwd(input.data_ptr(), offset.data_ptr(), mask.data_ptr(), grad_output.data_ptr(), _dtc(input), grad_input.data_ptr(),
                                    grad_offset.data_ptr(), grad_mask.data_ptr(), C.byref(g), _s()), "mtp_dcnv3_bwd")
     return [grad_input, grad_offset, grad_mask]
 

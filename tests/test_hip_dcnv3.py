@@ -45,9 +45,10 @@ def test_bf16_vs_oracle_on_the_same_rounded_inputs(name):
 
 
 @pytest.mark.parametrize("name", ["base", "rmc"])
-def test_float16_runs_on_the_f32_kernels_and_float64_is_refused(name):
+def test_float16_runs_on_the_f32_kernels_and_float64_on_double_kernels(name):
     """the reference dispatches float / double / half (dcnv3_cuda.cu:69): float16 operands are accepted -- float32 arithmetic on the same rounded inputs, the
-    output back in float16, float32 gradients as for the reference's promoted half -- and through DCNv3Function with half leaves; float64 raises"""
+    output back in float16, float32 gradients as for the reference's promoted half -- and through DCNv3Function with half leaves; float64 runs on double kernels
+    (MTP_F64): output and the three gradients equal the float64 oracle to 1e-12"""
     from mtp_amd.ops_dcnv3 import DCNv3Function, dcnv3_backward, dcnv3_forward
     from oracle import dcnv3_oracle as D
     t, args, rmc = load_case(name)
@@ -62,8 +63,30 @@ def test_float16_runs_on_the_f32_kernels_and_float64_is_refused(name):
     xa, oa, ma = x.clone().requires_grad_(True), off.clone().requires_grad_(True), m.clone().requires_grad_(True)
     DCNv3Function.apply(xa, oa, ma, *args, 256, rmc).backward(G)
     assert xa.grad.dtype == torch.float16 and rel(xa.grad.double().cpu(), ref_g[0]) < 2e-3
-    with pytest.raises(RuntimeError, match="float64"):
-        dcnv3_forward(x.double(), off.double(), m.double(), *args, 256, rmc)
+    d = {k: t[k].double() for k in ("input", "offset", "mask", "grad_output")}
+    ref_y = D.dcnv3_forward(d["input"], d["offset"], d["mask"], *args, rmc)
+    ref_g = D.dcnv3_backward(d["input"], d["offset"], d["mask"], *args, d["grad_output"], rmc)
+    xd, od, md, Gd = (d[k].cuda().contiguous() for k in ("input", "offset", "mask", "grad_output"))
+    yd = dcnv3_forward(xd, od, md, *args, 256, rmc)
+    assert yd.dtype == torch.float64 and rel(yd.cpu(), ref_y) < 1e-12
+    for g, rg in zip(dcnv3_backward(xd, od, md, *args, Gd, 256, rmc), ref_g):
+        assert g.dtype == torch.float64 and rel(g.cpu(), rg) < 1e-12
+
+
+def test_double_gradients_pass_torch_gradcheck():
+    """what the reference's own test-suite does with its double dispatch (ops_dcnv3/test.py: check_gradient_numerical): torch.autograd.gradcheck of
+    DCNv3Function in float64 -- numerical against analytical gradients of input, offset and mask (offsets kept away from the bilinear cell edges, where the
+    operator is not differentiable)"""
+    from mtp_amd.ops_dcnv3 import DCNv3Function
+    g = torch.Generator().manual_seed(3)
+    N, H, W, G, GC, P = 1, 4, 5, 2, 4, 9
+    x = (0.5 * torch.randn(N, H, W, G * GC, generator=g)).double().cuda().requires_grad_(True)
+    off = (0.25 + 0.2 * torch.rand(N, H, W, G * P * 2, generator=g)).double().cuda().requires_grad_(True)      # locations at integer + 0.25 .. 0.45: clear of the edges
+    m = torch.softmax(torch.randn(N, H, W, G, P, generator=g), -1).reshape(N, H, W, G * P).double().cuda().requires_grad_(True)
+
+    def f(a, b, c):
+        return DCNv3Function.apply(a, b, c, 3, 3, 1, 1, 1, 1, 1, 1, G, GC, 1.0, 256, 0)
+    assert torch.autograd.gradcheck(f, (x, off, m), eps=1e-6, atol=1e-7, rtol=1e-5, nondet_tol=1e-12)
 
 
 def test_autograd_function_matches_the_extension_calls():
