@@ -243,6 +243,17 @@ int mtp_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y,
 int mtp_dwconv3x3_bwd_dx(const void* dy, int dtype, const float* w, float* dx, int accumulate, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream);
 int64_t mtp_dwconv3x3_bwd_dw_partial_rows(int64_t N, int64_t H, int64_t W);
 int mtp_dwconv3x3_bwd_dw(const void* dy, const void* x, int dtype, float* part, int64_t N, int64_t H, int64_t W, int64_t C, mtp_stream_t stream);
+/* The same for any odd k (InternImage-H/G's dw_kernel_size, ops_dcnv3/modules/dcnv3.py:124, 146-151): plain per-(pixel, 4 channels) kernels; w (C, 1, k, k) f32.
+ * mtp_dwconv_bwd_dw ACCUMULATES into dw / db with f32 atomics (clear them first); db may be NULL.  (k = 3: the mtp_dwconv3x3_* entries above are the fast path.) */
+int mtp_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int dtype, int64_t N, int64_t H, int64_t W, int64_t C, int k, mtp_stream_t stream);
+int mtp_dwconv_bwd_dx(const void* dy, int dtype, const float* w, float* dx, int accumulate, int64_t N, int64_t H, int64_t W, int64_t C, int k, mtp_stream_t stream);
+int mtp_dwconv_bwd_dw(const void* dy, const void* x, int dtype, float* dw, float* db, int64_t N, int64_t H, int64_t W, int64_t C, int k, mtp_stream_t stream);
+/* center_feature_scale (InternImage-H/G; ops_dcnv3/modules/dcnv3.py:80-88, 209-215): out (rows, G * GC) = y (1 - s) + xp s with s = sigmoid(logits[row][group]);
+ * logits: rows of ld >= G elements (the G-output Linear on the depth-wise branch).  bwd: dy (`dtype`) = dout (1 - s); dxp (f32) = dout s; dlogits (rows of ld,
+ * pad columns zeroed) = s (1 - s) x the sum over the group's channels of dout (xp - y). */
+int mtp_center_feature_scale_fwd(const void* y, const void* xp, const void* logits, int64_t ld, void* out, int dtype, int64_t rows, int64_t G, int64_t GC, mtp_stream_t stream);
+int mtp_center_feature_scale_bwd(const void* dout, const void* y, const void* xp, const void* logits, int64_t ld, void* dy, float* dxp, void* dlogits, int dtype, int64_t rows,
+                                 int64_t G, int64_t GC, mtp_stream_t stream);
 /* softmax over the P <= 32 sampling points of each of G groups (dcnv3.py:341-342): logits (rows, ld >= G*P) -> prob (rows, G*P).
  * bwd: dprob (rows, G*P) f32 -> dlogits (rows, ld) ACT, columns G*P .. ld zeroed. */
 int mtp_softmax_groups_fwd(const void* logits, int64_t ld, void* prob, int dtype, int64_t rows, int64_t G, int64_t P, mtp_stream_t stream);

@@ -40,6 +40,11 @@ class Dcnv3Geom(C.Structure):
 # name -> (restype, argtypes); must list EVERY function declared in include/mtp_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
     "mtp_weight_images": (i32, [p, i32, i64, i32, p]),
+    "mtp_dwconv_fwd": (i32, [p, p, p, p, i32, i64, i64, i64, i64, i32, p]),
+    "mtp_dwconv_bwd_dx": (i32, [p, i32, p, p, i32, i64, i64, i64, i64, i32, p]),
+    "mtp_dwconv_bwd_dw": (i32, [p, p, i32, p, p, i64, i64, i64, i64, i32, p]),
+    "mtp_center_feature_scale_fwd": (i32, [p, p, p, i64, p, i32, i64, i64, i64, p]),
+    "mtp_center_feature_scale_bwd": (i32, [p, p, p, p, i64, p, p, p, i32, i64, i64, i64, p]),
     "mtp_dcnv3_out_size": (i32, [C.POINTER(Dcnv3Geom), C.POINTER(i64), C.POINTER(i64)]),
     "mtp_dcnv3_fwd": (i32, [p, p, p, p, i32, C.POINTER(Dcnv3Geom), p]),
     "mtp_dcnv3_bwd": (i32, [p, p, p, p, i32, p, p, p, C.POINTER(Dcnv3Geom), p]),

@@ -79,13 +79,11 @@ class InternImage(nn.Module):
         super().__init__()
         if core_op not in ("DCNv3", "DCNv3_pytorch"):
             raise NotImplementedError("core_op %r" % (core_op,))
-        # the layer branches of II:407-427 are all scheduled (round 6): post_norm or pre-norm, with or without layer scale, res_post_norm, and the level-2
-        # post norms of InternImage-H/G (II:497-502, 512-515).  Still only on the reference: a depth-wise kernel other than 3 x 3 and center_feature_scale
-        # (both change the DCNv3 module itself, DCNM:124-173 / :209-215; no MTP configuration sets them).
-        if dw_kernel_size not in (None, 3):
-            raise NotImplementedError("InternImage-H/G option dw_kernel_size=%r is not built on the HIP path (the depth-wise kernel is 3 x 3)" % (dw_kernel_size,))
-        if center_feature_scale:
-            raise NotImplementedError("InternImage-H/G option center_feature_scale is not built on the HIP path")
+        # every option of II:367-416 / 499-515 is scheduled (round 6): post_norm or pre-norm, with or without layer scale, res_post_norm, the level-2 post norms,
+        # and InternImage-H/G's two switches inside the DCNv3 module -- a depth-wise kernel of any odd size (DCNM:124, 146-151: plain k x k kernels; 3 x 3 keeps the
+        # fast path) and center_feature_scale (DCNM:168-173, 209-215)
+        if dw_kernel_size is not None and (int(dw_kernel_size) < 1 or int(dw_kernel_size) % 2 == 0 or int(dw_kernel_size) > 15):
+            raise ValueError("dw_kernel_size must be odd and <= 15, got %r" % (dw_kernel_size,))
         if act_layer != "GELU" or norm_layer != "LN" or drop_rate != 0.0:
             raise NotImplementedError("the HIP path schedules act_layer='GELU', norm_layer='LN', drop_rate=0 (what MTP uses, models.py:92-104)")
         if res_post_norm and (post_norm or layer_scale is not None):
@@ -109,7 +107,10 @@ class InternImage(nn.Module):
         self.level2_post_norm_block_ids = level2_post_norm_block_ids
         self.level2_post_norm = bool(level2_post_norm)
         self.res_post_norm = bool(res_post_norm)
+        self.dw_kernel_size = int(dw_kernel_size) if dw_kernel_size is not None else 3
+        self.center_feature_scale = bool(center_feature_scale)
         self.offset_scale = float(offset_scale)
+        self.has_level_norm = (not post_norm) or bool(center_feature_scale)      # II:497, 516
         self.has_layer_scale = layer_scale is not None
         self.layer_scale = float(layer_scale) if layer_scale is not None else None
         self.kernel_size = 3
@@ -173,7 +174,10 @@ class InternImage(nn.Module):
                     _put(self, p + "gamma1", self.layer_scale * torch.ones(C))
                     _put(self, p + "gamma2", self.layer_scale * torch.ones(C))
                 ln(p + "norm1.0", C)
-                w, b = conv(C, C, 3, groups=C)
+                if self.center_feature_scale:      # (own parameters of the DCNv3 module: ahead of its sub-modules in the state dict; DCNM:168-172: zeros)
+                    _put(self, p + "dcn.center_feature_scale_proj_weight", torch.zeros(G, C))
+                    _put(self, p + "dcn.center_feature_scale_proj_bias", torch.zeros(G))
+                w, b = conv(C, C, self.dw_kernel_size, groups=C)
                 _put(self, p + "dcn.dw_conv.0.weight", w)
                 _put(self, p + "dcn.dw_conv.0.bias", b)
                 ln(p + "dcn.dw_conv.1.1", C)
@@ -191,7 +195,7 @@ class InternImage(nn.Module):
                 if self.res_post_norm:
                     ln(p + "res_post_norm1.0", C)
                     ln(p + "res_post_norm2.0", C)
-            if not self.post_norm:                       # II:497-498: the level's closing norm of the pre-norm forms
+            if self.has_level_norm:                      # II:497-498: the level's closing norm of the pre-norm forms (and of center_feature_scale models)
                 ln("levels.%d.norm.0" % i, C)
             for k in range(len(self.post_norm_ids(i))):   # II:499-502
                 ln("levels.%d.post_norms.%d.0" % (i, k), C)

@@ -503,6 +503,117 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ sr
 
 inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Depth-wise k x k convolution for any odd k (InternImage-H/G's dw_kernel_size, DCNM:124, 146-151), channels-last, stride 1, "same" padding: the plain forms --
+// a lane = (pixel, 4 channels), a loop over the taps.  (The 3 x 3 kernels above are the fast path every MTP configuration runs.)
+template <typename T, bool DX>
+__global__ __launch_bounds__(256) void dwconvk_kernel(const T* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, float* __restrict__ dx,
+                                                     int accumulate, int H, int W, int C, int k, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c4n = C >> 2, c = (int)(idx % c4n) * 4;
+    const int64_t pix = idx / c4n;
+    const int wo = (int)(pix % W);
+    const int64_t t = pix / W;
+    const int ho = (int)(t % H);
+    const int64_t n = t / H;
+    const int p = (k - 1) >> 1, kk = k * k;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!DX && bias) acc = *reinterpret_cast<const float4*>(bias + c);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+            // forward: y[h][w] += w[i][j] x[h + i - p][w + j - p];   data gradient: dx[h][w] += w[i][j] dy[h - i + p][w - j + p]
+            const int hh = DX ? ho - i + p : ho + i - p, ww = DX ? wo - j + p : wo + j - p;
+            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            const float4 v = load4(src + ((n * H + hh) * W + ww) * C + c);
+            const int tp = i * k + j;
+            acc.x += w[(c + 0) * kk + tp] * v.x; acc.y += w[(c + 1) * kk + tp] * v.y; acc.z += w[(c + 2) * kk + tp] * v.z; acc.w += w[(c + 3) * kk + tp] * v.w;
+        }
+    if (DX) {
+        float* d = dx + pix * C + c;
+        if (accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(d);
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        *reinterpret_cast<float4*>(d) = acc;
+    } else {
+        store4(y + pix * C + c, acc);
+    }
+}
+// weight / bias gradient: grid (column blocks, row blocks, taps); block = 64 four-channel columns x 4 row lanes; f32 atomics into dw (C, 1, k, k) and db (C)
+template <typename T>
+__global__ __launch_bounds__(256) void dwconvk_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int H, int W, int C, int k,
+                                                        int64_t pixels, int64_t rows_per_block) {
+    __shared__ float4 red[4][64];
+    __shared__ float4 redb[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + cx) * 4;
+    const int tp = blockIdx.z, i = tp / k, j = tp - i * k, p = (k - 1) >> 1;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < pixels ? r1 : pixels;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+        for (int64_t r = r0 + ry; r < r1; r += 4) {
+            const int wo = (int)(r % W);
+            const int64_t t = r / W;
+            const int ho = (int)(t % H);
+            const int64_t n = t / H;
+            const float4 g = load4(dy + r * C + c);
+            if (tp == 0) { sb.x += g.x; sb.y += g.y; sb.z += g.z; sb.w += g.w; }
+            const int hh = ho + i - p, ww = wo + j - p;
+            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            const float4 v = load4(x + ((n * H + hh) * W + ww) * C + c);
+            s.x += g.x * v.x; s.y += g.y * v.y; s.z += g.z * v.z; s.w += g.w * v.w;
+        }
+    }
+    red[ry][cx] = s;
+    redb[ry][cx] = sb;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 a = red[q][cx], b = redb[q][cx];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            sb.x += b.x; sb.y += b.y; sb.z += b.z; sb.w += b.w;
+        }
+        const int kk = k * k;
+        atomicAdd(dw + (c + 0) * kk + tp, s.x); atomicAdd(dw + (c + 1) * kk + tp, s.y); atomicAdd(dw + (c + 2) * kk + tp, s.z); atomicAdd(dw + (c + 3) * kk + tp, s.w);
+        if (tp == 0 && db) { atomicAdd(db + c, sb.x); atomicAdd(db + c + 1, sb.y); atomicAdd(db + c + 2, sb.z); atomicAdd(db + c + 3, sb.w); }
+    }
+}
+
+// center_feature_scale (InternImage-H/G, DCNM:209-215):  out = y (1 - s) + xp s,  s[row][group] = sigmoid(logits[row][group]) shared by the group's channels.
+// A lane = (row, group).  Backward: dy = dout (1 - s);  dxp (f32) = dout s;  dlogits = s (1 - s) sum_c dout_c (xp_c - y_c), pad columns zeroed.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void cfs_kernel(const T* __restrict__ a0, const T* __restrict__ y, const T* __restrict__ xp, const T* __restrict__ logits, int64_t ld,
+                                                 T* __restrict__ out, float* __restrict__ dxp, T* __restrict__ dlogits, int G, int GC, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    const int64_t row = idx / G;
+    const int64_t e0 = (row * G + g) * GC;
+    const float s = 1.0f / (1.0f + __expf(-Elem<T>::load(logits + row * ld + g)));
+    if (!BWD) {
+        for (int c = 0; c < GC; c += 4) {
+            const float4 u = load4(y + e0 + c), v = load4(xp + e0 + c);
+            store4(out + e0 + c, make_float4(u.x + s * (v.x - u.x), u.y + s * (v.y - u.y), u.z + s * (v.z - u.z), u.w + s * (v.w - u.w)));
+        }
+    } else {
+        float acc = 0.f;
+        for (int c = 0; c < GC; c += 4) {
+            const float4 d = load4(a0 + e0 + c), u = load4(y + e0 + c), v = load4(xp + e0 + c);
+            acc += d.x * (v.x - u.x) + d.y * (v.y - u.y) + d.z * (v.z - u.z) + d.w * (v.w - u.w);
+            store4(out + e0 + c, make_float4(d.x * (1.f - s), d.y * (1.f - s), d.z * (1.f - s), d.w * (1.f - s)));
+            *reinterpret_cast<float4*>(dxp + e0 + c) = make_float4(d.x * s, d.y * s, d.z * s, d.w * s);
+        }
+        Elem<T>::store(dlogits + row * ld + g, acc * s * (1.f - s));
+        if (g == 0)
+            for (int64_t q = G; q < ld; ++q) Elem<T>::store(dlogits + row * ld + q, 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int mtp_im2col3x3(const void* x, int x_dtype, int64_t sN, int64_t sH, int64_t sW, int64_t sC, void* cols, int cols_dtype,
@@ -710,6 +821,63 @@ extern "C" int mtp_copy_rows(const void* src, int64_t src_ld, void* dst, int64_t
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MTP_BF16) hipLaunchKernelGGL((copy_rows_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)src, src_ld, (bf16_t*)dst, dst_ld, n, total);
     else if (dtype == MTP_F32) hipLaunchKernelGGL((copy_rows_kernel<float>), grid, block, 0, s, (const float*)src, src_ld, (float*)dst, dst_ld, n, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+/* ---- depth-wise k x k convolution, any odd k (InternImage-H/G: dw_kernel_size, ops_dcnv3/modules/dcnv3.py:124,146-151) -- the plain forms; k = 3 callers use the
+ * mtp_dwconv3x3_* entries.  w (C, 1, k, k) f32.  bwd_dw ACCUMULATES into dw / db (f32 atomics): clear them first. */
+extern "C" int mtp_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int dtype, int64_t N, int64_t H, int64_t W, int64_t C, int k, mtp_stream_t stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) || k < 1 || !(k & 1) || k > 15) return MTP_ERR_ARG;
+    const int64_t total = N * H * W * (C / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconvk_kernel<bf16_t, false>), dim3(blocks_for(total)), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)y, (float*)nullptr, 0, (int)H, (int)W, (int)C, k, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconvk_kernel<float, false>), dim3(blocks_for(total)), dim3(256), 0, s, (const float*)x, w, bias, (float*)y, (float*)nullptr, 0, (int)H, (int)W, (int)C, k, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+extern "C" int mtp_dwconv_bwd_dx(const void* dy, int dtype, const float* w, float* dx, int accumulate, int64_t N, int64_t H, int64_t W, int64_t C, int k, mtp_stream_t stream) {
+    if (!dy || !w || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) || k < 1 || !(k & 1) || k > 15) return MTP_ERR_ARG;
+    const int64_t total = N * H * W * (C / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconvk_kernel<bf16_t, true>), dim3(blocks_for(total)), dim3(256), 0, s, (const bf16_t*)dy, w, (const float*)nullptr, (bf16_t*)nullptr, dx, accumulate, (int)H, (int)W, (int)C, k, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconvk_kernel<float, true>), dim3(blocks_for(total)), dim3(256), 0, s, (const float*)dy, w, (const float*)nullptr, (float*)nullptr, dx, accumulate, (int)H, (int)W, (int)C, k, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+extern "C" int mtp_dwconv_bwd_dw(const void* dy, const void* x, int dtype, float* dw, float* db, int64_t N, int64_t H, int64_t W, int64_t C, int k, mtp_stream_t stream) {
+    if (!dy || !x || !dw || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) || k < 1 || !(k & 1) || k > 15) return MTP_ERR_ARG;
+    const int64_t pixels = N * H * W;
+    int64_t rb = (pixels + 511) / 512;
+    rb = rb < 256 ? rb : 256;
+    const int64_t rpb = ((pixels + rb - 1) / rb + 3) / 4 * 4;
+    const dim3 grid((unsigned)((C / 4 + 63) / 64), (unsigned)((pixels + rpb - 1) / rpb), (unsigned)(k * k)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((dwconvk_dw_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)x, dw, db, (int)H, (int)W, (int)C, k, pixels, rpb);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((dwconvk_dw_kernel<float>), grid, block, 0, s, (const float*)dy, (const float*)x, dw, db, (int)H, (int)W, (int)C, k, pixels, rpb);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+
+/* ---- center_feature_scale (InternImage-H/G; ops_dcnv3/modules/dcnv3.py:209-215): out (rows, G * GC) = y (1 - s) + xp s with s = sigmoid(logits[row][group]) (logits:
+ * rows of ld >= G elements, the G-output Linear on the depth-wise branch).  bwd: dy (`dtype`) = dout (1 - s); dxp (f32) = dout s; dlogits (rows of ld, pad columns
+ * zeroed) = s (1 - s) sum over the group's channels of dout (xp - y). */
+extern "C" int mtp_center_feature_scale_fwd(const void* y, const void* xp, const void* logits, int64_t ld, void* out, int dtype, int64_t rows, int64_t G, int64_t GC, mtp_stream_t stream) {
+    if (!y || !xp || !logits || !out || rows <= 0 || G <= 0 || GC <= 0 || (GC % 4) || ld < G) return MTP_ERR_ARG;
+    const int64_t total = rows * G;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((cfs_kernel<bf16_t, false>), dim3(blocks_for(total)), dim3(256), 0, s, (const bf16_t*)nullptr, (const bf16_t*)y, (const bf16_t*)xp, (const bf16_t*)logits, ld, (bf16_t*)out, (float*)nullptr, (bf16_t*)nullptr, (int)G, (int)GC, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((cfs_kernel<float, false>), dim3(blocks_for(total)), dim3(256), 0, s, (const float*)nullptr, (const float*)y, (const float*)xp, (const float*)logits, ld, (float*)out, (float*)nullptr, (float*)nullptr, (int)G, (int)GC, total);
+    else return MTP_ERR_UNSUPPORTED;
+    return mtp_launch_status();
+}
+extern "C" int mtp_center_feature_scale_bwd(const void* dout, const void* y, const void* xp, const void* logits, int64_t ld, void* dy, float* dxp, void* dlogits, int dtype, int64_t rows,
+                                            int64_t G, int64_t GC, mtp_stream_t stream) {
+    if (!dout || !y || !xp || !logits || !dy || !dxp || !dlogits || rows <= 0 || G <= 0 || GC <= 0 || (GC % 4) || ld < G) return MTP_ERR_ARG;
+    const int64_t total = rows * G;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTP_BF16) hipLaunchKernelGGL((cfs_kernel<bf16_t, true>), dim3(blocks_for(total)), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)xp, (const bf16_t*)logits, ld, (bf16_t*)dy, dxp, (bf16_t*)dlogits, (int)G, (int)GC, total);
+    else if (dtype == MTP_F32) hipLaunchKernelGGL((cfs_kernel<float, true>), dim3(blocks_for(total)), dim3(256), 0, s, (const float*)dout, (const float*)y, (const float*)xp, (const float*)logits, ld, (float*)dy, dxp, (float*)dlogits, (int)G, (int)GC, total);
     else return MTP_ERR_UNSUPPORTED;
     return mtp_launch_status();
 }

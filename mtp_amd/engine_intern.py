@@ -224,7 +224,11 @@ class InternEngine:
         Pn = K * K
         d = pre + "dcn."
         xp = self._linear(xa, d + "input_proj.weight", P[d + "input_proj.bias"])
-        x1c = ops.dwconv3x3_fwd(xa, P[d + "dw_conv.0.weight"], P[d + "dw_conv.0.bias"], self._e(rows, C), N, H, W)
+        kd = self.m.dw_kernel_size
+        if kd == 3:
+            x1c = ops.dwconv3x3_fwd(xa, P[d + "dw_conv.0.weight"], P[d + "dw_conv.0.bias"], self._e(rows, C), N, H, W)
+        else:      # InternImage-H/G: a k x k depth-wise kernel (plain kernels)
+            x1c = ops.dwconv_fwd(xa, P[d + "dw_conv.0.weight"], P[d + "dw_conv.0.bias"], self._e(rows, C), N, H, W, kd)
         x1, m0, r0 = self._ln(x1c, P, d + "dw_conv.1.1", gelu=True)
         off = self._linear(x1, d + "offset.weight", P[d + "offset.bias"])
         logits = self._linear(x1, d + "mask.weight", P[d + "mask.bias"], padded_out=True)
@@ -232,8 +236,12 @@ class InternEngine:
         pad = K // 2
         y = dcn.dcnv3_forward(xp.view(N, H, W, C), off.view(N, H, W, -1), mask.view(N, H, W, -1), K, K, 1, 1, pad, pad, 1, 1, G, C // G,
                               self.m.offset_scale, 256).view(rows, C)
-        h = self._linear(y, d + "output_proj.weight", P[d + "output_proj.bias"])
-        return h, dict(xa=xa, xp=xp, x1c=x1c, m0=m0, r0=r0, x1=x1, off=off, mask=mask, y=y, h=h)
+        cfl = y2 = None
+        if self.m.center_feature_scale:      # DCNM:209-215: x = x (1 - s) + x_proj s, s = sigmoid(Linear_G(x1)) per group
+            cfl = self._linear(x1, d + "center_feature_scale_proj_weight", P[d + "center_feature_scale_proj_bias"], padded_out=True)
+            y2 = ops.center_feature_scale_fwd(y, xp, cfl, self._e(rows, C), G)
+        h = self._linear(y2 if y2 is not None else y, d + "output_proj.weight", P[d + "output_proj.bias"])
+        return h, dict(xa=xa, xp=xp, x1c=x1c, m0=m0, r0=r0, x1=x1, off=off, mask=mask, y=y, h=h, cfl=cfl, y2=y2)
 
     def _mlp_fwd(self, pre, xab):
         """MLPLayer: fc1 -> GELU -> fc2 (dropout p = 0); fc1 stores gelu'(u) next to gelu(u) for the backward"""
@@ -322,8 +330,13 @@ class InternEngine:
         Pn = K * K
         d = pre + "dcn."
         Lo = self._lin[d + "output_proj.weight"]
-        self._wq.add(dh, c["y"], Gd[d + "output_proj.weight"], Gd[d + "output_proj.bias"])
+        self._wq.add(dh, c["y2"] if c.get("y2") is not None else c["y"], Gd[d + "output_proj.weight"], Gd[d + "output_proj.bias"])
         dy = ops.gemm_nt(dh, Lo.wt, self._e(rows, C))
+        dxs = dcl = None
+        if c.get("cfl") is not None:      # center_feature_scale: dy -> the DCNv3 core's share, the input projection's share (f32, added below) and the gate's logits
+            Lc = self._lin[d + "center_feature_scale_proj_weight"]
+            dxs, dcl = self._e(rows, C, dtype=F32), self._e(rows, Lc.Rp if Lc.padded else Lc.R)
+            dy = ops.center_feature_scale_bwd(dy, c["y"], c["xp"], c["cfl"], self._e(rows, C), dxs, dcl, G)
         pad = K // 2
         Lf, Lm = self._lin[d + "offset.weight"], self._lin[d + "mask.weight"]
         doffa = None
@@ -341,17 +354,29 @@ class InternEngine:
         self._wgrad(dlog, c["x1"], d + "mask.weight", Gd)
         dx1 = ops.gemm_nt(doffa, Lf.wt, self._e(rows, C, dtype=F32))
         dx1 = ops.gemm_nt(dlog, Lm.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx1)
+        if dcl is not None:
+            self._wgrad(dcl, c["x1"], d + "center_feature_scale_proj_weight", Gd)
+            dx1 = ops.gemm_nt(dcl, self._lin[d + "center_feature_scale_proj_weight"].wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=dx1)
         dx1c = self._ln_bwd(dx1, c["x1c"], c["m0"], c["r0"], P, Gd, d + "dw_conv.1.1", gelu=True)      # (f32 dy, ACT x / dx: no cast pass)
-        ops.dwconv3x3_bwd_dw(dx1c, c["xa"], Gd[d + "dw_conv.0.weight"], Gd[d + "dw_conv.0.bias"], N, H, W, accumulate=True)
+        kd = self.m.dw_kernel_size
+        if kd == 3:
+            ops.dwconv3x3_bwd_dw(dx1c, c["xa"], Gd[d + "dw_conv.0.weight"], Gd[d + "dw_conv.0.bias"], N, H, W, accumulate=True)
+        else:
+            ops.dwconv_bwd_dw(dx1c, c["xa"], Gd[d + "dw_conv.0.weight"], Gd[d + "dw_conv.0.bias"], N, H, W, kd)
         # input_proj -> d(x); plus the depth-wise branch and the residual path
         Li = self._lin[d + "input_proj.weight"]
+        if dxs is not None:
+            ops.axpy(dxp.view(rows, C), dxs)      # + the gate's share of the projected input's gradient
         dxpa = self._to_act(dxp.view(rows, C))
         self._wq.add(dxpa, c["xa"], Gd[d + "input_proj.weight"], Gd[d + "input_proj.bias"])
         if res is not None:
             dxin = ops.gemm_nt(dxpa, Li.wt, self._e(rows, C, dtype=F32), epi=ops.EPI_BIAS_RES, res=res)
         else:
             dxin = ops.gemm_nt(dxpa, Li.wt, self._e(rows, C, dtype=F32))
-        ops.dwconv3x3_bwd_dx(dx1c, P[d + "dw_conv.0.weight"], dxin, N, H, W, accumulate=True)
+        if kd == 3:
+            ops.dwconv3x3_bwd_dx(dx1c, P[d + "dw_conv.0.weight"], dxin, N, H, W, accumulate=True)
+        else:
+            ops.dwconv_bwd_dx(dx1c, P[d + "dw_conv.0.weight"], dxin, N, H, W, kd, accumulate=True)
         return dxin
 
     def _layer_bwd(self, pre, c, dx32, N, H, W, C, G, Gd):
@@ -449,7 +474,7 @@ class InternEngine:
                     xa = None
                     pn_saved[j] = sv if save else None
             lnorm = None
-            if not m.post_norm:      # the pre-norm forms close a level with its own LayerNorm (II:516-517); the taps are taken behind it
+            if m.has_level_norm:      # the pre-norm forms (and center_feature_scale models) close a level with its own LayerNorm (II:516-517); the taps are taken behind it
                 x32, sv = self._norm_f32(x32, "levels.%d.norm.0" % i)
                 xa = None
                 lnorm = sv if save else None

@@ -852,6 +852,36 @@ def dwconv3x3_bwd_dw(dy, x, dw, db, N, H, W, accumulate=False):
     _reduce_pair(part, 9 * Cc, dw, db, accumulate)
 
 
+def dwconv_fwd(x, w, b, y, N, H, W, k):
+    """depth-wise k x k (any odd k; InternImage-H/G's dw_kernel_size): w (C, 1, k, k) f32"""
+    check(lib().mtp_dwconv_fwd(_p(x), _f32(w), _f32(b), _p(y), _dt(x), N, H, W, x.shape[-1], int(k), _s()), "mtp_dwconv_fwd")
+    return y
+
+
+def dwconv_bwd_dx(dy, w, dx, N, H, W, k, accumulate=False):
+    check(lib().mtp_dwconv_bwd_dx(_p(dy), _dt(dy), _f32(w), _f32(dx), int(accumulate), N, H, W, dy.shape[-1], int(k), _s()), "mtp_dwconv_bwd_dx")
+    return dx
+
+
+def dwconv_bwd_dw(dy, x, dw, db, N, H, W, k):
+    """dw (C, 1, k, k) / db (C,) f32 += the weight / bias gradient (f32 atomics: accumulates)"""
+    check(lib().mtp_dwconv_bwd_dw(_p(dy), _p(x), _dt(dy), _f32(dw), _f32(db), N, H, W, dy.shape[-1], int(k), _s()), "mtp_dwconv_bwd_dw")
+
+
+def center_feature_scale_fwd(y, xp, logits, out, G):
+    rows, Cc = y.shape
+    check(lib().mtp_center_feature_scale_fwd(_p(y), _p(xp), _p(logits), logits.shape[1], _p(out), _dt(y), rows, G, Cc // G, _s()), "mtp_center_feature_scale_fwd")
+    return out
+
+
+def center_feature_scale_bwd(dout, y, xp, logits, dy, dxp, dlogits, G):
+    rows, Cc = y.shape
+    assert dlogits.shape == logits.shape
+    check(lib().mtp_center_feature_scale_bwd(_p(dout), _p(y), _p(xp), _p(logits), logits.shape[1], _p(dy), _f32(dxp), _p(dlogits), _dt(y), rows, G, Cc // G, _s()),
+          "mtp_center_feature_scale_bwd")
+    return dy
+
+
 def softmax_groups_fwd(logits, prob, G, P):
     rows = logits.shape[0]
     check(lib().mtp_softmax_groups_fwd(_p(logits), logits.shape[1], _p(prob), _dt(logits), rows, G, P, _s()), "mtp_softmax_groups_fwd")

@@ -5,7 +5,7 @@ layers around it are plain torch modules in the reference ("II" = /root/referenc
 "DCNM" = .../backbone/ops_dcnv3/modules/dcnv3.py).  This file restates them channels-last, from a flat parameter dict with the
 reference's state-dict keys, for norm_layer='LN', act_layer='GELU': the configuration family BASELINE config 5 uses (II:700-712:
 layer_scale set, post_norm=True) and, since round 6, the other layer branches (pre-norm, no layer scale, res_post_norm, level-2 post
-norms); not center_feature_scale / dw_kernel_size.
+norms, center_feature_scale, dw_kernel_size).
 The DCNv3 core inside is oracle/dcnv3_oracle.py (explicit bilinear gather), so gradients flow through torch autograd.
 
 PINNED: tests/golden/f12_internimage.npz (and f15_internimage_variants.npz for the other branches) = outputs and gradients of the
@@ -23,7 +23,7 @@ EPS = 1e-6   # build_norm_layer default (II:39-43, DCNM:37-41)
 
 
 def state_shapes(channels=192, depths=(5, 5, 24, 5), groups=(12, 24, 48, 96), mlp_ratio=4.0, kernel_size=3, post_norm=True, layer_scale=True,
-                 res_post_norm=False, level2_post_norm_block_ids=None):
+                 res_post_norm=False, level2_post_norm_block_ids=None, dw_kernel_size=None, center_feature_scale=False):
     """reference state-dict keys and shapes in the reference's order (own parameters of a module before its sub-modules'): the defaults are the
     layer_scale + post_norm family of BASELINE config 5; the other branches of II:407-427 / II:497-502 by the keyword flags (fixture f15)"""
     s = {}
@@ -47,7 +47,10 @@ def state_shapes(channels=192, depths=(5, 5, 24, 5), groups=(12, 24, 48, 96), ml
                 s[p + "gamma2"] = (C,)
             s[p + "norm1.0.weight"] = (C,)
             s[p + "norm1.0.bias"] = (C,)
-            s[p + "dcn.dw_conv.0.weight"] = (C, 1, kernel_size, kernel_size)
+            if center_feature_scale:                        # DCNM:168-172: own parameters of the module, ahead of its sub-modules
+                s[p + "dcn.center_feature_scale_proj_weight"] = (G, C)
+                s[p + "dcn.center_feature_scale_proj_bias"] = (G,)
+            s[p + "dcn.dw_conv.0.weight"] = (C, 1, dw_kernel_size or kernel_size, dw_kernel_size or kernel_size)
             s[p + "dcn.dw_conv.0.bias"] = (C,)
             s[p + "dcn.dw_conv.1.1.weight"] = (C,)
             s[p + "dcn.dw_conv.1.1.bias"] = (C,)
@@ -69,7 +72,7 @@ def state_shapes(channels=192, depths=(5, 5, 24, 5), groups=(12, 24, 48, 96), ml
                 for k in (1, 2):
                     s[p + "res_post_norm%d.0.weight" % k] = (C,)
                     s[p + "res_post_norm%d.0.bias" % k] = (C,)
-        if not post_norm:                                   # II:497-498
+        if not post_norm or center_feature_scale:           # II:497-498
             s["levels.%d.norm.0.weight" % i] = (C,)
             s["levels.%d.norm.0.bias" % i] = (C,)
         if level2_post_norm_block_ids and i == 2:           # II:499-502, 593-594
@@ -125,6 +128,10 @@ def dcnv3_module(x, p, pre, group, offset_scale, kernel_size=3):
         PROBE["min_edge_distance"] = min(PROBE.get("min_edge_distance", 1.0), d)
         PROBE["calls"] = PROBE.get("calls", 0) + 1
     y = D.dcnv3_forward(xp, offset, mask, kernel_size, kernel_size, 1, 1, pad, pad, 1, 1, group, C // group, offset_scale, 0)
+    if (pre + "center_feature_scale_proj_weight") in p:      # DCNM:80-88, 209-215: a per-group gate between the sampled and the projected features
+        sc = torch.sigmoid(F.linear(x1, p[pre + "center_feature_scale_proj_weight"], p[pre + "center_feature_scale_proj_bias"]))
+        sc = sc[..., None].expand(N, H, W, group, C // group).reshape(N, H, W, C)
+        y = y * (1 - sc) + xp * sc
     return F.linear(y, p[pre + "output_proj.weight"], p[pre + "output_proj.bias"])
 
 
@@ -156,7 +163,7 @@ def downsample(x, p, pre):
     return _ln(_conv_nhwc(x, p[pre + "conv.weight"], None, 2), p, pre + "norm.1")
 
 
-def backbone_forward(img, p, depths, groups, offset_scale=2.0, out_indices=(0, 1, 2, 3), post_norm=True, level2_post_norm_block_ids=None):
+def backbone_forward(img, p, depths, groups, offset_scale=2.0, out_indices=(0, 1, 2, 3), post_norm=True, level2_post_norm_block_ids=None):      # (the level norm is applied when its parameters exist)
     """InternImage.forward II:690-698 (+ InternImageBlock.forward II:509-525: the level-2 post norms behind their blocks, the level's closing norm of the
     pre-norm forms): list of NCHW maps at strides 4, 8, 16, 32 taken before each level's downsample"""
     x = stem(img, p)
@@ -167,7 +174,7 @@ def backbone_forward(img, p, depths, groups, offset_scale=2.0, out_indices=(0, 1
             x = layer(x, p, "levels.%d.blocks.%d." % (i, j), G, offset_scale, post_norm)
             if j in ids:
                 x = _ln(x, p, "levels.2.post_norms.%d.0" % ids.index(j))
-        if not post_norm:
+        if ("levels.%d.norm.0.weight" % i) in p:      # II:516-517: `not post_norm or center_feature_scale`
             x = _ln(x, p, "levels.%d.norm.0" % i)
         if i in out_indices:
             outs.append(x.permute(0, 3, 1, 2).contiguous())

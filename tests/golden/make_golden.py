@@ -438,7 +438,8 @@ def f15():
                     drop_path_rate=0.0, norm_layer="LN", offset_scale=cfg["offset_scale"], with_cp=False, out_indices=(0, 1, 2, 3), **kw)
         sd = net.state_dict()
         shapes = IO.state_shapes(cfg["channels"], cfg["depths"], cfg["groups"], post_norm=kw["post_norm"], layer_scale=kw["layer_scale"] is not None,
-                                 res_post_norm=kw.get("res_post_norm", False), level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"))
+                                 res_post_norm=kw.get("res_post_norm", False), level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"),
+                                 dw_kernel_size=kw.get("dw_kernel_size"), center_feature_scale=kw.get("center_feature_scale", False))
         assert list(sd.keys()) == list(shapes.keys()), "state_shapes() order/names differ from the reference (%s)" % name
         for k, v in sd.items():
             assert tuple(v.shape) == tuple(shapes[k]), k
@@ -453,7 +454,8 @@ def f15():
                 "levels.2.blocks.0.norm2.0.bias", "levels.2.blocks.1.dcn.input_proj.weight", "levels.0.downsample.conv.weight", "levels.3.blocks.0.mlp.fc2.bias",
                 "levels.3.blocks.0.dcn.output_proj.weight"]
         keep += [k for k in ("levels.0.blocks.0.gamma1", "levels.2.blocks.1.gamma2", "levels.1.norm.0.weight", "levels.3.norm.0.bias", "levels.2.post_norms.0.0.weight",
-                             "levels.2.blocks.0.res_post_norm1.0.weight", "levels.3.blocks.0.res_post_norm2.0.bias") if k in grads]
+                             "levels.2.blocks.0.res_post_norm1.0.weight", "levels.3.blocks.0.res_post_norm2.0.bias",
+                             "levels.0.blocks.0.dcn.center_feature_scale_proj_weight", "levels.2.blocks.1.dcn.center_feature_scale_proj_bias") if k in grads]
         out[name + ".keys"] = np.array(list(sd.keys()))
         out[name + ".shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
         out[name + ".grad_img"] = img.grad.float()           # (stored as float32: the float64 run's own error against an exact evaluation is 1e-5, see f12)

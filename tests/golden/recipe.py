@@ -131,14 +131,21 @@ II_VARIANTS = {
     "postnorm_nols": dict(post_norm=True, layer_scale=None),                                   # II:409-411
     "respostnorm_l2": dict(post_norm=False, layer_scale=None, res_post_norm=True, level2_post_norm=True, level2_post_norm_block_ids=[0]),   # II:412-414, 512-515 (H/G)
 }
-II_VARIANT_SEEDS = {"prenorm_ls": 26, "prenorm": 33, "postnorm_nols": 32, "respostnorm_l2": 50}
+II_VARIANTS["hg_full"] = dict(post_norm=False, layer_scale=None, res_post_norm=True, level2_post_norm=True, level2_post_norm_block_ids=[0], dw_kernel_size=5,
+                              center_feature_scale=True)                                     # every InternImage-H/G switch together (DCNM:124, 168-173, 209-215)
+II_VARIANTS["postnorm_cfs"] = dict(post_norm=True, layer_scale=0.5, center_feature_scale=True, dw_kernel_size=7)      # the level norm that center_feature_scale adds to post-norm models (II:497, 516)
+II_VARIANT_SEEDS = {"prenorm_ls": 26, "prenorm": 33, "postnorm_nols": 32, "respostnorm_l2": 50, "hg_full": 41, "postnorm_cfs": 42}
 
 
 def internimage_variant_params(shapes, seed=77):
     """f15's parameters: f12's recipe with the offset heads at a quarter of its scale (offsets of +-3 px instead of +-12).  With LayerNorms right behind the
     branches and no layer scale < 1 (postnorm_nols, respostnorm_l2) the unscaled recipe is ill-conditioned on the 4 x 4 and 2 x 2 maps -- the oracle's own float32
     run is 2e-3 away from its float64 run in single gradients, 1e-5 with this scale -- and a fixture that cannot tell 2e-3 from right is no check"""
-    return {k: (0.25 * v if ".dcn.offset." in k else v) for k, v in internimage_params(shapes, seed).items()}
+    out = {k: (0.25 * v if ".dcn.offset." in k else v) for k, v in internimage_params(shapes, seed).items()}
+    for k in out:      # the gate's Linear (zero-initialised in the reference): scaled like the mask head so that the gates really differ
+        if k.endswith("center_feature_scale_proj_weight"):
+            out[k] = 0.2 * torch.randn(out[k].shape, generator=torch.Generator().manual_seed(seed * 7919 + zlib.crc32(k.encode()) % 7919))
+    return out
 
 
 def internimage_params(shapes, seed=77):

@@ -22,7 +22,8 @@ VARIANTS = recipe.II_VARIANTS
 
 def variant_shapes(kw):
     return IO.state_shapes(CFG["channels"], CFG["depths"], CFG["groups"], post_norm=kw["post_norm"], layer_scale=kw["layer_scale"] is not None,
-                           res_post_norm=kw.get("res_post_norm", False), level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"))
+                           res_post_norm=kw.get("res_post_norm", False), level2_post_norm_block_ids=kw.get("level2_post_norm_block_ids"),
+                           dw_kernel_size=kw.get("dw_kernel_size"), center_feature_scale=kw.get("center_feature_scale", False))
 
 
 def rel(a, b):
@@ -71,10 +72,8 @@ def test_hip_backbone_class_has_the_reference_state_dict_and_init_rules():
     assert float(sd["levels.0.blocks.0.mlp.fc1.weight"].abs().max()) <= 2.0 and 0.01 < float(sd["levels.0.blocks.0.mlp.fc1.weight"].std()) < 0.03
     assert len(net.drop_path_rates) == sum(CFG["depths"]) and net.drop_path_rates[0] == 0.0 and abs(net.drop_path_rates[-1] - 0.2) < 1e-6
     assert mtp_amd.MODELS.get("InternImage") is mtp_amd.InternImage
-    with pytest.raises(NotImplementedError):
-        mtp_amd.InternImage(layer_scale=1.0, post_norm=True, center_feature_scale=True)
-    with pytest.raises(NotImplementedError):
-        mtp_amd.InternImage(layer_scale=1.0, post_norm=True, dw_kernel_size=5)
+    with pytest.raises(ValueError):
+        mtp_amd.InternImage(layer_scale=1.0, post_norm=True, dw_kernel_size=4)       # even depth-wise kernels have no "same" padding (DCNM:150)
     with pytest.raises(ValueError):
         mtp_amd.InternImage(layer_scale=1.0, post_norm=False, res_post_norm=True)      # (the reference would silently ignore res_post_norm here, II:408-427)
     with pytest.raises(RuntimeError):
@@ -132,7 +131,7 @@ def test_layer_variants_oracle_and_class_surface_vs_reference(name):
     flat = FlatParams(net, unused=net._unused_params)
     gids = [flat.groups[m] for m in flat.names]
     assert gids == sorted(gids, reverse=True) and gids[-1] == -1
-    if not kw["post_norm"]:
+    if not kw["post_norm"] or kw.get("center_feature_scale"):
         assert flat.groups["levels.1.norm.0.weight"] == flat.groups["levels.1.blocks.0.mlp.fc1.weight"]
     if kw.get("level2_post_norm"):
         assert flat.groups["levels.2.post_norms.0.0.weight"] == flat.groups["levels.2.blocks.0.mlp.fc1.weight"]
