@@ -66,3 +66,43 @@ def pytest_sessionfinish(session, exitstatus):
             old = {}
     old.update(_PARITY)
     json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+
+
+def spawn_ranks(worker, world, extra_args=(), deadline=600):
+    """start `world` processes `worker(rank, world, port, queue, *extra_args)` on a free rendezvous port and collect one queue item per rank.  Up to three attempts:
+    the port is picked, released and bound again by rank 0 a moment later -- on a busy machine another process can take it in between (EADDRINUSE).  A worker that
+    dies BEFORE reporting is retried on a fresh port; one that reports is not (its checks are the test's business)."""
+    import multiprocessing as mp
+    import queue as _queue
+    import socket
+    import time
+    ctx = mp.get_context("spawn")
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=worker, args=(r, world, port, q) + tuple(extra_args)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res, t0, died = [], time.time(), False
+        while len(res) < world:
+            try:
+                res.append(q.get(timeout=5))
+            except _queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    died = True
+                    break
+                assert time.time() - t0 < deadline, "workers neither reported nor exited in %d s" % deadline
+        if died:
+            for p in procs:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.kill()
+            assert attempt < 2, "a worker died before reporting, three times in a row"
+            continue
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        return res

@@ -85,17 +85,8 @@ def _worker(rank, world, port, q, native=False, mode="allreduce", bf16=False):
 
 
 def _run(world, native=False, mode="allreduce", bf16=False):
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, native, mode, bf16)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=600) for _ in range(world))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    return res
+    from conftest import spawn_ranks
+    return sorted(spawn_ranks(_worker, world, (native, mode, bf16)))
 
 
 def test_forced_comm_single_rank_rccl_side_stream():

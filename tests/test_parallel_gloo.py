@@ -176,16 +176,8 @@ def _worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 3, 8])      # 8 = the node BASELINE's headline names; 3 does not divide the bucket lengths (rs_ag falls back per bucket)
 def test_bucketed_allreduce_equals_single_allreduce(world):
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    from conftest import spawn_ranks
+    res = spawn_ranks(_worker, world, deadline=300)
     assert sorted(res) == [(r, True, True) for r in range(world)]
 
 
@@ -212,14 +204,6 @@ def _sync_worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 8])
 def test_trainer_synchronises_replicas(world):
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    from conftest import spawn_ranks
+    res = spawn_ranks(_sync_worker, world, deadline=300)
     assert sorted(res) == [(r, True) for r in range(world)]
